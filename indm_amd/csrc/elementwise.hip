@@ -1,0 +1,288 @@
+// HBM-bound elementwise / permutation kernels (fp32, float4-vectorised, grid-stride).
+//   * Sin activation of the residual-flow g-net and its derivative in ONE pass
+//     (flow_models/wolf/flows/resflow/layers/base/activations.py:7-12)
+//   * SiLU / ELU, axpby, mul, per-image dot products (Hutchinson traces, iresblock.py:253-273)
+//   * nearest x2 upsample / 2x2 mean downsample (models/up_or_down_sampling.py:59-69)
+//   * squeeze / unsqueeze space-to-depth (flows/resflow/layers/squeeze.py:27-45) in NHWC
+//   * NCHW <-> NHWC layout conversion at the API edge
+//   * Lop weight normalisation (layers/base/lipschitz.py:350-359) on RSCK weights
+#include "indm_common.h"
+
+namespace {
+
+constexpr float TWO_PI = 6.283185307179586f;
+constexpr float INV_TWO_PI = 0.15915494309189535f;
+
+template <typename F>
+__global__ __launch_bounds__(256) void ew_kernel(long n, F f) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) f(i);
+}
+template <typename F>
+int ew_launch(long n, hipStream_t st, F f) {
+  if (n <= 0) return INDM_OK;
+  hipLaunchKernelGGL(ew_kernel<F>, dim3(ew_grid(n, 256)), dim3(256), 0, st, n, f);
+  if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+  return INDM_OK;
+}
+
+// per-image reduction: out[b] = alpha * sum_i f(i) over D contiguous elements; one block per (b, chunk)
+template <int MODE>
+__global__ __launch_bounds__(256) void rowreduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                        float* __restrict__ part, long D, int chunks) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y, c = blockIdx.x;
+  const long per = ((D + chunks - 1) / chunks + 3) & ~3L;
+  const long i0 = (long)c * per, i1 = min(D, i0 + per);
+  const float* xb = x + (long)b * D;
+  const float* yb = y ? y + (long)b * D : nullptr;
+  float s = 0.f;
+  for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float a = xb[i];
+    if (MODE == 0) s += a * yb[i];
+    else if (MODE == 1) s += a * a;
+    else s += a;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[(long)b * chunks + c] = s;
+}
+__global__ void rowreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int chunks,
+                                       float alpha) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(long)b * chunks + c];
+  out[b] = alpha * s;
+}
+
+// Lop normalisation over RSCK weight viewed as [R, Co]: per-column L1 norm.
+__global__ __launch_bounds__(256) void lop_colnorm_kernel(const float* __restrict__ w, float* __restrict__ l1, int R,
+                                                          int Co) {
+  // one block per 64 columns; 4 row-lanes x 64 col-lanes
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < Co)
+    for (int r = rl; r < R; r += 4) s += fabsf(w[(long)r * Co + c]);
+  sh[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < Co) l1[c] = sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63];
+}
+// dot[c] = sum_r dwn[r,c]*w[r,c]
+__global__ __launch_bounds__(256) void lop_coldot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, int R, int Co) {
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < Co)
+    for (int r = rl; r < R; r += 4) s += a[(long)r * Co + c] * b[(long)r * Co + c];
+  sh[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < Co) out[c] = sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63];
+}
+
+}  // namespace
+
+// a = sin(2*pi*p)/(2*pi), d = cos(2*pi*p)   (d may be null)
+INDM_API int indm_sincos_act_fwd_f32(const float* p, float* a, float* d, long n, void* stream) {
+  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) {
+    float s, c;
+    sincosf(TWO_PI * p[i], &s, &c);
+    a[i] = s * INV_TWO_PI;
+    if (d) d[i] = c;
+  });
+}
+// dp = da * d + dd * (-4*pi^2 * a)   (da / dd may be null)
+INDM_API int indm_sincos_act_bwd_f32(const float* da, const float* dd, const float* a, const float* d, float* dp,
+                                     long n, void* stream) {
+  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) {
+    float g = 0.f;
+    if (da) g += da[i] * d[i];
+    if (dd) g -= dd[i] * (TWO_PI * TWO_PI) * a[i];
+    dp[i] = g;
+  });
+}
+
+// act: 1 = SiLU, 2 = ELU(alpha=1)
+INDM_API int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream) {
+  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) {
+    const float u = x[i];
+    y[i] = act == 1 ? u / (1.f + expf(-u)) : (u > 0.f ? u : expm1f(u));
+  });
+}
+INDM_API int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream) {
+  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) {
+    const float u = x[i];
+    float g;
+    if (act == 1) {
+      const float s = 1.f / (1.f + expf(-u));
+      g = s * (1.f + u * (1.f - s));
+    } else {
+      g = u > 0.f ? 1.f : expf(u);
+    }
+    dx[i] = dy[i] * g;
+  });
+}
+
+// out = a*x + b*y   (y may be null)
+INDM_API int indm_axpby_f32(const float* x, const float* y, float* out, float a, float b, long n, void* stream) {
+  if ((n & 3) == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)y) & 15) == 0) {
+    const float4* x4 = (const float4*)x;
+    const float4* y4 = (const float4*)y;
+    float4* o4 = (float4*)out;
+    return ew_launch(n >> 2, (hipStream_t)stream, [=] __device__(long i) {
+      float4 v = x4[i];
+      v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+      if (y4) {
+        const float4 w = y4[i];
+        v.x += b * w.x; v.y += b * w.y; v.z += b * w.z; v.w += b * w.w;
+      }
+      o4[i] = v;
+    });
+  }
+  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) { out[i] = a * x[i] + (y ? b * y[i] : 0.f); });
+}
+
+// out = alpha * x * y
+INDM_API int indm_mul_f32(const float* x, const float* y, float* out, float alpha, long n, void* stream) {
+  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) { out[i] = alpha * x[i] * y[i]; });
+}
+
+// out[b, j] = x[b, j] * s[b] (+ bias)
+INDM_API int indm_scale_rows_f32(const float* x, const float* s, float* out, long B, long D, void* stream) {
+  return ew_launch(B * D, (hipStream_t)stream, [=] __device__(long i) { out[i] = x[i] * s[i / D]; });
+}
+
+INDM_API long indm_rowreduce_ws_floats(long B, long D) {
+  int chunks = (int)((D + 8191) / 8192);
+  if (chunks < 1) chunks = 1;
+  return B * chunks;
+}
+// out[b] = alpha * reduce_i f(x[b,i], y[b,i]); mode 0: x*y, 1: x*x, 2: x
+INDM_API int indm_rowreduce_f32(const float* x, const float* y, float* out, long B, long D, int mode, float alpha,
+                                float* ws, void* stream) {
+  if (B <= 0) return INDM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int chunks = (int)((D + 8191) / 8192);
+  if (chunks < 1) chunks = 1;
+  dim3 grid(chunks, (unsigned)B);
+  if (mode == 0) hipLaunchKernelGGL(rowreduce_kernel<0>, grid, dim3(256), 0, st, x, y, ws, D, chunks);
+  else if (mode == 1) hipLaunchKernelGGL(rowreduce_kernel<1>, grid, dim3(256), 0, st, x, y, ws, D, chunks);
+  else hipLaunchKernelGGL(rowreduce_kernel<2>, grid, dim3(256), 0, st, x, y, ws, D, chunks);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rowreduce_final_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, ws, out, (int)B, chunks, alpha);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+// nearest-neighbour x2 upsample, NHWC: y[n,2h+a,2w+b,c] = alpha * x[n,h,w,c]
+INDM_API int indm_upsample2x_f32(const float* x, float* y, int N, int H, int W, int C, float alpha, void* stream) {
+  const long total = (long)N * 4 * H * W * C;
+  return ew_launch(total, (hipStream_t)stream, [=] __device__(long i) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ow = (int)(r % (2 * W));
+    r /= 2 * W;
+    const int oh = (int)(r % (2 * H));
+    const int n = (int)(r / (2 * H));
+    y[i] = alpha * x[(((long)n * H + (oh >> 1)) * W + (ow >> 1)) * C + c];
+  });
+}
+// 2x2 sum-pool scaled by alpha (alpha = 0.25 -> mean), NHWC
+INDM_API int indm_downsample2x_f32(const float* x, float* y, int N, int H, int W, int C, float alpha, void* stream) {
+  const int OH = H / 2, OW = W / 2;
+  const long total = (long)N * OH * OW * C;
+  return ew_launch(total, (hipStream_t)stream, [=] __device__(long i) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ow = (int)(r % OW);
+    r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const float* b = x + (((long)n * H + 2 * oh) * W + 2 * ow) * C + c;
+    y[i] = alpha * (b[0] + b[C] + b[(long)W * C] + b[(long)W * C + C]);
+  });
+}
+
+// squeeze (space-to-depth x2) in NHWC with the reference's channel order c*4 + dy*2 + dx:
+//   y[n, h, w, c*4+dy*2+dx] = x[n, 2h+dy, 2w+dx, c];   x: [N,H,W,C] -> y: [N,H/2,W/2,4C]
+INDM_API int indm_squeeze2x_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  const long total = (long)N * H * W * C;
+  const int OH = H / 2, OW = W / 2;
+  return ew_launch(total, (hipStream_t)stream, [=] __device__(long i) {  // i indexes y
+    const int co = (int)(i % (4 * C));
+    long r = i / (4 * C);
+    const int w = (int)(r % OW);
+    r /= OW;
+    const int h = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int c = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+    y[i] = x[(((long)n * H + 2 * h + dy) * W + 2 * w + dx) * C + c];
+  });
+}
+// inverse of the above: x: [N,H,W,4C] -> y: [N,2H,2W,C]
+INDM_API int indm_unsqueeze2x_f32(const float* x, float* y, int N, int H, int W, int C4, void* stream) {
+  const int C = C4 / 4;
+  const long total = (long)N * H * W * C4;
+  return ew_launch(total, (hipStream_t)stream, [=] __device__(long i) {  // i indexes y [N,2H,2W,C]
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ow = (int)(r % (2 * W));
+    r /= 2 * W;
+    const int oh = (int)(r % (2 * H));
+    const int n = (int)(r / (2 * H));
+    y[i] = x[(((long)n * H + (oh >> 1)) * W + (ow >> 1)) * C4 + c * 4 + (oh & 1) * 2 + (ow & 1)];
+  });
+}
+
+// layout conversion at the API edge: NCHW -> NHWC (dir 0) or NHWC -> NCHW (dir 1)
+INDM_API int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, int dir, void* stream) {
+  const long total = (long)N * C * HW;
+  return ew_launch(total, (hipStream_t)stream, [=] __device__(long i) {
+    if (dir == 0) {  // i indexes y [N,HW,C]
+      const int c = (int)(i % C);
+      const long r = i / C;
+      const int p = (int)(r % HW);
+      const int n = (int)(r / HW);
+      y[i] = x[((long)n * C + c) * HW + p];
+    } else {  // i indexes y [N,C,HW]
+      const int p = (int)(i % HW);
+      const long r = i / HW;
+      const int c = (int)(r % C);
+      const int n = (int)(r / C);
+      y[i] = x[((long)n * HW + p) * C + c];
+    }
+  });
+}
+
+// Lop normalisation forward: wn[r,c] = w[r,c] / max(1, l1[c]/coeff);  l1[c] = sum_r |w[r,c]|
+INDM_API int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff,
+                                        void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lop_colnorm_kernel, dim3(cdiv(Co, 64)), dim3(256), 0, st, w, l1, R, Co);
+  INDM_CHECK_LAUNCH();
+  return ew_launch((long)R * Co, st, [=] __device__(long i) {
+    const int c = (int)(i % Co);
+    wn[i] = w[i] / fmaxf(1.f, l1[c] / coeff);
+  });
+}
+// backward: dw = dwn/f - [l1/coeff > 1] * sign(w) * dot[c] / (f^2 * coeff), dot[c] = sum_r dwn*w
+INDM_API int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const float* l1, float* dw, float* dot,
+                                        int R, int Co, float coeff, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lop_coldot_kernel, dim3(cdiv(Co, 64)), dim3(256), 0, st, dwn, w, dot, R, Co);
+  INDM_CHECK_LAUNCH();
+  return ew_launch((long)R * Co, st, [=] __device__(long i) {
+    const int c = (int)(i % Co);
+    const float s = l1[c] / coeff;
+    const float f = fmaxf(1.f, s);
+    float g = dwn[i] / f;
+    if (s > 1.f) {
+      const float wv = w[i];
+      const float sg = wv > 0.f ? 1.f : (wv < 0.f ? -1.f : 0.f);
+      g -= sg * dot[c] / (f * f * coeff);
+    }
+    dw[i] = g;
+  });
+}

@@ -1,0 +1,443 @@
+// HBM-bound normalisation / activation kernels (NHWC fp32) for gfx950.
+//   * GroupNorm (+ optional SiLU, + optional Philox dropout) forward / backward
+//     - reference: nn.GroupNorm(min(C/4,32), C, eps=1e-6) + nn.SiLU + nn.Dropout,
+//       models/layerspp.py:232-279, models/layers.py:38-39
+//   * row softmax forward / backward (attention logits, models/layerspp.py:95-99)
+//   * column reductions (bias grads, BatchNorm statistics)
+// Layout: activations are [N, HW, C] with C contiguous, so every wave reads whole 256 B+
+// rows (float4 per lane); group statistics use wavefront shuffles + one LDS hop.
+#include "indm_common.h"
+
+namespace {
+
+constexpr int GN_SPLIT_TARGET = 1024;  // aim for >= this many workgroups
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.f + __expf(-u)); }
+__device__ __forceinline__ float silu_grad(float u) {
+  const float s = 1.f / (1.f + __expf(-u));
+  return s * (1.f + u * (1.f - s));
+}
+
+__device__ __forceinline__ float dropout_keep(uint64_t seed, uint64_t idx4, int lane_in4, float p) {
+  // one Philox call yields the 4 uniforms of an aligned float4 group
+  uint4 r = philox4x32(make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)),
+                       make_uint4((uint32_t)idx4, (uint32_t)(idx4 >> 32), 0u, 0u));
+  const uint32_t v = lane_in4 == 0 ? r.x : lane_in4 == 1 ? r.y : lane_in4 == 2 ? r.z : r.w;
+  return u32_to_unit(v) > p ? 1.f / (1.f - p) : 0.f;
+}
+
+// ---- pass 1: partial sums per (n, split, group) ---------------------------------
+// grid (S, N); each block owns HW/S pixels of one image; thread owns channel-quad
+// c4 = tid % (C/4) and strides over pixels.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                        int HW, int C, int G, int S) {
+  extern __shared__ float sh[];  // [2][pstride][C] per-thread partials, reduced in a fixed order
+  const int n = blockIdx.y, s = blockIdx.x;
+  const int C4 = C >> 2;
+  const int cpg = C / G;
+  const int p_per = (HW + S - 1) / S;
+  const int p0 = s * p_per, p1 = min(HW, p0 + p_per);
+  const float* xn = x + (long)n * HW * C;
+  const int c4 = threadIdx.x % C4;
+  const int prow = threadIdx.x / C4, pstride = blockDim.x / C4;
+  float* sh1 = sh;
+  float* sh2 = sh + pstride * C;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (prow < pstride) {
+    for (int p = p0 + prow; p < p1; p += pstride) {
+      const float4 v = *(const float4*)(xn + (long)p * C + c4 * 4);
+      s1[0] += v.x; s2[0] += v.x * v.x;
+      s1[1] += v.y; s2[1] += v.y * v.y;
+      s1[2] += v.z; s2[2] += v.z * v.z;
+      s1[3] += v.w; s2[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sh1[prow * C + c4 * 4 + i] = s1[i];
+      sh2[prow * C + c4 * 4 + i] = s2[i];
+    }
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < pstride; ++r)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        a += sh1[r * C + c];
+        b += sh2[r * C + c];
+      }
+    part[((long)(n * S + s)) * 2 * G + g] = a;
+    part[((long)(n * S + s)) * 2 * G + G + g] = b;
+  }
+}
+
+// ---- finalize: mean / rstd per (n, g) ---------------------------------------------
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                   float* __restrict__ rstd, int NG, int G, int S, float inv_cnt, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NG) return;
+  const int n = i / G, g = i - n * G;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < S; ++s) {
+    a += part[((long)(n * S + s)) * 2 * G + g];
+    b += part[((long)(n * S + s)) * 2 * G + G + g];
+  }
+  const float m = a * inv_cnt;
+  float var = b * inv_cnt - m * m;
+  var = fmaxf(var, 0.f);
+  mean[i] = m;
+  rstd[i] = rsqrtf(var + eps);
+}
+
+// ---- pass 2: normalise + affine (+SiLU) (+dropout) --------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ y,
+                                                        long total4, int HW, int C, int G, int act, float drop_p,
+                                                        uint64_t seed) {
+  const int C4 = C >> 2;
+  const int cpg = C / G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long pix = i / C4;
+    const int n = (int)(pix / HW);
+    const float4 v = *(const float4*)(x + i * 4);
+    const float4 gm = *(const float4*)(gamma + c4 * 4);
+    const float4 bt = *(const float4*)(beta + c4 * 4);
+    float in[4] = {v.x, v.y, v.z, v.w};
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+    const float btv[4] = {bt.x, bt.y, bt.z, bt.w};
+    float out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int g = (c4 * 4 + k) / cpg;
+      const float m = mean[n * G + g], r = rstd[n * G + g];
+      float u = (in[k] - m) * r * gmv[k] + btv[k];
+      if (act == 1) u = silu_f(u);
+      if (drop_p > 0.f) u *= dropout_keep(seed, (uint64_t)i, k, drop_p);
+      out[k] = u;
+    }
+    *(float4*)(y + i * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// ---- backward pass 1: per (n,split): group sums + per-channel dgamma/dbeta partials ----
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ gpart, float* __restrict__ cpart, int HW,
+                                                            int C, int G, int S, int act, float drop_p, uint64_t seed) {
+  extern __shared__ float sh[];  // [2][pstride][C] partials, then [2][C] channel sums
+  const int n = blockIdx.y, s = blockIdx.x;
+  const int C4 = C >> 2, cpg = C / G;
+  const int p_per = (HW + S - 1) / S;
+  const int p0 = s * p_per, p1 = min(HW, p0 + p_per);
+  const long base = (long)n * HW * C;
+  const int c4 = threadIdx.x % C4;
+  const int prow = threadIdx.x / C4, pstride = blockDim.x / C4;
+  float* sh1 = sh;
+  float* sh2 = sh + pstride * C;
+  float* ch = sh + 2 * pstride * C;  // [2][C]
+  if (prow < pstride) {
+    const float4 gm = *(const float4*)(gamma + c4 * 4);
+    const float4 bt = *(const float4*)(beta + c4 * 4);
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+    const float btv[4] = {bt.x, bt.y, bt.z, bt.w};
+    float mg[4], rg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int g = (c4 * 4 + k) / cpg;
+      mg[k] = mean[n * G + g];
+      rg[k] = rstd[n * G + g];
+    }
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};  // sum dyu, sum dyu*xhat (per channel)
+    for (int p = p0 + prow; p < p1; p += pstride) {
+      const long off = base + (long)p * C + c4 * 4;
+      const float4 xv = *(const float4*)(x + off);
+      const float4 dv = *(const float4*)(dy + off);
+      const float xi[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float di[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (xi[k] - mg[k]) * rg[k];
+        float d = di[k];
+        if (drop_p > 0.f) d *= dropout_keep(seed, (uint64_t)(off >> 2), k, drop_p);
+        if (act == 1) d *= silu_grad(xh * gmv[k] + btv[k]);
+        a1[k] += d;
+        a2[k] += d * xh;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sh1[prow * C + c4 * 4 + k] = a1[k];
+      sh2[prow * C + c4 * 4 + k] = a2[k];
+    }
+  }
+  __syncthreads();
+  const long blk = (long)(n * S + s);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < pstride; ++r) {
+      a += sh1[r * C + c];
+      b += sh2[r * C + c];
+    }
+    ch[c] = a;
+    ch[C + c] = b;
+    cpart[blk * 2 * C + c] = a;      // dbeta partial
+    cpart[blk * 2 * C + C + c] = b;  // dgamma partial
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      a += ch[c] * gamma[c];      // sum gamma*dyu
+      b += ch[C + c] * gamma[c];  // sum gamma*dyu*xhat
+    }
+    gpart[blk * 2 * G + g] = a;
+    gpart[blk * 2 * G + G + g] = b;
+  }
+}
+
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ gpart, const float* __restrict__ cpart,
+                                       float* __restrict__ gsum, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int N, int C, int G, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N * G) {
+    const int n = i / G, g = i - n * G;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < S; ++s) {
+      a += gpart[((long)(n * S + s)) * 2 * G + g];
+      b += gpart[((long)(n * S + s)) * 2 * G + G + g];
+    }
+    gsum[2 * i] = a;
+    gsum[2 * i + 1] = b;
+  }
+  if (i < C) {
+    float db = 0.f, dg = 0.f;
+    for (int b = 0; b < N * S; ++b) {
+      db += cpart[(long)b * 2 * C + i];
+      dg += cpart[(long)b * 2 * C + C + i];
+    }
+    dbeta[i] = db;
+    dgamma[i] = dg;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gsum, float* __restrict__ dx,
+                                                            long total4, int HW, int C, int G, int act, float drop_p,
+                                                            uint64_t seed, float inv_cnt) {
+  const int C4 = C >> 2, cpg = C / G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long pix = i / C4;
+    const int n = (int)(pix / HW);
+    const float4 xv = *(const float4*)(x + i * 4);
+    const float4 dv = *(const float4*)(dy + i * 4);
+    const float4 gm = *(const float4*)(gamma + c4 * 4);
+    const float4 bt = *(const float4*)(beta + c4 * 4);
+    const float xi[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float di[4] = {dv.x, dv.y, dv.z, dv.w};
+    const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+    const float btv[4] = {bt.x, bt.y, bt.z, bt.w};
+    float out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int g = (c4 * 4 + k) / cpg;
+      const float m = mean[n * G + g], r = rstd[n * G + g];
+      const float xh = (xi[k] - m) * r;
+      float d = di[k];
+      if (drop_p > 0.f) d *= dropout_keep(seed, (uint64_t)i, k, drop_p);
+      if (act == 1) d *= silu_grad(xh * gmv[k] + btv[k]);
+      const float s1 = gsum[2 * (n * G + g)] * inv_cnt, s2 = gsum[2 * (n * G + g) + 1] * inv_cnt;
+      out[k] = r * (gmv[k] * d - s1 - xh * s2);
+    }
+    *(float4*)(dx + i * 4) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
+// ---- softmax over the last dim (T <= 1024), one wavefront per row -------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           long rows, int T, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * T;
+  float* yr = y + row * T;
+  float v[16];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    v[j] = c < T ? xr[c] * scale : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    v[j] = c < T ? expf(v[j] - mx) : 0.f;
+    s += v[j];
+  }
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    if (c < T) yr[c] = v[j] * inv;
+  }
+}
+
+// dx = scale * y * (dy - sum(dy*y))
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           float* __restrict__ dx, long rows, int T, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* dr = dy + row * T;
+  const float* yr = y + row * T;
+  float a[16], b[16];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    a[j] = c < T ? dr[c] : 0.f;
+    b[j] = c < T ? yr[c] : 0.f;
+    s += a[j] * b[j];
+  }
+  s = wave_sum(s);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + j * 64;
+    if (c < T) dx[row * T + c] = scale * b[j] * (a[j] - s);
+  }
+}
+
+// ---- column reductions over a [R, C] matrix ------------------------------------------
+// mode 0: sum x ; mode 1: sum x*y ; mode 2: sum x^2.  Two-stage, deterministic.
+__global__ __launch_bounds__(256) void colreduce_part_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              float* __restrict__ part, long R, int C, int mode,
+                                                              long rows_per_block) {
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const float v = x[r * C + c];
+      s += mode == 0 ? v : mode == 1 ? v * y[r * C + c] : v * v;
+    }
+    part[(long)blockIdx.y * C + c] = s;
+  }
+}
+__global__ void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int P,
+                                       float alpha, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(long)p * C + c];
+  out[c] = alpha * s + (beta != 0.f ? beta * out[c] : 0.f);
+}
+
+int gn_split(int N, int HW) {
+  int S = (GN_SPLIT_TARGET + N - 1) / N;
+  if (S > HW / 4) S = HW / 4;
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  return S;
+}
+
+}  // namespace
+
+// Workspace (floats) needed by the GroupNorm entry points.
+INDM_API long indm_groupnorm_ws_floats(int N, int HW, int C, int G) {
+  const int S = gn_split(N, HW);
+  return (long)N * S * (2 * G + 2 * C) + 2L * N * G + 16;
+}
+
+// y = dropout(act(GroupNorm(x)));  x,y: [N, HW, C];  mean,rstd: [N, G] (saved for backward)
+INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                    float* mean, float* rstd, int N, int HW, int C, int G, float eps, int act,
+                                    float drop_p, unsigned long long seed, float* ws, void* stream) {
+  if (N <= 0) return INDM_OK;
+  if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / 4) > 256) return INDM_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = gn_split(N, HW);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(S, N), dim3(256), 2 * (256 / (C / 4)) * C * sizeof(float), st, x, ws, HW, C, G, S);
+  INDM_CHECK_LAUNCH();
+  const float inv_cnt = 1.f / ((float)HW * (float)(C / G));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, st, ws, mean, rstd, N * G, G, S,
+                     inv_cnt, eps);
+  INDM_CHECK_LAUNCH();
+  const long total4 = (long)N * HW * C / 4;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, st, x, gamma, beta, mean, rstd, y,
+                     total4, HW, C, G, act, drop_p, (uint64_t)seed);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+INDM_API int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                                    const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                                    int N, int HW, int C, int G, int act, float drop_p, unsigned long long seed,
+                                    float* ws, void* stream) {
+  if (N <= 0) return INDM_OK;
+  if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / 4) > 256) return INDM_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const int S = gn_split(N, HW);
+  float* gpart = ws;
+  float* cpart = gpart + (long)N * S * 2 * G;
+  float* gsum = cpart + (long)N * S * 2 * C;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(S, N), dim3(256), (2 * (256 / (C / 4)) * C + 2 * C) * sizeof(float), st, dy, x, gamma,
+                     beta, mean, rstd, gpart, cpart, HW, C, G, S, act, drop_p, (uint64_t)seed);
+  INDM_CHECK_LAUNCH();
+  const int nfin = N * G > C ? N * G : C;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(nfin, 256)), dim3(256), 0, st, gpart, cpart, gsum, dgamma,
+                     dbeta, N, C, G, S);
+  INDM_CHECK_LAUNCH();
+  const long total4 = (long)N * HW * C / 4;
+  const float inv_cnt = 1.f / ((float)HW * (float)(C / G));
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, st, dy, x, gamma, beta, mean,
+                     rstd, gsum, dx, total4, HW, C, G, act, drop_p, (uint64_t)seed, inv_cnt);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+// y[r,:] = softmax(scale * x[r,:]), T <= 1024
+INDM_API int indm_softmax_fwd_f32(const float* x, float* y, long rows, int T, float scale, void* stream) {
+  if (rows <= 0) return INDM_OK;
+  if (T <= 0 || T > 1024) return INDM_E_SHAPE;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, T, scale);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+INDM_API int indm_softmax_bwd_f32(const float* dy, const float* y, float* dx, long rows, int T, float scale,
+                                  void* stream) {
+  if (rows <= 0) return INDM_OK;
+  if (T <= 0 || T > 1024) return INDM_E_SHAPE;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, rows, T,
+                     scale);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+INDM_API long indm_colreduce_ws_floats(long R, int C) {
+  long P = (R + 255) / 256;
+  if (P > 512) P = 512;
+  if (P < 1) P = 1;
+  return P * C;
+}
+// out[c] = alpha * sum_r f(x[r,c], y[r,c]) + beta*out[c]; mode 0: x, 1: x*y, 2: x*x
+INDM_API int indm_colreduce_f32(const float* x, const float* y, float* out, long R, int C, int mode, float alpha,
+                                float beta, float* ws, void* stream) {
+  if (C <= 0) return INDM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  long P = (R + 255) / 256;
+  if (P > 512) P = 512;
+  if (P < 1) P = 1;
+  const long rpb = (R + P - 1) / P;
+  hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C, 256), (int)P), dim3(256), 0, st, x, y, ws, R, C, mode, rpb);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, ws, out, C, (int)P, alpha, beta);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}

@@ -1,0 +1,250 @@
+// Per-step fused kernels around the networks (all HBM-bound, fp32):
+//   * SDE perturbation  x_t = mean_coef[b]*x + std[b]*eps            (sde_lib.py:153-157, losses.py:103-105)
+//   * denoising-score-matching loss + its gradient                    (losses.py:106-118, models/utils.py:175-177)
+//   * predictor / corrector affine update  x' = a[b]*x + b[b]*s + c[b]*z  (sampling.py:186-210, 263-292)
+//   * Langevin step-size from batch-mean norms                         (sampling.py:284-288)
+//   * global grad-norm, clip + AdamW + EMA in one pass over flat buffers (losses.py:30-62, models/ema.py:32-51)
+// Per-image scalars (mean_coef, std, g, ...) are [B] device arrays produced by the host-side
+// SDE mirror (fp32, same op order as the reference) -- see DESIGN.md "SDE scalars".
+#include "indm_common.h"
+
+namespace {
+
+template <typename F>
+__global__ __launch_bounds__(256) void ew2_kernel(long n, F f) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) f(i);
+}
+template <typename F>
+int ew2_launch(long n, hipStream_t st, F f) {
+  if (n <= 0) return INDM_OK;
+  hipLaunchKernelGGL(ew2_kernel<F>, dim3(ew_grid(n, 256)), dim3(256), 0, st, n, f);
+  if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+  return INDM_OK;
+}
+
+// score from raw network output: kind 0 -> -out/std (VP, ddpm_score); kind 1 -> out (VE)
+__device__ __forceinline__ float score_of(float o, float sd, int kind) { return kind == 0 ? -o / sd : o; }
+
+// one block per (image, chunk): partial sums of the per-element DSM term
+__global__ __launch_bounds__(256) void dsm_loss_kernel(const float* __restrict__ out, const float* __restrict__ z,
+                                                        const float* __restrict__ std, float* __restrict__ part, long D,
+                                                        int chunks, int kind, int mode) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y, c = blockIdx.x;
+  const long per = ((D + chunks - 1) / chunks + 3) & ~3L;
+  const long i0 = (long)c * per, i1 = min(D, i0 + per);
+  const float sd = std[b];
+  float s = 0.f;
+  for (long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const float sc = score_of(out[(long)b * D + i], sd, kind);
+    const float e = mode == 0 ? sc * sd + z[(long)b * D + i] : sc + z[(long)b * D + i] / sd;
+    s += e * e;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[(long)b * chunks + c] = s;
+}
+__global__ void dsm_final_kernel(const float* __restrict__ part, const float* __restrict__ w, float* __restrict__ loss,
+                                 int B, int chunks, float red_scale) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(long)b * chunks + c];
+  loss[b] = w[b] * (s * red_scale);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_part_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  const float4* g4 = (const float4*)g;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = g4[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0)
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ part, int P, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) s += part[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[0] = s;
+}
+
+struct AdamArgs {
+  float lr, beta1, beta2, eps, wd, bc1, bc2s, clip, ema_omd, gscale;
+};
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ ema, long n, AdamArgs a,
+                                                         const float* __restrict__ gnorm_sq) {
+  // torch.nn.utils.clip_grad_norm_: coef = clip / (norm + 1e-6), clamped to 1
+  float coef = a.gscale;
+  if (a.clip >= 0.f && gnorm_sq) {
+    const float nrm = sqrtf(gnorm_sq[0]) * a.gscale;
+    const float cc = a.clip / (nrm + 1e-6f);
+    coef *= cc < 1.f ? cc : 1.f;
+  }
+  const long n4 = n >> 2;
+  float4* p4 = (float4*)p;
+  const float4* g4 = (const float4*)g;
+  float4* m4 = (float4*)m;
+  float4* v4 = (float4*)v;
+  float4* e4 = (float4*)ema;
+  auto upd = [&](float& pw, float gw, float& mw, float& vw, float* ew) {
+    gw *= coef;
+    pw *= 1.f - a.lr * a.wd;
+    mw = a.beta1 * mw + (1.f - a.beta1) * gw;
+    vw = a.beta2 * vw + (1.f - a.beta2) * gw * gw;
+    const float denom = sqrtf(vw) / a.bc2s + a.eps;
+    pw -= (a.lr / a.bc1) * (mw / denom);
+    if (ew) *ew -= a.ema_omd * (*ew - pw);
+  };
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const float4 gg = g4[i];
+    float4 ee = ema ? e4[i] : make_float4(0, 0, 0, 0);
+    upd(pp.x, gg.x, mm.x, vv.x, ema ? &ee.x : nullptr);
+    upd(pp.y, gg.y, mm.y, vv.y, ema ? &ee.y : nullptr);
+    upd(pp.z, gg.z, mm.z, vv.z, ema ? &ee.z : nullptr);
+    upd(pp.w, gg.w, mm.w, vv.w, ema ? &ee.w : nullptr);
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    if (ema) e4[i] = ee;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+      float pp = p[i], mm = m[i], vv = v[i], ee = ema ? ema[i] : 0.f;
+      upd(pp, g[i], mm, vv, ema ? &ee : nullptr);
+      p[i] = pp; m[i] = mm; v[i] = vv;
+      if (ema) ema[i] = ee;
+    }
+  }
+}
+
+// step[b] = (snr * mean_b||noise|| / mean_b||grad||)^2 * 2 * alpha[b]
+__global__ __launch_bounds__(256) void langevin_step_kernel(const float* __restrict__ gsq, const float* __restrict__ nsq,
+                                                             const float* __restrict__ alpha, float* __restrict__ step,
+                                                             float* __restrict__ noise_coef, int B, float snr) {
+  __shared__ float sh[16];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    a += sqrtf(gsq[i]);
+    b += sqrtf(nsq[i]);
+  }
+  a = block_sum(a, sh);
+  b = block_sum(b, sh);
+  const float gn = a / B, nn = b / B;
+  const float r = snr * nn / gn;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float s = r * r * 2.f * alpha[i];
+    step[i] = s;
+    noise_coef[i] = sqrtf(s * 2.f);
+  }
+}
+
+}  // namespace
+
+// out[b,:] = mc[b]*x[b,:] + sd[b]*noise[b,:]   (noise / sd may be null -> pure scaling)
+INDM_API int indm_sde_perturb_f32(const float* x, const float* noise, const float* mc, const float* sd, float* out,
+                                  long B, long D, void* stream) {
+  return ew2_launch(B * D, (hipStream_t)stream, [=] __device__(long i) {
+    const long b = i / D;
+    float v = mc[b] * x[i];
+    if (noise) v += sd[b] * noise[i];
+    out[i] = v;
+  });
+}
+
+INDM_API long indm_dsm_ws_floats(long B, long D) {
+  int chunks = (int)((D + 8191) / 8192);
+  if (chunks < 1) chunks = 1;
+  return B * chunks;
+}
+// loss[b] = w[b] * red( e^2 ),  e = score*std + z (mode 0)  |  score + z/std (mode 1)
+// score = -out/std (kind 0) | out (kind 1);  red = mean (reduce_mean=1) or sum over D
+INDM_API int indm_dsm_loss_fwd_f32(const float* out, const float* z, const float* std, const float* w, float* loss,
+                                   long B, long D, int kind, int mode, int reduce_mean, float* ws, void* stream) {
+  if (B <= 0) return INDM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int chunks = (int)((D + 8191) / 8192);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(dsm_loss_kernel, dim3(chunks, (unsigned)B), dim3(256), 0, st, out, z, std, ws, D, chunks, kind, mode);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dsm_final_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, ws, w, loss, (int)B, chunks,
+                     reduce_mean ? 1.f / (float)D : 1.f);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+// dout[b,i] = gl[b]*w[b]*red_scale * 2*e * de/dout
+INDM_API int indm_dsm_loss_bwd_f32(const float* gl, const float* out, const float* z, const float* std, const float* w,
+                                   float* dout, long B, long D, int kind, int mode, int reduce_mean, void* stream) {
+  const float rs = reduce_mean ? 1.f / (float)D : 1.f;
+  return ew2_launch(B * D, (hipStream_t)stream, [=] __device__(long i) {
+    const long b = i / D;
+    const float sd = std[b];
+    const float sc = score_of(out[i], sd, kind);
+    const float e = mode == 0 ? sc * sd + z[i] : sc + z[i] / sd;
+    const float dsc = kind == 0 ? -1.f / sd : 1.f;  // dscore/dout
+    const float de = mode == 0 ? dsc * sd : dsc;
+    dout[i] = gl[b] * w[b] * rs * 2.f * e * de;
+  });
+}
+
+// x_mean = a[b]*x + b[b]*s ;  x_new = x_mean + c[b]*z      (s, z, x_mean may be null)
+INDM_API int indm_affine_update_f32(const float* x, const float* s, const float* z, const float* a, const float* b,
+                                    const float* c, float* x_new, float* x_mean, long B, long D, void* stream) {
+  return ew2_launch(B * D, (hipStream_t)stream, [=] __device__(long i) {
+    const long r = i / D;
+    float m = a[r] * x[i];
+    if (s) m += b[r] * s[i];
+    if (x_mean) x_mean[i] = m;
+    if (x_new) x_new[i] = z ? m + c[r] * z[i] : m;
+  });
+}
+
+INDM_API int indm_langevin_step_f32(const float* grad_sq, const float* noise_sq, const float* alpha, float* step,
+                                    float* noise_coef, int B, float snr, void* stream) {
+  if (B <= 0) return INDM_OK;
+  hipLaunchKernelGGL(langevin_step_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, grad_sq, noise_sq, alpha, step,
+                     noise_coef, B, snr);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+#define INDM_SQNORM_BLOCKS 1024
+INDM_API long indm_sqnorm_ws_floats(void) { return INDM_SQNORM_BLOCKS; }
+// out[0] = sum g^2   (device scalar; no host sync)
+INDM_API int indm_sqnorm_f32(const float* g, long n, float* out, float* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (((uintptr_t)g & 15) != 0) return INDM_E_ARG;
+  int blocks = ew_grid(n >> 2, 256);
+  if (blocks > INDM_SQNORM_BLOCKS) blocks = INDM_SQNORM_BLOCKS;
+  hipLaunchKernelGGL(sqnorm_part_kernel, dim3(blocks), dim3(256), 0, st, g, n, ws);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, ws, blocks, out);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+// Fused  [grad *= gscale] -> clip_grad_norm_(clip) -> AdamW(step t) -> EMA  over flat fp32 buffers.
+// gnorm_sq: device scalar holding sum(g^2) of the UNSCALED grads (from indm_sqnorm_f32); clip < 0 disables.
+// ema may be null.  ema_one_minus_decay = 1-d for the already warmed-up decay d: s -= (1-d)*(s-p_new).
+INDM_API int indm_adamw_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int step, float clip,
+                                const float* gnorm_sq, float gscale, float ema_one_minus_decay, void* stream) {
+  if (n <= 0) return INDM_OK;
+  if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) != 0) return INDM_E_ARG;
+  AdamArgs a;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  a.clip = clip; a.ema_omd = ema_one_minus_decay; a.gscale = gscale;
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(ew_grid(n >> 2, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema,
+                     n, a, gnorm_sq);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}

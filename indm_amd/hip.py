@@ -1,0 +1,476 @@
+"""ctypes binding of libindm_hip.so (the C ABI in include/indm_hip.h).
+
+This is the ONLY compute backend of the package: every function here takes torch tensors that
+live in MI355X HBM, hands raw device pointers + the current HIP stream to a hand-written gfx950
+kernel and returns torch tensors.  There is no CPU / eager fallback -- a missing library or a
+non-GPU tensor raises immediately (tests/ may monkeypatch this module with a CPU emulation to
+exercise host logic; nothing in the package does).
+
+PyTorch's role is plumbing: device memory (torch.empty), streams, autograd bookkeeping.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libindm_hip.so")
+_lib = None
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_p = ctypes.c_void_p
+c_u64 = ctypes.c_ulonglong
+
+ERRORS = {-1: "INDM_E_SHAPE", -2: "INDM_E_DTYPE", -3: "INDM_E_LAUNCH", -4: "INDM_E_ARG"}
+
+# name -> argtypes (restype is int unless listed in _LONG_RET)
+_SIGS = {
+    "indm_gemm_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_l, c_l, c_l, c_f, c_p, c_p,
+                      c_i, c_p, c_l, c_l, c_f, c_p, c_l, c_p],
+    "indm_conv2d_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
+                            c_p, c_p, c_f, c_p],
+    "indm_conv2d_dgrad_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
+                              c_p],
+    "indm_conv2d_wgrad_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
+                              c_p, c_l, c_p],
+    "indm_groupnorm_ws_floats": [c_i, c_i, c_i, c_i],
+    "indm_groupnorm_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p],
+    "indm_groupnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64,
+                               c_p, c_p],
+    "indm_softmax_fwd_f32": [c_p, c_p, c_l, c_i, c_f, c_p],
+    "indm_softmax_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_f, c_p],
+    "indm_colreduce_ws_floats": [c_l, c_i],
+    "indm_colreduce_f32": [c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_f, c_p, c_p],
+    "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
+    "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
+    "indm_act_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
+    "indm_axpby_f32": [c_p, c_p, c_p, c_f, c_f, c_l, c_p],
+    "indm_mul_f32": [c_p, c_p, c_p, c_f, c_l, c_p],
+    "indm_scale_rows_f32": [c_p, c_p, c_p, c_l, c_l, c_p],
+    "indm_rowreduce_ws_floats": [c_l, c_l],
+    "indm_rowreduce_f32": [c_p, c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
+    "indm_upsample2x_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "indm_downsample2x_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "indm_squeeze2x_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "indm_unsqueeze2x_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "indm_nchw_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "indm_lop_normalize_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "indm_lop_normalize_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "indm_sde_perturb_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
+    "indm_dsm_ws_floats": [c_l, c_l],
+    "indm_dsm_loss_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p],
+    "indm_dsm_loss_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_p],
+    "indm_affine_update_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
+    "indm_langevin_step_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p],
+    "indm_sqnorm_ws_floats": [],
+    "indm_sqnorm_f32": [c_p, c_l, c_p, c_p, c_p],
+    "indm_adamw_ema_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p, c_f, c_f, c_p],
+    "indm_upfirdn2d_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                           c_p],
+    "indm_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
+}
+_LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_rowreduce_ws_floats",
+             "indm_dsm_ws_floats", "indm_sqnorm_ws_floats"}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
+
+
+def lib():
+    """Load libindm_hip.so once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"indm_amd: {_LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C indm_amd/csrc`. There is no CPU fallback.")
+        L = ctypes.CDLL(_LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_l if name in _LONG_RET else c_i
+        _lib = L
+    return _lib
+
+
+def available():
+    return os.path.exists(_LIB_PATH)
+
+
+def _chk(status, name):
+    if status != 0:
+        raise RuntimeError(f"{name} failed: {ERRORS.get(status, status)}")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("indm_amd.hip: tensor is not on the GPU; the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"indm_amd.hip: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("indm_amd.hip: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws_cache = {}
+
+
+def _ws(nfloats, device):
+    """Grow-only scratch buffer per device (stream-ordered reuse)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+SPLITK_WS_FLOATS = 1 << 25  # 128 MiB of fp32 partial slabs for weight-grad split-K
+
+
+# --------------------------------------------------------------------------- GEMM / conv
+def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, rows_per_group=1, res=None,
+         beta=1.0, splitk=False):
+    """C[(batch),M,N] = alpha * op(a) @ op(b) + bias[N] + bias2[M//rows_per_group, N] + beta*res.
+
+    a: [..,M,K] (or stored [..,K,M] when trans_a); b: [..,K,N] (or stored [..,N,K] when trans_b).
+    2-D operands broadcast over the batch of the other one.
+    """
+    ab = a.shape[0] if a.dim() == 3 else 1
+    bb = b.shape[0] if b.dim() == 3 else 1
+    batch = max(ab, bb)
+    am, ak = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    bk, bn = (b.shape[-1], b.shape[-2]) if trans_b else (b.shape[-2], b.shape[-1])
+    if ak != bk:
+        raise RuntimeError(f"gemm: inner dims differ {tuple(a.shape)} x {tuple(b.shape)}")
+    M, N, K = am, bn, ak
+    shape = (batch, M, N) if (a.dim() == 3 or b.dim() == 3) else (M, N)
+    out = torch.empty(shape, dtype=torch.float32, device=a.device)
+    sA = a.shape[-1] * a.shape[-2] if a.dim() == 3 else 0
+    sB = b.shape[-1] * b.shape[-2] if b.dim() == 3 else 0
+    ws = _ws(SPLITK_WS_FLOATS, a.device) if splitk else None
+    st = lib().indm_gemm_f32(_ptr(a), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
+                             b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
+                             _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
+                             _ptr(ws), SPLITK_WS_FLOATS if splitk else 0, _stream())
+    _chk(st, "indm_gemm_f32")
+    return out
+
+
+def conv_out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
+    """NHWC cross-correlation. x [N,H,W,Ci], w [KH,KW,Ci,Co] -> [N,OH,OW,Co] (+bias[Co] +bias2[N,Co] +beta*res)."""
+    N, H, W, Ci = x.shape
+    KH, KW, Ci2, Co = w.shape
+    if Ci != Ci2:
+        raise RuntimeError("conv2d: channel mismatch")
+    OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    y = torch.empty((N, OH, OW, Co), dtype=torch.float32, device=x.device)
+    st = lib().indm_conv2d_fwd_f32(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, KH, KW, stride, pad, 1, OH, OW,
+                                   alpha, _ptr(bias), _ptr(bias2), _ptr(res), beta, _stream())
+    _chk(st, "indm_conv2d_fwd_f32")
+    return y
+
+
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0):
+    """Gradient of conv2d w.r.t. its input (= transposed convolution). dy [N,OH,OW,Co], w [KH,KW,Ci,Co]
+    -> dx [N,H,W,Ci] with (H,W) = in_hw."""
+    N, OH, OW, Co = dy.shape
+    KH, KW, Ci, Co2 = w.shape
+    if Co != Co2:
+        raise RuntimeError("conv2d_dgrad: channel mismatch")
+    H, W = in_hw
+    dx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=dy.device)
+    st = lib().indm_conv2d_dgrad_f32(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride, H,
+                                     W, alpha, _ptr(res), beta, _stream())
+    _chk(st, "indm_conv2d_dgrad_f32")
+    return dx
+
+
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
+    """Gradient of conv2d w.r.t. its RSCK weight. x [N,H,W,Ci], dy [N,OH,OW,Co] -> [KH,KW,Ci,Co]."""
+    N, H, W, Ci = x.shape
+    _, OH, OW, Co = dy.shape
+    dw = torch.empty((kh, kw, Ci, Co), dtype=torch.float32, device=x.device)
+    ws = _ws(SPLITK_WS_FLOATS, x.device)
+    st = lib().indm_conv2d_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), N, H, W, Ci, Co, kh, kw, stride, pad, OH, OW,
+                                     alpha, None, 0.0, _ptr(ws), SPLITK_WS_FLOATS, _stream())
+    _chk(st, "indm_conv2d_wgrad_f32")
+    return dw
+
+
+# --------------------------------------------------------------------------- norms / softmax
+def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
+    """x [N,..spatial..,C] -> y, mean[N,G], rstd[N,G]. act: 0 none, 1 SiLU. dropout via Philox(seed)."""
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    mean = torch.empty((N, G), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ws = _ws(lib().indm_groupnorm_ws_floats(N, HW, C, G), x.device)
+    st = lib().indm_groupnorm_fwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), N, HW, C, G,
+                                      eps, act, drop_p, seed, _ptr(ws), _stream())
+    _chk(st, "indm_groupnorm_fwd_f32")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    ws = _ws(lib().indm_groupnorm_ws_floats(N, HW, C, G), x.device)
+    st = lib().indm_groupnorm_bwd_f32(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _ptr(ws), _stream())
+    _chk(st, "indm_groupnorm_bwd_f32")
+    return dx, dgamma, dbeta
+
+
+def softmax_fwd(x, scale=1.0):
+    y = torch.empty_like(x)
+    T = x.shape[-1]
+    _chk(lib().indm_softmax_fwd_f32(_ptr(x), _ptr(y), x.numel() // T, T, scale, _stream()), "indm_softmax_fwd_f32")
+    return y
+
+
+def softmax_bwd(dy, y, scale=1.0):
+    dx = torch.empty_like(y)
+    T = y.shape[-1]
+    _chk(lib().indm_softmax_bwd_f32(_ptr(dy), _ptr(y), _ptr(dx), y.numel() // T, T, scale, _stream()),
+         "indm_softmax_bwd_f32")
+    return dx
+
+
+def colreduce(x, y=None, mode=0, alpha=1.0):
+    """out[c] = alpha * sum over all leading dims of f(x, y); mode 0: x, 1: x*y, 2: x*x."""
+    C = x.shape[-1]
+    R = x.numel() // C
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().indm_colreduce_ws_floats(R, C), x.device)
+    _chk(lib().indm_colreduce_f32(_ptr(x), _ptr(y), _ptr(out), R, C, mode, alpha, 0.0, _ptr(ws), _stream()),
+         "indm_colreduce_f32")
+    return out
+
+
+# --------------------------------------------------------------------------- elementwise
+def sincos_fwd(p, want_d=True):
+    a = torch.empty_like(p)
+    d = torch.empty_like(p) if want_d else None
+    _chk(lib().indm_sincos_act_fwd_f32(_ptr(p), _ptr(a), _ptr(d), p.numel(), _stream()), "indm_sincos_act_fwd_f32")
+    return a, d
+
+
+def sincos_bwd(da, dd, a, d):
+    dp = torch.empty_like(a)
+    _chk(lib().indm_sincos_act_bwd_f32(_ptr(da), _ptr(dd), _ptr(a), _ptr(d), _ptr(dp), a.numel(), _stream()),
+         "indm_sincos_act_bwd_f32")
+    return dp
+
+
+ACT_SILU, ACT_ELU = 1, 2
+
+
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    _chk(lib().indm_act_fwd_f32(_ptr(x), _ptr(y), x.numel(), act, _stream()), "indm_act_fwd_f32")
+    return y
+
+
+def act_bwd(dy, x, act):
+    dx = torch.empty_like(x)
+    _chk(lib().indm_act_bwd_f32(_ptr(dy), _ptr(x), _ptr(dx), x.numel(), act, _stream()), "indm_act_bwd_f32")
+    return dx
+
+
+def axpby(x, y, a, b):
+    out = torch.empty_like(x)
+    _chk(lib().indm_axpby_f32(_ptr(x), _ptr(y), _ptr(out), a, b, x.numel(), _stream()), "indm_axpby_f32")
+    return out
+
+
+def mul(x, y, alpha=1.0):
+    out = torch.empty_like(x)
+    _chk(lib().indm_mul_f32(_ptr(x), _ptr(y), _ptr(out), alpha, x.numel(), _stream()), "indm_mul_f32")
+    return out
+
+
+def scale_rows(x, s):
+    """out[b, ...] = x[b, ...] * s[b]."""
+    out = torch.empty_like(x)
+    B = x.shape[0]
+    _chk(lib().indm_scale_rows_f32(_ptr(x), _ptr(s), _ptr(out), B, x.numel() // B, _stream()), "indm_scale_rows_f32")
+    return out
+
+
+def rowreduce(x, y=None, mode=0, alpha=1.0):
+    """out[b] = alpha * sum_i f(x[b,i], y[b,i]); mode 0: x*y, 1: x*x, 2: x."""
+    B = x.shape[0]
+    D = x.numel() // B
+    out = torch.empty((B,), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().indm_rowreduce_ws_floats(B, D), x.device)
+    _chk(lib().indm_rowreduce_f32(_ptr(x), _ptr(y), _ptr(out), B, D, mode, alpha, _ptr(ws), _stream()),
+         "indm_rowreduce_f32")
+    return out
+
+
+def upsample2x(x, alpha=1.0):
+    N, H, W, C = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_upsample2x_f32(_ptr(x), _ptr(y), N, H, W, C, alpha, _stream()), "indm_upsample2x_f32")
+    return y
+
+
+def downsample2x(x, alpha=0.25):
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_downsample2x_f32(_ptr(x), _ptr(y), N, H, W, C, alpha, _stream()), "indm_downsample2x_f32")
+    return y
+
+
+def squeeze2x(x):
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, 4 * C), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_squeeze2x_f32(_ptr(x), _ptr(y), N, H, W, C, _stream()), "indm_squeeze2x_f32")
+    return y
+
+
+def unsqueeze2x(x):
+    N, H, W, C4 = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, C4 // 4), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_unsqueeze2x_f32(_ptr(x), _ptr(y), N, H, W, C4, _stream()), "indm_unsqueeze2x_f32")
+    return y
+
+
+def nchw_to_nhwc(x):
+    N, C, H, W = x.shape
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_nchw_nhwc_f32(_ptr(x), _ptr(y), N, C, H * W, 0, _stream()), "indm_nchw_nhwc_f32")
+    return y
+
+
+def nhwc_to_nchw(x):
+    N, H, W, C = x.shape
+    y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_nchw_nhwc_f32(_ptr(x), _ptr(y), N, C, H * W, 1, _stream()), "indm_nchw_nhwc_f32")
+    return y
+
+
+def lop_normalize_fwd(w, coeff):
+    """w: RSCK weight (any leading dims, Cout last) -> wn, l1[Cout]."""
+    Co = w.shape[-1]
+    R = w.numel() // Co
+    wn = torch.empty_like(w)
+    l1 = torch.empty((Co,), dtype=torch.float32, device=w.device)
+    _chk(lib().indm_lop_normalize_fwd_f32(_ptr(w), _ptr(wn), _ptr(l1), R, Co, coeff, _stream()),
+         "indm_lop_normalize_fwd_f32")
+    return wn, l1
+
+
+def lop_normalize_bwd(dwn, w, l1, coeff):
+    Co = w.shape[-1]
+    R = w.numel() // Co
+    dw = torch.empty_like(w)
+    dot = torch.empty_like(l1)
+    _chk(lib().indm_lop_normalize_bwd_f32(_ptr(dwn), _ptr(w), _ptr(l1), _ptr(dw), _ptr(dot), R, Co, coeff, _stream()),
+         "indm_lop_normalize_bwd_f32")
+    return dw
+
+
+# --------------------------------------------------------------------------- SDE / loss / sampler / optimiser
+def sde_perturb(x, noise, mc, sd):
+    out = torch.empty_like(x)
+    B = x.shape[0]
+    _chk(lib().indm_sde_perturb_f32(_ptr(x), _ptr(noise), _ptr(mc), _ptr(sd), _ptr(out), B, x.numel() // B, _stream()),
+         "indm_sde_perturb_f32")
+    return out
+
+
+def dsm_loss_fwd(out, z, std, w, kind, mode, reduce_mean):
+    B = out.shape[0]
+    D = out.numel() // B
+    loss = torch.empty((B,), dtype=torch.float32, device=out.device)
+    ws = _ws(lib().indm_dsm_ws_floats(B, D), out.device)
+    _chk(lib().indm_dsm_loss_fwd_f32(_ptr(out), _ptr(z), _ptr(std), _ptr(w), _ptr(loss), B, D, kind, mode,
+                                     int(reduce_mean), _ptr(ws), _stream()), "indm_dsm_loss_fwd_f32")
+    return loss
+
+
+def dsm_loss_bwd(gl, out, z, std, w, kind, mode, reduce_mean):
+    B = out.shape[0]
+    D = out.numel() // B
+    dout = torch.empty_like(out)
+    _chk(lib().indm_dsm_loss_bwd_f32(_ptr(gl), _ptr(out), _ptr(z), _ptr(std), _ptr(w), _ptr(dout), B, D, kind, mode,
+                                     int(reduce_mean), _stream()), "indm_dsm_loss_bwd_f32")
+    return dout
+
+
+def affine_update(x, s, z, a, b, c, want_mean=True):
+    """x_mean = a[b]*x + b[b]*s ; x_new = x_mean + c[b]*z."""
+    B = x.shape[0]
+    x_new = torch.empty_like(x)
+    x_mean = torch.empty_like(x) if want_mean else None
+    _chk(lib().indm_affine_update_f32(_ptr(x), _ptr(s), _ptr(z), _ptr(a), _ptr(b), _ptr(c), _ptr(x_new), _ptr(x_mean),
+                                      B, x.numel() // B, _stream()), "indm_affine_update_f32")
+    return x_new, x_mean
+
+
+def langevin_step(grad_sq, noise_sq, alpha, snr):
+    step = torch.empty_like(grad_sq)
+    ncoef = torch.empty_like(grad_sq)
+    _chk(lib().indm_langevin_step_f32(_ptr(grad_sq), _ptr(noise_sq), _ptr(alpha), _ptr(step), _ptr(ncoef),
+                                      grad_sq.numel(), snr, _stream()), "indm_langevin_step_f32")
+    return step, ncoef
+
+
+def sqnorm(g):
+    out = torch.empty((1,), dtype=torch.float32, device=g.device)
+    ws = _ws(lib().indm_sqnorm_ws_floats(), g.device)
+    _chk(lib().indm_sqnorm_f32(_ptr(g), g.numel(), _ptr(out), _ptr(ws), _stream()), "indm_sqnorm_f32")
+    return out
+
+
+def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, wd, step, clip, gnorm_sq, gscale, ema_one_minus_decay):
+    _chk(lib().indm_adamw_ema_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), lr, beta1, beta2, eps, wd,
+                                  step, clip, _ptr(gnorm_sq), gscale, ema_one_minus_decay, _stream()),
+         "indm_adamw_ema_f32")
+
+
+# --------------------------------------------------------------------------- reference native ops
+def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, layout):
+    """layout 0: x is [N,C,H,W]; layout 1: x is [N,H,W,C]."""
+    if layout == 0:
+        N, C, H, W = x.shape
+    else:
+        N, H, W, C = x.shape
+    kh, kw = kernel.shape
+    oh = (H * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    ow = (W * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    shape = (N, C, oh, ow) if layout == 0 else (N, oh, ow, C)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _chk(lib().indm_upfirdn2d_f32(_ptr(x), _ptr(kernel), _ptr(y), N, C, H, W, kh, kw, up_x, up_y, down_x, down_y,
+                                  pad_x0, pad_x1, pad_y0, pad_y1, layout, _stream()), "indm_upfirdn2d_f32")
+    return y
+
+
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
+    """Same contract as the reference's fused.fused_bias_act (op/fused_bias_act.cpp:11-21), x is [N,C,...]."""
+    y = torch.empty_like(x)
+    size_b = bias.numel() if bias is not None and bias.numel() > 0 else 0
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    _chk(lib().indm_fused_bias_act_f32(_ptr(x), _ptr(bias) if size_b else None,
+                                       _ptr(ref) if ref is not None and ref.numel() > 0 else None, _ptr(y), x.numel(),
+                                       step_b, size_b, act, grad, alpha, scale, _stream()), "indm_fused_bias_act_f32")
+    return y

@@ -1,0 +1,319 @@
+"""Plain-PyTorch statement of what every entry point of indm_amd.hip computes.
+
+TEST INFRASTRUCTURE ONLY.  Two uses:
+  * `-m gpu` kernel tests compare each hand-written HIP kernel with the function of the same
+    name here (run on CPU in fp64/fp32) -- the "plain PyTorch reference of the same op".
+  * `-m "not gpu"` host-logic tests monkeypatch indm_amd.hip with these functions (see
+    conftest.emulate_hip) so the autograd wiring / module graph can be checked against the
+    oracle without a GPU.  The package itself never imports this file.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, rows_per_group=1, res=None,
+         beta=1.0, splitk=False):
+    A = a.transpose(-1, -2) if trans_a else a
+    Bm = b.transpose(-1, -2) if trans_b else b
+    out = alpha * torch.matmul(A, Bm)
+    if bias is not None:
+        out = out + bias
+    if bias2 is not None:
+        out = out + bias2.repeat_interleave(rows_per_group, dim=0)
+    if res is not None:
+        out = out + beta * res
+    return out.contiguous()
+
+
+def conv_out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def _w_oihw(w):
+    return w.permute(3, 2, 0, 1)
+
+
+def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
+    y = F.conv2d(x.permute(0, 3, 1, 2), _w_oihw(w), None, stride, pad).permute(0, 2, 3, 1)
+    y = alpha * y
+    if bias is not None:
+        y = y + bias
+    if bias2 is not None:
+        y = y + bias2[:, None, None, :]
+    if res is not None:
+        y = y + beta * res
+    return y.contiguous()
+
+
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0):
+    N, OH, OW, Co = dy.shape
+    KH, KW, Ci, _ = w.shape
+    H, W = in_hw
+    dx = torch.nn.grad.conv2d_input((N, Ci, H, W), _w_oihw(w), dy.permute(0, 3, 1, 2), stride, pad)
+    dx = alpha * dx.permute(0, 2, 3, 1)
+    if res is not None:
+        dx = dx + beta * res
+    return dx.contiguous()
+
+
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
+    N, H, W, Ci = x.shape
+    Co = dy.shape[-1]
+    dw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (Co, Ci, kh, kw), dy.permute(0, 3, 1, 2), stride, pad)
+    return (alpha * dw.permute(2, 3, 1, 0)).contiguous()
+
+
+def _dropout_mask_unavailable(drop_p):
+    if drop_p > 0:
+        raise NotImplementedError("Philox dropout masks exist only in the HIP kernel")
+
+
+def _gn_u(x, gamma, beta, mean, rstd, G):
+    N, C = x.shape[0], x.shape[-1]
+    xs = x.reshape(N, -1, G, C // G)
+    xh = (xs - mean[:, None, :, None]) * rstd[:, None, :, None]
+    xh = xh.reshape(x.shape)
+    return xh, xh * gamma + beta
+
+
+def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
+    _dropout_mask_unavailable(drop_p)
+    N, C = x.shape[0], x.shape[-1]
+    xs = x.reshape(N, -1, G, C // G)
+    mean = xs.mean(dim=(1, 3))
+    var = xs.var(dim=(1, 3), unbiased=False)
+    rstd = torch.rsqrt(var + eps)
+    _, u = _gn_u(x, gamma, beta, mean, rstd, G)
+    y = F.silu(u) if act == 1 else u
+    return y.contiguous(), mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
+    _dropout_mask_unavailable(drop_p)
+    N, C = x.shape[0], x.shape[-1]
+    xh, u = _gn_u(x, gamma, beta, mean, rstd, G)
+    d = dy
+    if act == 1:
+        s = torch.sigmoid(u)
+        d = dy * s * (1 + u * (1 - s))
+    red = tuple(range(x.dim() - 1))
+    dgamma = (d * xh).sum(red)
+    dbeta = d.sum(red)
+    gd = (d * gamma).reshape(N, -1, G, C // G)
+    xhs = xh.reshape(N, -1, G, C // G)
+    s1 = gd.mean(dim=(1, 3), keepdim=True)
+    s2 = (gd * xhs).mean(dim=(1, 3), keepdim=True)
+    dx = rstd[:, None, :, None] * (gd - s1 - xhs * s2)
+    return dx.reshape(x.shape).contiguous(), dgamma, dbeta
+
+
+def softmax_fwd(x, scale=1.0):
+    return torch.softmax(x * scale, dim=-1)
+
+
+def softmax_bwd(dy, y, scale=1.0):
+    return scale * y * (dy - (dy * y).sum(-1, keepdim=True))
+
+
+def colreduce(x, y=None, mode=0, alpha=1.0):
+    v = x if mode == 0 else (x * y if mode == 1 else x * x)
+    return alpha * v.reshape(-1, x.shape[-1]).sum(0)
+
+
+def sincos_fwd(p, want_d=True):
+    a = torch.sin(2 * math.pi * p) / (2 * math.pi)
+    return a, (torch.cos(2 * math.pi * p) if want_d else None)
+
+
+def sincos_bwd(da, dd, a, d):
+    g = torch.zeros_like(a)
+    if da is not None:
+        g = g + da * d
+    if dd is not None:
+        g = g - dd * (4 * math.pi ** 2) * a
+    return g
+
+
+ACT_SILU, ACT_ELU = 1, 2
+
+
+def act_fwd(x, act):
+    return F.silu(x) if act == 1 else F.elu(x)
+
+
+def act_bwd(dy, x, act):
+    if act == 1:
+        s = torch.sigmoid(x)
+        return dy * s * (1 + x * (1 - s))
+    return dy * torch.where(x > 0, torch.ones_like(x), torch.exp(x))
+
+
+def axpby(x, y, a, b):
+    return a * x + (b * y if y is not None else 0)
+
+
+def mul(x, y, alpha=1.0):
+    return alpha * x * y
+
+
+def scale_rows(x, s):
+    return x * s.reshape(-1, *([1] * (x.dim() - 1)))
+
+
+def rowreduce(x, y=None, mode=0, alpha=1.0):
+    B = x.shape[0]
+    v = x * y if mode == 0 else (x * x if mode == 1 else x)
+    return alpha * v.reshape(B, -1).sum(1)
+
+
+def upsample2x(x, alpha=1.0):
+    return (alpha * x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)).contiguous()
+
+
+def downsample2x(x, alpha=0.25):
+    N, H, W, C = x.shape
+    return alpha * x.reshape(N, H // 2, 2, W // 2, 2, C).sum(dim=(2, 4))
+
+
+def squeeze2x(x):
+    N, H, W, C = x.shape
+    v = x.reshape(N, H // 2, 2, W // 2, 2, C)  # n h dy w dx c
+    return v.permute(0, 1, 3, 5, 2, 4).reshape(N, H // 2, W // 2, 4 * C).contiguous()
+
+
+def unsqueeze2x(x):
+    N, H, W, C4 = x.shape
+    C = C4 // 4
+    v = x.reshape(N, H, W, C, 2, 2)  # n h w c dy dx
+    return v.permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * H, 2 * W, C).contiguous()
+
+
+def nchw_to_nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nhwc_to_nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def lop_normalize_fwd(w, coeff):
+    Co = w.shape[-1]
+    l1 = w.abs().reshape(-1, Co).sum(0)
+    return w / torch.clamp(l1 / coeff, min=1.0), l1
+
+
+def lop_normalize_bwd(dwn, w, l1, coeff):
+    Co = w.shape[-1]
+    s = l1 / coeff
+    f = torch.clamp(s, min=1.0)
+    dot = (dwn * w).reshape(-1, Co).sum(0)
+    g = dwn / f
+    corr = torch.sign(w) * dot / (f * f * coeff)
+    return g - torch.where(s > 1, corr, torch.zeros_like(corr))
+
+
+def _b(v, x):
+    return v.reshape(-1, *([1] * (x.dim() - 1)))
+
+
+def sde_perturb(x, noise, mc, sd):
+    out = _b(mc, x) * x
+    if noise is not None:
+        out = out + _b(sd, x) * noise
+    return out
+
+
+def _dsm_e(out, z, std, kind, mode):
+    sd = _b(std, out)
+    sc = -out / sd if kind == 0 else out
+    return (sc * sd + z) if mode == 0 else (sc + z / sd)
+
+
+def dsm_loss_fwd(out, z, std, w, kind, mode, reduce_mean):
+    e = _dsm_e(out, z, std, kind, mode)
+    B = out.shape[0]
+    r = (e * e).reshape(B, -1)
+    return w * (r.mean(1) if reduce_mean else r.sum(1))
+
+
+def dsm_loss_bwd(gl, out, z, std, w, kind, mode, reduce_mean):
+    e = _dsm_e(out, z, std, kind, mode)
+    B = out.shape[0]
+    D = out.numel() // B
+    sd = _b(std, out)
+    dsc = -1.0 / sd if kind == 0 else torch.ones_like(sd)
+    de = dsc * sd if mode == 0 else dsc
+    rs = 1.0 / D if reduce_mean else 1.0
+    return _b(gl * w, out) * rs * 2 * e * de
+
+
+def affine_update(x, s, z, a, b, c, want_mean=True):
+    m = _b(a, x) * x
+    if s is not None:
+        m = m + _b(b, x) * s
+    xn = m + _b(c, x) * z if z is not None else m
+    return xn, (m if want_mean else None)
+
+
+def langevin_step(grad_sq, noise_sq, alpha, snr):
+    gn = grad_sq.sqrt().mean()
+    nn_ = noise_sq.sqrt().mean()
+    step = (snr * nn_ / gn) ** 2 * 2 * alpha
+    return step, torch.sqrt(step * 2)
+
+
+def sqnorm(g):
+    return (g.double() ** 2).sum().float().reshape(1)
+
+
+def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, wd, step, clip, gnorm_sq, gscale, ema_one_minus_decay):
+    coef = gscale
+    if clip >= 0 and gnorm_sq is not None:
+        nrm = gnorm_sq.sqrt().item() * gscale
+        coef = coef * min(1.0, clip / (nrm + 1e-6))
+    gg = g * coef
+    p.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(gg, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p.addcdiv_(m, denom, value=-lr / bc1)
+    if ema is not None:
+        ema.sub_(ema_one_minus_decay * (ema - p))
+
+
+def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, layout):
+    if layout == 1:
+        x = x.permute(0, 3, 1, 2)
+    N, C, H, W = x.shape
+    kh, kw = kernel.shape
+    v = x.reshape(N * C, 1, H, 1, W, 1)
+    v = F.pad(v, [0, up_x - 1, 0, 0, 0, up_y - 1])
+    v = v.reshape(N * C, 1, H * up_y, W * up_x)
+    v = F.pad(v, [max(pad_x0, 0), max(pad_x1, 0), max(pad_y0, 0), max(pad_y1, 0)])
+    v = v[:, :, max(-pad_y0, 0): v.shape[2] - max(-pad_y1, 0), max(-pad_x0, 0): v.shape[3] - max(-pad_x1, 0)]
+    v = F.conv2d(v, torch.flip(kernel, [0, 1]).reshape(1, 1, kh, kw).to(v.dtype))
+    v = v[:, :, ::down_y, ::down_x]
+    v = v.reshape(N, C, v.shape[2], v.shape[3])
+    if layout == 1:
+        v = v.permute(0, 2, 3, 1)
+    return v.contiguous()
+
+
+def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
+    v = x
+    if bias is not None and bias.numel() > 0:
+        v = v + bias.reshape(1, -1, *([1] * (x.dim() - 2)))
+    if act == 1:
+        o = v if grad < 2 else torch.zeros_like(v)
+    else:
+        if grad == 0:
+            o = torch.where(v > 0, v, v * alpha)
+        elif grad == 1:
+            o = torch.where(ref > 0, v, v * alpha)
+        else:
+            o = torch.zeros_like(v)
+    return o * scale

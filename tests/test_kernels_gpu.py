@@ -1,0 +1,299 @@
+"""Per-kernel parity: every HIP kernel (called through the C ABI via indm_amd.hip) against the
+plain-PyTorch statement of the same op in tests/_emu.py, evaluated on CPU."""
+import math
+
+import pytest
+import torch
+
+import _emu
+from indm_amd import hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(a, b, rtol=2e-5, atol=2e-5, name=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= atol + rtol * ref, f"{name}: max err {err:.3e} (ref max {ref:.3e})"
+
+
+def run_both(fn, *args, **kw):
+    gargs = [a.to(DEV) if torch.is_tensor(a) else a for a in args]
+    gkw = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    out = getattr(hip, fn)(*gargs, **gkw)
+    ref = getattr(_emu, fn)(*[a.double() if torch.is_tensor(a) else a for a in args],
+                            **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    return out, ref
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 512, 512), (100, 70, 33), (1, 512, 64), (300, 3, 512),
+                                   (27, 512, 1000), (129, 130, 17), (4096, 512, 512)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm(M, N, K, ta, tb):
+    a = rnd(K, M) if ta else rnd(M, K)
+    b = rnd(N, K, seed=1) if tb else rnd(K, N, seed=1)
+    out, ref = run_both("gemm", a, b, trans_a=ta, trans_b=tb)
+    close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), name="gemm")
+
+
+def test_gemm_epilogue_batched_splitk():
+    a, b = rnd(6, 64, 48), rnd(6, 48, 40, seed=2)
+    bias, res = rnd(40, seed=3), rnd(6, 64, 40, seed=4)
+    out, ref = run_both("gemm", a, b, alpha=0.5, bias=bias, res=res, beta=-2.0)
+    close(out, ref, name="gemm batched")
+    a, b = rnd(512, 96), rnd(96, 72, seed=5)
+    bias2 = rnd(4, 72, seed=6)
+    out, ref = run_both("gemm", a, b, bias2=bias2, rows_per_group=128)
+    close(out, ref, name="gemm bias2")
+    # weight-grad shape: tiny output, long reduction -> split-K path
+    a, b = rnd(20000, 64), rnd(20000, 96, seed=7)
+    out, ref = run_both("gemm", a, b, trans_a=True, splitk=True)
+    close(out, ref, rtol=1e-5, atol=2e-3, name="gemm splitk")
+    # attention shapes: batched Q K^T and P V
+    q, k = rnd(8, 256, 64), rnd(8, 256, 64, seed=8)
+    out, ref = run_both("gemm", q, k, trans_b=True)
+    close(out, ref, name="qk^t")
+
+
+CONV_CASES = [
+    # N, H, W, Ci, Co, k, stride, pad
+    (2, 16, 16, 32, 64, 3, 1, 1),
+    (3, 8, 8, 128, 128, 3, 1, 1),
+    (2, 32, 32, 3, 64, 3, 1, 1),      # first conv / flow 3->512 style (scalar A path)
+    (2, 16, 16, 12, 48, 3, 1, 1),
+    (2, 16, 16, 64, 3, 3, 1, 1),      # 512->3 style (skinny N, scalar B path)
+    (2, 16, 16, 64, 12, 3, 1, 1),
+    (2, 16, 16, 48, 96, 3, 2, 1),     # encoder stride-2
+    (2, 16, 16, 48, 96, 1, 2, 0),     # encoder 1x1 stride-2 shortcut
+    (2, 17, 17, 16, 32, 3, 2, 0),     # VE conv_downsample_2d: FIR-padded 17x17 -> 8x8
+    (1, 4, 4, 256, 256, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(N, H, W, Ci, Co, k, s, p):
+    x, w = rnd(N, H, W, Ci), rnd(k, k, Ci, Co, seed=1, scale=0.2)
+    bias, bias2 = rnd(Co, seed=2), rnd(N, Co, seed=3)
+    out, ref = run_both("conv2d", x, w, stride=s, pad=p, bias=bias, bias2=bias2)
+    close(out, ref, rtol=1e-5, atol=1e-4, name="conv fwd")
+    dy = rnd(*ref.shape, seed=4)
+    res = rnd(N, H, W, Ci, seed=5)
+    out, r2 = run_both("conv2d_dgrad", dy, w, (H, W), stride=s, pad=p, alpha=2.0, res=res, beta=0.5)
+    close(out, r2, rtol=1e-5, atol=1e-4, name="conv dgrad")
+    out, r3 = run_both("conv2d_wgrad", x, dy, k, k, stride=s, pad=p)
+    close(out, r3, rtol=1e-5, atol=2e-4, name="conv wgrad")
+
+
+def test_conv2d_big_wgrad_splitk():
+    x, dy = rnd(16, 32, 32, 16), rnd(16, 32, 32, 32, seed=1)
+    out, ref = run_both("conv2d_wgrad", x, dy, 3, 3, stride=1, pad=1)
+    close(out, ref, rtol=1e-5, atol=2e-3, name="wgrad splitk")
+
+
+@pytest.mark.parametrize("N,HW,C", [(2, (32, 32), 128), (3, (16, 16), 256), (2, (16, 16), 384), (2, (4, 4), 512),
+                                    (4, (8, 8), 16), (2, (16, 16), 64)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_groupnorm(N, HW, C, act):
+    G = min(C // 4, 32)
+    x = rnd(N, *HW, C) * 2 + 0.3
+    gamma, beta = rnd(C, seed=1) + 1.5, rnd(C, seed=2)
+    (y, mean, rstd), (yr, mr, rr) = run_both("groupnorm_fwd", x, gamma, beta, G, 1e-6, act=act)
+    close(y, yr, name="gn y")
+    close(mean, mr, name="gn mean")
+    close(rstd, rr, rtol=1e-4, name="gn rstd")
+    dy = rnd(N, *HW, C, seed=3)
+    (dx, dg, db), (dxr, dgr, dbr) = run_both("groupnorm_bwd", dy, x, gamma, beta, mr.float(), rr.float(), G, act=act)
+    close(dx, dxr, rtol=1e-4, atol=1e-4, name="gn dx")
+    close(dg, dgr, rtol=1e-4, atol=1e-3, name="gn dgamma")
+    close(db, dbr, rtol=1e-4, atol=1e-3, name="gn dbeta")
+
+
+def test_groupnorm_dropout_statistics():
+    x = rnd(4, 16, 16, 128).to(DEV)
+    gamma, beta = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    y0, mean, rstd = hip.groupnorm_fwd(x, gamma, beta, 32, 1e-6, act=1)
+    y1, _, _ = hip.groupnorm_fwd(x, gamma, beta, 32, 1e-6, act=1, drop_p=0.1, seed=1234)
+    y2, _, _ = hip.groupnorm_fwd(x, gamma, beta, 32, 1e-6, act=1, drop_p=0.1, seed=1234)
+    assert torch.equal(y1, y2)
+    keep = (y1 != 0) | (y0 == 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.9) < 0.01, frac
+    close(y1[keep], (y0 / 0.9)[keep], name="dropout scale")
+    # backward regenerates the same mask: dx must vanish where the output was dropped w.r.t. dy path
+    dy = torch.ones_like(x)
+    dxa, _, _ = hip.groupnorm_bwd(dy * keep.float() / 0.9, x, gamma, beta, mean, rstd, 32, act=1)
+    dxb, _, _ = hip.groupnorm_bwd(dy, x, gamma, beta, mean, rstd, 32, act=1, drop_p=0.1, seed=1234)
+    close(dxb, dxa, rtol=1e-4, atol=1e-5, name="dropout bwd")
+
+
+@pytest.mark.parametrize("rows,T", [(512, 256), (64, 16), (7, 100), (3, 1000)])
+def test_softmax(rows, T):
+    x = rnd(rows, T) * 4
+    y, yr = run_both("softmax_fwd", x, scale=0.25)
+    close(y, yr, name="softmax")
+    dy = rnd(rows, T, seed=1)
+    dx, dxr = run_both("softmax_bwd", dy, yr.float(), scale=0.25)
+    close(dx, dxr, name="softmax bwd")
+
+
+def test_reductions_elementwise():
+    x, y = rnd(1000, 48), rnd(1000, 48, seed=1)
+    for mode in (0, 1, 2):
+        o, r = run_both("colreduce", x, y, mode=mode, alpha=0.5)
+        close(o, r, rtol=1e-5, atol=1e-4, name=f"colreduce{mode}")
+    x, y = rnd(5, 3, 32, 32), rnd(5, 3, 32, 32, seed=1)
+    for mode in (0, 1, 2):
+        o, r = run_both("rowreduce", x, y, mode=mode, alpha=-0.5)
+        close(o, r, rtol=1e-5, atol=1e-4, name=f"rowreduce{mode}")
+    p = rnd(3, 16, 16, 64) * 3
+    (a, d), (ar, dr) = run_both("sincos_fwd", p)
+    close(a, ar, name="sin")
+    close(d, dr, name="cos")
+    da, dd = rnd(3, 16, 16, 64, seed=2), rnd(3, 16, 16, 64, seed=3)
+    o, r = run_both("sincos_bwd", da, dd, ar.float(), dr.float())
+    close(o, r, name="sincos bwd")
+    for act in (1, 2):
+        o, r = run_both("act_fwd", p, act)
+        close(o, r, name="act")
+        o, r = run_both("act_bwd", da, p, act)
+        close(o, r, name="act bwd")
+    o, r = run_both("axpby", da, dd, 0.7, -1.3)
+    close(o, r, name="axpby")
+    o, r = run_both("axpby", da.reshape(-1)[:1001].clone(), dd.reshape(-1)[:1001].clone(), 0.7, -1.3)
+    close(o, r, name="axpby odd")
+    o, r = run_both("mul", da, dd, alpha=2.0)
+    close(o, r, name="mul")
+    o, r = run_both("scale_rows", da, rnd(3, seed=9))
+    close(o, r, name="scale_rows")
+
+
+def test_resample_permutes():
+    x = rnd(2, 8, 8, 12)
+    for fn in ("upsample2x", "downsample2x", "squeeze2x"):
+        o, r = run_both(fn, x)
+        close(o, r, name=fn)
+    x4 = rnd(2, 4, 4, 48)
+    o, r = run_both("unsqueeze2x", x4)
+    close(o, r, name="unsqueeze2x")
+    assert torch.equal(hip.unsqueeze2x(hip.squeeze2x(x.to(DEV))).cpu(), x)
+    xc = rnd(2, 5, 6, 7)
+    o, r = run_both("nchw_to_nhwc", xc)
+    close(o, r, name="nchw->nhwc")
+    o, r = run_both("nhwc_to_nchw", xc)
+    close(o, r, name="nhwc->nchw")
+    # squeeze must agree with the reference's NCHW squeeze (squeeze.py:27-45) through the layout change
+    xn = rnd(2, 3, 8, 8)
+    ref = xn.reshape(2, 3, 4, 2, 4, 2).permute(0, 1, 3, 5, 2, 4).reshape(2, 12, 4, 4)
+    got = hip.nhwc_to_nchw(hip.squeeze2x(hip.nchw_to_nhwc(xn.to(DEV)))).cpu()
+    assert torch.equal(got, ref)
+    assert torch.equal(hip.nhwc_to_nchw(hip.unsqueeze2x(hip.nchw_to_nhwc(ref.to(DEV)))).cpu(),
+                       torch.pixel_shuffle(ref, 2))
+
+
+def test_lop_normalize():
+    for shape, scale in [((3, 3, 3, 64), 0.5), ((1, 1, 64, 64), 0.01), ((3, 3, 32, 3), 0.2)]:
+        w = rnd(*shape, scale=scale)
+        (wn, l1), (wnr, l1r) = run_both("lop_normalize_fwd", w, 0.98)
+        close(wn, wnr, name="lop wn")
+        close(l1, l1r, name="lop l1")
+        dwn = rnd(*shape, seed=1)
+        dw, dwr = run_both("lop_normalize_bwd", dwn, w, l1r.float(), 0.98)
+        close(dw, dwr, name="lop bwd")
+        # and against autograd of the reference formula (lipschitz.py:350-359)
+        wt = w.double().requires_grad_()
+        sc = wt.abs().reshape(-1, shape[-1]).sum(0)
+        (wt / torch.max(torch.ones(1, dtype=torch.double), sc / 0.98) * dwn.double()).sum().backward()
+        close(dw, wt.grad, name="lop bwd autograd")
+
+
+def test_sde_loss_sampler_kernels():
+    B, shape = 5, (5, 32, 32, 3)
+    out, z = rnd(*shape), rnd(*shape, seed=1)
+    std, w = rnd(B, seed=2).abs() + 0.1, rnd(B, seed=3).abs() + 0.5
+    for kind in (0, 1):
+        for mode in (0, 1):
+            for rm in (True, False):
+                o, r = run_both("dsm_loss_fwd", out, z, std, w, kind, mode, rm)
+                close(o, r, rtol=1e-5, atol=1e-4, name="dsm fwd")
+                gl = rnd(B, seed=4)
+                o, r = run_both("dsm_loss_bwd", gl, out, z, std, w, kind, mode, rm)
+                close(o, r, rtol=1e-5, atol=1e-5, name="dsm bwd")
+    o, r = run_both("sde_perturb", out, z, std, w)
+    close(o, r, name="perturb")
+    (xn, xm), (xnr, xmr) = run_both("affine_update", out, z, rnd(*shape, seed=5), std, w, rnd(B, seed=6))
+    close(xn, xnr, name="affine new")
+    close(xm, xmr, name="affine mean")
+    (st, nc), (str_, ncr) = run_both("langevin_step", std, w, rnd(B, seed=7).abs(), 0.16)
+    close(st, str_, name="langevin step")
+    close(nc, ncr, name="langevin coef")
+
+
+def test_optimizer_kernels():
+    n = 100003
+    p, g = rnd(n), rnd(n, seed=1) * 3
+    m, v, ema = rnd(n, seed=2) * 0.1, rnd(n, seed=3).abs() * 0.01, rnd(n, seed=4)
+    gq = hip.sqnorm(g.to(DEV))
+    close(gq, _emu.sqnorm(g), rtol=1e-5, name="sqnorm")
+    P, M, V, E = p.clone().to(DEV), m.clone().to(DEV), v.clone().to(DEV), ema.clone().to(DEV)
+    hip.adamw_ema(P, g.to(DEV), M, V, E, 2e-4, 0.9, 0.99, 1e-8, 0.01, 7, 1.0, gq, 1.0, 1 - 0.999)
+    pr, mr, vr, er = p.double(), m.double(), v.double(), ema.double()
+    _emu.adamw_ema(pr, g.double(), mr, vr, er, 2e-4, 0.9, 0.99, 1e-8, 0.01, 7, 1.0, _emu.sqnorm(g).double(), 1.0,
+                   1 - 0.999)
+    close(P, pr, rtol=1e-6, atol=1e-6, name="adam p")
+    close(M, mr, name="adam m")
+    close(V, vr, name="adam v")
+    close(E, er, rtol=1e-6, atol=1e-6, name="ema")
+    # against torch.optim.AdamW + clip_grad_norm_ (losses.py:30-62)
+    pt = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([pt], lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    P2 = p.clone().to(DEV)
+    M2, V2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        gs = rnd(n, seed=10 + step) * 2
+        pt.grad = gs.clone()
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+        hip.adamw_ema(P2, gs.to(DEV), M2, V2, None, 2e-4, 0.9, 0.99, 1e-8, 0.01, step, 1.0, hip.sqnorm(gs.to(DEV)),
+                      1.0, 0.0)
+    close(P2, pt.data, rtol=1e-6, atol=1e-6, name="adamw vs torch")
+
+
+UFD_CASES = [  # C, H, W, up, down, pad0, pad1  (the 9 VE call signatures, SURVEY App. B, + crops)
+    (128, 32, 32, 1, 2, 1, 1), (3, 32, 32, 1, 1, 2, 2), (256, 16, 16, 1, 2, 1, 1), (128, 16, 16, 1, 1, 2, 2),
+    (256, 8, 8, 1, 2, 1, 1), (256, 8, 8, 1, 1, 2, 2), (256, 4, 4, 2, 1, 2, 1), (256, 8, 8, 2, 1, 2, 1),
+    (64, 16, 16, 2, 1, 2, 1), (5, 9, 7, 2, 3, -1, 2), (4, 8, 8, 1, 1, -1, -1), (2, 6, 6, 3, 2, 0, -2),
+]
+
+
+@pytest.mark.parametrize("C,H,W,up,down,p0,p1", UFD_CASES)
+@pytest.mark.parametrize("layout", [0, 1])
+def test_upfirdn2d(C, H, W, up, down, p0, p1, layout):
+    x = rnd(2, C, H, W) if layout == 0 else rnd(2, H, W, C)
+    k = torch.tensor([1., 3., 3., 1.])
+    k = torch.outer(k, k)
+    k = k / k.sum() + rnd(4, 4, seed=3) * 0.05  # asymmetric: catches flips / transposes
+    o, r = run_both("upfirdn2d", x, k, up, up, down, down, p0, p1, p0, p1, layout)
+    close(o, r, name="upfirdn2d")
+    k3 = rnd(3, 2, seed=5)
+    o, r = run_both("upfirdn2d", x, k3, up, 1, 1, down, p0, p1, p1, p0, layout)
+    close(o, r, name="upfirdn2d aniso")
+
+
+def test_fused_bias_act():
+    x, b = rnd(3, 8, 5, 5), rnd(8, seed=1)
+    ref = rnd(3, 8, 5, 5, seed=2)
+    for act in (1, 3):
+        for grad in (0, 1, 2):
+            o, r = run_both("fused_bias_act", x, b, ref, act, grad, 0.2, math.sqrt(2))
+            close(o, r, name=f"fba {act}{grad}")
+    o, r = run_both("fused_bias_act", x, None, ref, 3, 1, 0.1, 1.0)
+    close(o, r, name="fba nobias")
