@@ -1,0 +1,402 @@
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE (/root/reference)
+in this container (CPU, fp32) with inert stubs (ref_import.py).  Run manually:
+
+    cd /root/repo && python tests/golden/make_golden.py
+
+Fixtures hold data only: inputs, weights of a mini configuration, every random draw the reference
+made (in call order) and the outputs it produced.  No reference source is copied.
+The reference never travels to the GPU box; tests read only the .npz files.
+"""
+import contextlib
+import io
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+torch = ref_import.install()
+import numpy as np  # noqa: E402
+
+import losses  # noqa: E402
+import likelihood  # noqa: E402
+import sampling  # noqa: E402
+import sde_lib  # noqa: E402
+import utils as ref_utils  # noqa: E402
+from models import ncsnpp  # noqa: F401,E402
+from models import utils as mutils  # noqa: E402
+from models import layers as ref_layers  # noqa: E402
+from models import layerspp as ref_layerspp  # noqa: E402
+from models.ema import ExponentialMovingAverage  # noqa: E402
+from flow_models.flow_model import create_flow_model, flow_forward  # noqa: E402
+from op.upfirdn2d import upfirdn2d_native  # noqa: E402
+from op.fused_act import fused_leaky_relu  # noqa: E402
+import datasets as ref_datasets  # noqa: E402
+
+
+class _NullFile(io.BytesIO):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+sys.modules["tensorflow"].io.gfile.GFile = _NullFile
+sampling.tf = sys.modules["tensorflow"]
+
+
+# ----------------------------------------------------------------------------- noise recording
+class Recorder:
+    def __init__(self):
+        self.events = []
+
+    @contextlib.contextmanager
+    def on(self):
+        o = dict(randn=torch.randn, randn_like=torch.randn_like, rand=torch.rand, rand_like=torch.rand_like,
+                 randint_like=torch.randint_like, poisson=np.random.poisson)
+        ev = self.events
+
+        def randn(*a, **k):
+            r = o["randn"](*a, **k); ev.append(("randn", r.detach().cpu().numpy().copy())); return r
+
+        def randn_like(x, **k):
+            r = o["randn_like"](x, **k); ev.append(("randn", r.detach().cpu().numpy().copy())); return r
+
+        def rand(*a, **k):
+            r = o["rand"](*a, **k); ev.append(("rand", r.detach().cpu().numpy().copy())); return r
+
+        def randint_like(x, **k):
+            r = o["randint_like"](x, **k)
+            ev.append(("rademacher", (r.float() * 2 - 1).cpu().numpy().copy())); return r
+
+        def poisson(lam, n):
+            r = o["poisson"](lam, n); ev.append(("poisson", np.asarray(r[0], dtype=np.int64))); return r
+
+        torch.randn, torch.randn_like, torch.rand = randn, randn_like, rand
+        torch.randint_like, np.random.poisson = randint_like, poisson
+        try:
+            yield
+        finally:
+            torch.randn, torch.randn_like, torch.rand = o["randn"], o["randn_like"], o["rand"]
+            torch.randint_like, np.random.poisson = o["randint_like"], o["poisson"]
+
+
+def pack_events(prefix, events, out):
+    out[f"{prefix}/n_events"] = np.asarray(len(events))
+    for i, (k, v) in enumerate(events):
+        out[f"{prefix}/ev{i:03d}_{k}"] = np.asarray(v)
+
+
+def pack_sd(prefix, module, out):
+    for k, v in module.state_dict().items():
+        out[f"{prefix}/{k[len('module.'):] if k.startswith('module.') else k}"] = v.detach().cpu().numpy().copy()
+
+
+def tensor_stats(named):
+    return {k: np.asarray([float(v.double().sum()), float(v.double().pow(2).sum())]) for k, v in named}
+
+
+# ----------------------------------------------------------------------------- configs
+def mini(cfg, batch=2):
+    cfg.model.nf = 16
+    cfg.model.ch_mult = (1, 2)
+    cfg.model.num_res_blocks = 1
+    cfg.model.dropout = 0.0
+    cfg.flow.nblocks = "2-2"
+    cfg.flow.intermediate_dim = 32
+    # shrunken wolf JSON (same structure as wolf_configs/cifar10/glow/resflow-gaussian-uni.json:1-34)
+    import json
+    wolf = json.load(open(os.path.join(ref_import.REF, cfg.flow.model_config)))
+    wolf["discriminator"]["encoder"]["hidden_planes"] = [8, 16, 16]
+    wolf["discriminator"]["prior"]["hidden_features"] = 32
+    path = "/tmp/mini_wolf.json"
+    json.dump(wolf, open(path, "w"))
+    cfg.flow.model_config = path
+    cfg.training.batch_size = batch
+    cfg.sampling.batch_size = batch
+    cfg.sampling.num_scales = 3
+    cfg.eval.batch_size = batch
+    return cfg
+
+
+def build(cfg, seed):
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    score = mutils.create_model(cfg)
+    flow = create_flow_model(cfg)
+    # make the untrained nets non-degenerate: init_scale=0 zeroes the last conv / attention out-proj
+    with torch.no_grad():
+        for n, p in score.named_parameters():
+            if p.abs().max() < 1e-6 and p.dim() > 1:
+                p.copy_(torch.randn_like(p) * 0.05)
+        for n, b in flow.named_buffers():
+            if n.endswith("running_mean"):
+                b.copy_(torch.randn_like(b) * 0.1)
+            if n.endswith("running_var"):
+                b.copy_(torch.rand_like(b) + 0.5)
+    return score, flow
+
+
+def make_states(cfg, score, flow):
+    opt = losses.get_optimizer(cfg, score.parameters())
+    ema = ExponentialMovingAverage(score.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=opt, model=score, ema=ema, step=0)
+    fopt = losses.get_optimizer(cfg, flow.parameters(), lr=cfg.flow.lr)
+    fema = ExponentialMovingAverage(flow.parameters(), decay=cfg.flow.ema_rate)
+    fstate = dict(optimizer=fopt, model=flow, ema=fema, step=0)
+    return state, fstate
+
+
+def data_batch(cfg, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, cfg.data.image_size, cfg.data.image_size, generator=g)
+    x = (255.0 * x + torch.rand(x.shape, generator=g)) / 256.0  # run_lib.py:86
+    return ref_datasets.get_data_scaler(cfg)(x)
+
+
+# ----------------------------------------------------------------------------- fixtures
+def golden_sde(out_dir):
+    out = {}
+    t = torch.tensor([1e-5, 8.2764716353e-05, 1e-3, 0.1, 0.5, 0.999, 1.0])
+    u = torch.tensor([0.0, 1e-4, 0.01, 0.3, 0.5, 0.9, 0.9999])
+    x = torch.linspace(-1, 1, 7 * 3 * 4 * 4).reshape(7, 3, 4, 4)
+    out["t"], out["u"], out["x"] = t.numpy(), u.numpy(), x.numpy()
+    cfg = ref_import.get_config()
+    for name, sde in (("vp", sde_lib.VPSDE(1e-5, 0.1, 20.0, 1000)), ("ve", sde_lib.VESDE(1e-5, 0.01, 50.0, 1000))):
+        mean, std = sde.marginal_prob(x, t)
+        drift, diff = sde.sde(x, t)
+        out[f"{name}/mean"], out[f"{name}/std"] = mean.numpy(), std.numpy()
+        out[f"{name}/drift"], out[f"{name}/diffusion"] = drift.numpy(), diff.numpy()
+        out[f"{name}/prior_logp"] = sde.prior_logp(x).numpy()
+        f, G = sde.discretize(x, t, None)
+        out[f"{name}/disc_f"], out[f"{name}/disc_G"] = f.numpy(), G.numpy()
+        nt = t * 0.5
+        f, G = sde.discretize(x, t, nt)
+        out[f"{name}/disc2_f"], out[f"{name}/disc2_G"] = f.numpy(), G.numpy()
+        out[f"{name}/antiderivative"] = sde.antiderivative(t).numpy()
+        out[f"{name}/antiderivative_T"] = sde.antiderivative(1.0).numpy()
+        out[f"{name}/Z"] = sde.normalizing_constant(1e-5).numpy()
+        orig = torch.rand
+        torch.rand = lambda *a, **k: u.clone()
+        try:
+            tt, Z = sde.get_diffusion_time(cfg, 7, torch.device("cpu"), 1e-5, importance_sampling=True)
+        finally:
+            torch.rand = orig
+        out[f"{name}/is_t"] = tt.numpy()
+    out["timestep_embedding"] = ref_layers.get_timestep_embedding(t * 999, 128).numpy()
+    torch.manual_seed(3)
+    gfp = ref_layerspp.GaussianFourierProjection(embedding_size=8, scale=16.0)
+    out["gfp/W"] = gfp.W.detach().numpy()
+    out["gfp/out"] = gfp(torch.log(torch.tensor([0.01, 0.5, 3.0, 50.0]))).detach().numpy()
+    np.savez_compressed(os.path.join(out_dir, "sde_known_answers.npz"), **out)
+
+
+def golden_ops(out_dir):
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k = torch.outer(k1, k1)
+    k = k / k.sum()
+    krand = torch.rand(4, 4, generator=g)
+    # the 9 VE call signatures with shrunken channel counts + crops + random kernels
+    cases = [(8, 32, 32, 1, 2, 1, 1), (3, 32, 32, 1, 1, 2, 2), (8, 16, 16, 1, 2, 1, 1), (8, 16, 16, 1, 1, 2, 2),
+             (8, 8, 8, 1, 2, 1, 1), (8, 8, 8, 1, 1, 2, 2), (8, 4, 4, 2, 1, 2, 1), (8, 8, 8, 2, 1, 2, 1),
+             (8, 16, 16, 2, 1, 2, 1), (5, 9, 7, 2, 3, -1, 2), (4, 8, 8, 1, 1, -1, -1)]
+    out["cases"] = np.asarray(cases)
+    out["k_fir"], out["k_rand"] = k.numpy(), krand.numpy()
+    for i, (c, h, w, up, down, p0, p1) in enumerate(cases):
+        for kn, kk in (("fir", k * (up ** 2)), ("rand", krand)):
+            x = torch.rand(2, c, h, w, generator=g, requires_grad=True)
+            y = upfirdn2d_native(x, kk, up, up, down, down, p0, p1, p0, p1)
+            gy = torch.rand(y.shape, generator=g)
+            (gx,) = torch.autograd.grad(y, x, gy)
+            out[f"ufd{i}_{kn}/x"], out[f"ufd{i}_{kn}/y"] = x.detach().numpy(), y.detach().numpy()
+            out[f"ufd{i}_{kn}/gy"], out[f"ufd{i}_{kn}/gx"] = gy.numpy(), gx.numpy()
+            out[f"ufd{i}_{kn}/k"] = kk.numpy()
+    x = torch.randn(3, 8, 5, 5, generator=g)
+    b = torch.randn(8, generator=g)
+    out["flr/x"], out["flr/b"] = x.numpy(), b.numpy()
+    out["flr/y"] = fused_leaky_relu(x, b, 0.2, 2 ** 0.5).numpy()
+    np.savez_compressed(os.path.join(out_dir, "native_ops.npz"), **out)
+
+
+def golden_model(out_dir, name, cfg_name, patch):
+    cfg = mini(ref_import.get_config(cfg_name))
+    patch(cfg)
+    out = {}
+    score, flow = build(cfg, seed=1234)
+    pack_sd("score", score, out)
+    pack_sd("flow", flow, out)
+    out["flow_param_order"] = np.asarray([n[len("module."):] for n, p in flow.named_parameters() if p.requires_grad])
+    out["score_param_order"] = np.asarray([n[len("module."):] for n, p in score.named_parameters() if p.requires_grad])
+    sde = sde_lib.get_sde(cfg)
+    B = 2
+    x = data_batch(cfg, B, seed=5)
+    out["x"] = x.numpy()
+    inverse_scaler = ref_datasets.get_data_inverse_scaler(cfg)
+    scaler = ref_datasets.get_data_scaler(cfg)
+
+    # ---- score network forward + grads (eval mode, fixed t) ----
+    score.eval()
+    t = torch.tensor([0.3, 0.9])
+    xs = x.clone().requires_grad_(True)
+    score_fn = mutils.get_score_fn(cfg, sde, score, train=False, continuous=True)
+    s = score_fn(xs, t)
+    gy = torch.linspace(-1, 1, s.numel()).reshape(s.shape)
+    pnames = [n for n, p in score.named_parameters() if p.requires_grad]
+    pick = [pnames[2], pnames[len(pnames) // 2], pnames[-2]] + [n for n in pnames if "NIN_1.W" in n][:1] + \
+           [n for n in pnames if "GroupNorm_1.weight" in n][:1] + [n for n in pnames if "Dense_0.weight" in n][:1]
+    params = dict(score.named_parameters())
+    grads = torch.autograd.grad(s, [xs] + [params[n] for n in pick], gy)
+    out["score/t"], out["score/out"], out["score/gy"] = t.numpy(), s.detach().numpy(), gy.numpy()
+    out["score/gx"] = grads[0].numpy()
+    for n, gr in zip(pick, grads[1:]):
+        out[f"score/grad/{n[len('module.'):]}"] = gr.numpy()
+    raw = score(x, t * 999 if cfg.training.sde == "vpsde" else sde.marginal_prob(x, t)[1])
+    out["score/raw_out"] = raw.detach().numpy()
+
+    # ---- flow forward: train (Neumann surrogate), eval (power series), no-logdet, reverse ----
+    for mode in ("train", "eval"):
+        flow.train() if mode == "train" else flow.eval()
+        saved = {k: v.clone() for k, v in flow.state_dict().items()}
+        rec = Recorder()
+        with rec.on():
+            z, ld = flow_forward(cfg, flow, x.clone(), reverse=False)
+        if mode == "train":
+            gz = torch.linspace(-1, 1, z.numel()).reshape(z.shape)
+            fparams = dict(flow.named_parameters())
+            fpn = [n for n, p in fparams.items() if p.requires_grad and "lamb" not in n and "geom_p" not in n]
+            fpick = [fpn[0], fpn[2], fpn[4], fpn[5], fpn[6], fpn[8]] + [n for n in fpn if "encoder" in n][:2] + \
+                    [n for n in fpn if "discriminator.fc" in n] + [n for n in fpn if "steps.0.linear.weight" in n] + \
+                    [n for n in fpn if "steps.1.unit.coupling2_dn.net.fc3" in n] + \
+                    [n for n in fpn if "steps.0.actnorm" in n] + [n for n in fpn if "transforms.1.chain.1.nnet.3" in n]
+            gr = torch.autograd.grad([z, ld], [fparams[n] for n in fpick], [gz, torch.tensor([1.0, -0.5])])
+            out["flow_train/gz"] = gz.numpy()
+            for n, g_ in zip(fpick, gr):
+                out[f"flow_train/grad/{n[len('module.'):]}"] = g_.numpy()
+            for k, v in flow.state_dict().items():
+                if "running" in k or "last_" in k or k.endswith(".scale") or "num_batches" in k:
+                    out[f"flow_train/buffers/{k[len('module.'):]}"] = v.detach().numpy().copy()
+        out[f"flow_{mode}/z"], out[f"flow_{mode}/logdet_kl"] = z.detach().numpy(), ld.detach().numpy()
+        pack_events(f"flow_{mode}", rec.events, out)
+        flow.load_state_dict(saved)
+    flow.eval()
+    rec = Recorder()
+    with rec.on(), torch.no_grad():
+        z2, _ = flow_forward(cfg, flow, x.clone(), log_det=None, reverse=False)
+    out["flow_nologdet/z"] = z2.numpy()
+    pack_events("flow_nologdet", rec.events, out)
+    rec = Recorder()
+    with rec.on(), torch.no_grad():
+        xr, _ = flow_forward(cfg, flow, torch.tensor(out["flow_eval/z"]), log_det=None, reverse=True)
+    out["flow_reverse/x"] = xr.numpy()
+    pack_events("flow_reverse", rec.events, out)
+
+    # ---- NELBO ----
+    nelbo_fn = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=inverse_scaler)
+    score.eval(); flow.eval()
+    rec = Recorder()
+    with rec.on():
+        n1, n2 = nelbo_fn(score, flow, x.clone())
+    out["nelbo/bpd"], out["nelbo/bpd_residual"] = n1.detach().numpy(), n2.detach().numpy()
+    pack_events("nelbo", rec.events, out)
+
+    # ---- PC sampler, 3 scales ----
+    shape = (B, 3, cfg.data.image_size, cfg.data.image_size)
+    cfg.sampling.method = "pc"
+    sampler = sampling.get_sampling_fn(cfg, sde, shape, inverse_scaler, cfg.sampling.truncation_time)
+    rec = Recorder()
+    with rec.on():
+        before, after, nfe = sampler(score, flow, sample_dir="/tmp", r=0)
+    out["pc/before"], out["pc/after"], out["pc/nfe"] = before.numpy(), after.numpy(), np.asarray(nfe)
+    pack_events("pc", rec.events, out)
+
+    # ---- PF-ODE: one RHS evaluation + full RK45 NLL + ODE sampler ----
+    if cfg.training.sde == "vpsde":
+        lik = likelihood.get_likelihood_fn(cfg, sde, inverse_scaler, rtol=1e-3, atol=1e-3)
+        rec = Recorder()
+        with rec.on():
+            bpd, zlat, nfe = lik(score, flow, x.clone())
+        out["nll/bpd"], out["nll/z"], out["nll/nfe"] = bpd.numpy(), zlat.numpy(), np.asarray(nfe)
+        pack_events("nll", rec.events, out)
+        score_fn = mutils.get_score_fn(cfg, sde, score, train=False, continuous=True)
+        rsde = sde.reverse(score_fn, probability_flow=True)
+        eps_r = torch.tensor(out["nll/ev%03d_rademacher" % [i for i, e in enumerate(rec.events) if e[0] == "rademacher"][0]])
+        vt = torch.ones(B) * 0.4
+        xx = x.clone()
+        drift = rsde.sde(xx, vt)[0]
+        div = likelihood.get_div_fn(lambda a, b: rsde.sde(a, b)[0])(xx, vt, eps_r)
+        out["ode_rhs/t"], out["ode_rhs/drift"], out["ode_rhs/div"] = vt.numpy(), drift.detach().numpy(), div.numpy()
+        out["ode_rhs/eps"] = eps_r.numpy()
+        cfg.sampling.method = "ode"
+        cfg.eval.rtol, cfg.eval.atol = 1e-3, 1e-3
+        osamp = sampling.get_sampling_fn(cfg, sde, shape, inverse_scaler, cfg.sampling.truncation_time)
+        rec = Recorder()
+        with rec.on():
+            before, after, nfe = osamp(score, flow)
+        out["ode/before"], out["ode/after"], out["ode/nfe"] = before.numpy(), after.numpy(), np.asarray(nfe)
+        pack_events("ode", rec.events, out)
+
+    # ---- two training steps (the north-star path) ----
+    optimize_fn = losses.optimization_manager(cfg)
+    step_fn = losses.get_step_fn(cfg, sde, train=True, optimize_fn=optimize_fn, scaler=scaler)
+    state, fstate = make_states(cfg, score, flow)
+    score.train(); flow.train()
+    for it in range(2):
+        xb = data_batch(cfg, B, seed=100 + it)
+        out[f"step{it}/x"] = xb.numpy()
+        rec = Recorder()
+        with rec.on():
+            l, ls, lf, lp = step_fn(state, fstate, xb)
+        for nm, v in (("loss", l), ("loss_score", ls), ("loss_flow", lf), ("loss_logp", lp)):
+            out[f"step{it}/{nm}"] = v.numpy()
+        pack_events(f"step{it}", rec.events, out)
+        if it == 0:
+            gs = {n[len("module."):]: p.grad for n, p in score.named_parameters() if p.grad is not None}
+            gf = {n[len("module."):]: p.grad for n, p in flow.named_parameters() if p.grad is not None}
+            # grads after clipping (optimize_fn clips in place, losses.py:58-59)
+            for k, v in tensor_stats(gs.items()).items():
+                out[f"step0/gradstat/score/{k}"] = v
+            for k, v in tensor_stats(gf.items()).items():
+                out[f"step0/gradstat/flow/{k}"] = v
+    for pre, mod, st in (("score", score, state), ("flow", flow, fstate)):
+        named = [(n[len("module."):], p.detach()) for n, p in mod.named_parameters()]
+        for k, v in tensor_stats(named).items():
+            out[f"after2/{pre}/stat/{k}"] = v
+        tr = [n for n, p in named if dict(mod.named_parameters())["module." + n].requires_grad]
+        for n, s_ in zip(tr, st["ema"].shadow_params):
+            out[f"after2/{pre}/emastat/{n}"] = np.asarray([float(s_.double().sum()), float(s_.double().pow(2).sum())])
+        for n, p in named[:: max(1, len(named) // 6)]:
+            out[f"after2/{pre}/full/{n}"] = p.numpy().copy()
+    for k, v in flow.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            out[f"after2/flow/buffers/{k[len('module.'):]}"] = v.detach().numpy().copy()
+    out["after2/steps"] = np.asarray([state["step"], fstate["step"], state["ema"].num_updates])
+    np.savez_compressed(os.path.join(out_dir, f"{name}.npz"), **out)
+    print(name, "done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
+
+
+def patch_vp_nll(cfg):
+    pass
+
+
+def patch_vp_fid(cfg):
+    cfg.training.likelihood_weighting = False
+    cfg.training.importance_sampling = False
+
+
+def patch_ve(cfg):
+    pass
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sde", "ops", "vp_nll", "vp_fid", "ve"]
+    if "sde" in which:
+        golden_sde(HERE)
+    if "ops" in which:
+        golden_ops(HERE)
+    if "vp_nll" in which:
+        golden_model(HERE, "mini_vp_nll", "configs.vp.CIFAR10.indm_nll", patch_vp_nll)
+    if "vp_fid" in which:
+        golden_model(HERE, "mini_vp_fid", "configs.vp.CIFAR10.indm_fid", patch_vp_fid)
+    if "ve" in which:
+        golden_model(HERE, "mini_ve", "configs.ve.CIFAR10.indm", patch_ve)

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle (oracle/indm_oracle.py) to golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only; this is what makes every later HIP-vs-oracle comparison
+a comparison with the reference."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu
+import indm_oracle as O
+
+FIXTURES = ["mini_vp_nll", "mini_vp_fid", "mini_ve"]
+
+
+def bit_equal(a, b):
+    """bitwise equality with NaN == NaN (discretize() legitimately yields NaN for G^2 > 1)."""
+    return a.shape == b.shape and torch.allclose(a, b, rtol=0, atol=0, equal_nan=True)
+
+
+def test_sde_known_answers():
+    d = gu.load("sde_known_answers")
+    t, u, x = (torch.from_numpy(d[k]) for k in ("t", "u", "x"))
+    for name, sde in (("vp", O.VPSDE()), ("ve", O.VESDE())):
+        mean, std = sde.marginal_prob(x, t)
+        drift, diff = sde.sde(x, t)
+        for k, v in (("mean", mean), ("std", std), ("drift", drift), ("diffusion", diff),
+                     ("prior_logp", sde.prior_logp(x)), ("antiderivative", sde.antiderivative(t)),
+                     ("antiderivative_T", sde.antiderivative(1.0)), ("Z", sde.normalizing_constant(1e-5))):
+            assert bit_equal(v, torch.from_numpy(d[f"{name}/{k}"])), (name, k)
+        f, G = sde.discretize(x, t, None)
+        assert bit_equal(f, torch.from_numpy(d[f"{name}/disc_f"])) and bit_equal(G, torch.from_numpy(d[f"{name}/disc_G"]))
+        f, G = sde.discretize(x, t, t * 0.5)
+        assert bit_equal(f, torch.from_numpy(d[f"{name}/disc2_f"])) and bit_equal(G, torch.from_numpy(d[f"{name}/disc2_G"]))
+        tt, _ = sde.get_diffusion_time(7, 1e-5, True, O.ReplayRng([("rand", d["u"])]))
+        assert bit_equal(tt, torch.from_numpy(d[f"{name}/is_t"])), name
+    assert torch.equal(O.get_timestep_embedding(t * 999, 128), torch.from_numpy(d["timestep_embedding"]))
+    # SURVEY Appendix E anchors
+    vp = O.VPSDE()
+    assert abs(float(vp.normalizing_constant(1e-5)) - 23.852275848388672) < 1e-6
+    assert abs(float(vp.marginal_prob(x[:1], torch.tensor([1e-5]))[1]) - 0.00100661756) < 1e-9
+
+
+def test_native_op_oracles():
+    d = gu.load("native_ops")
+    for i, (c, h, w, up, down, p0, p1) in enumerate(d["cases"]):
+        for kn in ("fir", "rand"):
+            g = gu.sub(d, f"ufd{i}_{kn}")
+            x = g["x"].clone().requires_grad_(True)
+            y = O.upfirdn2d_native(x, g["k"], int(up), int(up), int(down), int(down), int(p0), int(p1), int(p0), int(p1))
+            gu.assert_close(y, g["y"], 1e-6, 1e-6, f"ufd{i}")
+            (gx,) = torch.autograd.grad(y, x, g["gy"])
+            gu.assert_close(gx, g["gx"], 1e-6, 1e-6, f"ufd{i} grad")
+    g = gu.sub(d, "flr")
+    gu.assert_close(O.fused_leaky_relu(g["x"], g["b"]), g["y"], 1e-6, 1e-6, "fused_leaky_relu")
+    gu.assert_close(O.fused_bias_act(g["x"], g["b"], None, 3, 0, 0.2, 2 ** 0.5), g["y"], 1e-6, 1e-6, "fused_bias_act")
+
+
+@pytest.mark.parametrize("fx", FIXTURES)
+def test_score_network(fx):
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    P = gu.state_dict(d, "score")
+    sde = O.get_sde(cfg)
+    x = torch.from_numpy(d["x"]).clone().requires_grad_(True)
+    t = torch.from_numpy(d["score/t"])
+    names = [k[len("score/grad/"):] for k in d if k.startswith("score/grad/")]
+    for n in names:
+        P[n].requires_grad_(True)
+    s = O.get_score_fn(P, cfg, sde, train=False)(x, t)
+    gu.assert_close(s, d["score/out"], 1e-4, 1e-5, "score out")
+    grads = torch.autograd.grad(s, [x] + [P[n] for n in names], torch.from_numpy(d["score/gy"]))
+    gu.assert_close(grads[0], d["score/gx"], 1e-4, 1e-5, "score gx")
+    for n, gr in zip(names, grads[1:]):
+        gu.assert_close(gr, d[f"score/grad/{n}"], 1e-4, 1e-5, n)
+
+
+@pytest.mark.parametrize("fx", FIXTURES)
+def test_flow_forward_modes(fx):
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    x = torch.from_numpy(d["x"])
+    for mode in ("train", "eval"):
+        P = gu.state_dict(d, "flow")
+        names = [k[len("flow_train/grad/"):] for k in d if k.startswith("flow_train/grad/")] if mode == "train" else []
+        for n in names:
+            P[n].requires_grad_(True)
+        rng = O.ReplayRng(gu.events(d, f"flow_{mode}"))
+        bn = {}
+        z, ld = O.flow_forward(P, cfg, x.clone(), training=(mode == "train"), rng=rng, bn_updates=bn)
+        assert rng.done()
+        gu.assert_close(z, d[f"flow_{mode}/z"], 1e-5, 1e-5, f"flow {mode} z")
+        gu.assert_close(ld, d[f"flow_{mode}/logdet_kl"], 2e-5, 1e-4, f"flow {mode} logdet")
+        if mode == "train":
+            gr = torch.autograd.grad([z, ld], [P[n] for n in names],
+                                     [torch.from_numpy(d["flow_train/gz"]), torch.tensor([1.0, -0.5])])
+            for n, g_ in zip(names, gr):
+                gu.assert_close(g_, d[f"flow_train/grad/{n}"], 2e-4, 2e-5, "grad " + n)
+            for k, v in bn.items():
+                gu.assert_close(v, d[f"flow_train/buffers/{k}"], 1e-5, 1e-6, k)
+    P = gu.state_dict(d, "flow")
+    rng = O.ReplayRng(gu.events(d, "flow_nologdet"))
+    with torch.no_grad():
+        z, _ = O.flow_forward(P, cfg, x.clone(), log_det=None, training=False, rng=rng)
+    gu.assert_close(z, d["flow_nologdet/z"], 1e-5, 1e-5, "flow nologdet")
+    rng = O.ReplayRng(gu.events(d, "flow_reverse"))
+    with torch.no_grad():
+        xr, _ = O.flow_forward(P, cfg, torch.from_numpy(d["flow_eval/z"]), log_det=None, reverse=True, rng=rng)
+    assert rng.done()
+    gu.assert_close(xr, d["flow_reverse/x"], 1e-4, 1e-4, "flow reverse")
+
+
+@pytest.mark.parametrize("fx", FIXTURES)
+def test_nelbo(fx):
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    Ps, Pf = gu.state_dict(d, "score"), gu.state_dict(d, "flow")
+    rng = O.ReplayRng(gu.events(d, "nelbo"))
+    b1, b2 = O.nelbo_fn(Ps, Pf, cfg, O.get_sde(cfg), torch.from_numpy(d["x"]), rng)
+    assert rng.done()
+    gu.assert_close(b1, d["nelbo/bpd"], 1e-4, 1e-4, "nelbo")
+    gu.assert_close(b2, d["nelbo/bpd_residual"], 1e-4, 1e-4, "nelbo residual")
+
+
+@pytest.mark.parametrize("fx", FIXTURES)
+def test_pc_sampler(fx):
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    cfg.sampling.method = "pc"
+    Ps, Pf = gu.state_dict(d, "score"), gu.state_dict(d, "flow")
+    rng = O.ReplayRng(gu.events(d, "pc"))
+    shape = tuple(d["x"].shape)
+    before, after, nfe = O.pc_sampler(Ps, Pf, cfg, O.get_sde(cfg), shape, rng, cfg.sampling.truncation_time)
+    assert rng.done() and nfe == int(d["pc/nfe"])
+    gu.assert_close(before, d["pc/before"], 1e-4, 1e-4, "pc before")
+    gu.assert_close(after, d["pc/after"], 1e-3, 1e-3, "pc after")
+
+
+@pytest.mark.parametrize("fx", ["mini_vp_nll"])
+def test_pf_ode_likelihood_and_sampler(fx):
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    Ps, Pf = gu.state_dict(d, "score"), gu.state_dict(d, "flow")
+    sde = O.get_sde(cfg)
+    x = torch.from_numpy(d["x"])
+    drift, div = O.pf_ode_drift_and_div(Ps, cfg, sde, x, torch.from_numpy(d["ode_rhs/t"]),
+                                        torch.from_numpy(d["ode_rhs/eps"]))
+    gu.assert_close(drift, d["ode_rhs/drift"], 1e-4, 1e-5, "pf-ode drift")
+    gu.assert_close(div, d["ode_rhs/div"], 1e-4, 1e-3, "pf-ode div")
+    rng = O.ReplayRng(gu.events(d, "nll"))
+    bpd, z, nfe = O.likelihood_fn(Ps, Pf, cfg, sde, x, rng, rtol=1e-3, atol=1e-3)
+    assert rng.done() and nfe == int(d["nll/nfe"])
+    gu.assert_close(bpd, d["nll/bpd"], 1e-4, 1e-3, "nll bpd")
+    gu.assert_close(z, d["nll/z"], 1e-3, 1e-3, "nll z")
+    rng = O.ReplayRng(gu.events(d, "ode"))
+    before, after, nfe = O.ode_sampler(Ps, Pf, cfg, sde, tuple(x.shape), rng, cfg.sampling.truncation_time, 1e-3, 1e-3)
+    assert rng.done() and nfe == int(d["ode/nfe"])
+    gu.assert_close(before, d["ode/before"], 1e-3, 1e-3, "ode before")
+    gu.assert_close(after, d["ode/after"], 1e-3, 1e-3, "ode after")
+
+
+@pytest.mark.parametrize("fx", FIXTURES)
+def test_two_training_steps(fx):
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    sde = O.get_sde(cfg)
+    state = O.OracleState(gu.state_dict(d, "score"), cfg.optim.lr, cfg.model.ema_rate, cfg)
+    fstate = O.OracleState(gu.state_dict(d, "flow"), cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    assert state.trainable == list(d["score_param_order"]) and fstate.trainable == list(d["flow_param_order"])
+    step = O.flow_step_fn_nll if cfg.training.likelihood_weighting else O.flow_step_fn_fid
+    for it in range(2):
+        rng = O.ReplayRng(gu.events(d, f"step{it}"))
+        out = step(cfg, sde, state, fstate, torch.from_numpy(d[f"step{it}/x"]), rng)
+        assert rng.done()
+        for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+            gu.assert_close(v, d[f"step{it}/{nm}"], 2e-4, 1e-5, f"step{it} {nm}")
+        if it == 0:
+            for pre, st in (("score", state), ("flow", fstate)):
+                for k in st.trainable:
+                    key = f"step0/gradstat/{pre}/{k}"
+                    if key in d:
+                        gu.assert_close(gu.stat(st.P[k].grad), d[key], 1e-3, 1e-7, "gradstat " + k)
+                    else:
+                        assert st.P[k].grad is None, k
+    for pre, st in (("score", state), ("flow", fstate)):
+        for k in st.trainable:
+            gu.assert_close(gu.stat(st.P[k]), d[f"after2/{pre}/stat/{k}"], 1e-5, 1e-6, "param " + k)
+        for k, s_ in zip(st.trainable, st.ema):
+            gu.assert_close(gu.stat(s_), d[f"after2/{pre}/emastat/{k}"], 1e-5, 1e-6, "ema " + k)
+        for k, v in gu.sub(d, f"after2/{pre}/full").items():
+            gu.assert_close(st.P[k], v, 1e-4, 2e-6, "full " + k)
+    for k, v in gu.sub(d, "after2/flow/buffers").items():
+        gu.assert_close(fstate.P[k].float(), v.float(), 1e-5, 1e-6, k)
+    assert [state.step, fstate.step, state.num_updates] == list(d["after2/steps"])
