@@ -82,6 +82,21 @@ __global__ __launch_bounds__(256) void lop_coldot_kernel(const float* __restrict
   if (rl == 0 && c < Co) out[c] = sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63];
 }
 
+// counts elements violating (x-xp)^2 / (atol + |y|*rtol) < 1  (iresblock.py:81-82)
+__global__ __launch_bounds__(256) void fp_check_kernel(const float* __restrict__ x, const float* __restrict__ xp,
+                                                       const float* __restrict__ y, long n, float atol, float rtol,
+                                                       float* __restrict__ out) {
+  __shared__ float sh[16];
+  float c = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = x[i] - xp[i];
+    const float tol = atol + fabsf(y[i]) * rtol;
+    c += (d * d / tol < 1.f) ? 0.f : 1.f;
+  }
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0 && c != 0.f) atomicAdd(out, c);
+}
+
 }  // namespace
 
 // a = sin(2*pi*p)/(2*pi), d = cos(2*pi*p)   (d may be null)
@@ -125,23 +140,25 @@ INDM_API int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n
   });
 }
 
-// out = a*x + b*y   (y may be null)
-INDM_API int indm_axpby_f32(const float* x, const float* y, float* out, float a, float b, long n, void* stream) {
+// out = a*x + b*y + c   (y may be null)
+INDM_API int indm_axpby_f32(const float* x, const float* y, float* out, float a, float b, float c, long n,
+                            void* stream) {
   if ((n & 3) == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)y) & 15) == 0) {
     const float4* x4 = (const float4*)x;
     const float4* y4 = (const float4*)y;
     float4* o4 = (float4*)out;
     return ew_launch(n >> 2, (hipStream_t)stream, [=] __device__(long i) {
       float4 v = x4[i];
-      v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+      v.x = a * v.x; v.y = a * v.y; v.z = a * v.z; v.w = a * v.w;
       if (y4) {
         const float4 w = y4[i];
         v.x += b * w.x; v.y += b * w.y; v.z += b * w.z; v.w += b * w.w;
       }
+      v.x += c; v.y += c; v.z += c; v.w += c;
       o4[i] = v;
     });
   }
-  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) { out[i] = a * x[i] + (y ? b * y[i] : 0.f); });
+  return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) { out[i] = a * x[i] + (y ? b * y[i] : 0.f) + c; });
 }
 
 // out = alpha * x * y
@@ -285,4 +302,15 @@ INDM_API int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const 
     }
     dw[i] = g;
   });
+}
+
+// out[0] = number of elements where NOT ((x-xp)^2 / (atol + |y|*rtol) < 1)  -- fixed-point stop test
+INDM_API int indm_fixed_point_check_f32(const float* x, const float* xp, const float* y, long n, float atol,
+                                        float rtol, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return INDM_E_LAUNCH;
+  if (n <= 0) return INDM_OK;
+  hipLaunchKernelGGL(fp_check_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, st, x, xp, y, n, atol, rtol, out);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
 }

@@ -35,7 +35,7 @@ struct IgemmParams {
   // convolution geometry (A_CONV / A_WGRAD / B_DGRAD)
   int H, W, Cin, OH, OW, KH, KW, stride, pad, dil;
   int Cout;  // B_DGRAD: inner (reduction) width per tap of the packed weight
-  // epilogue: C = alpha*acc + bias[n] + bias2[m/rpg][n] + beta*R[m][n]
+  // epilogue: C = alpha*(acc + bias[n] + bias2[m/rpg][n]) + beta*R[m][n]
   float alpha, beta;
   const float* bias;
   const float* bias2;
@@ -363,8 +363,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         if (m >= p.M) continue;
         float v = acc[i][j][r];
         if (!partial) {
-          v = p.alpha * v + bn;
+          v += bn;
           if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
+          v *= p.alpha;
           if (R) v += p.beta * R[(long)m * p.ldr + n];
         }
         C[(long)m * ldc + n] = v;
@@ -383,9 +384,10 @@ __global__ void igemm_splitk_reduce(IgemmParams p) {
     const int m = (int)(r / p.N), n = (int)(r - (long)m * p.N);
     float s = 0.f;
     for (int kz = 0; kz < p.splitk; ++kz) s += p.ws[((long)(bz * p.splitk + kz) * p.M + m) * p.N + n];
-    float v = p.alpha * s;
+    float v = s;
     if (p.bias) v += p.bias[n];
     if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
+    v *= p.alpha;
     if (p.R) v += p.beta * p.R[(long)bz * p.sR + (long)m * p.ldr + n];
     p.C[(long)bz * p.sC + (long)m * p.ldc + n] = v;
   }
@@ -459,7 +461,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
 // C ABI (declared in include/indm_hip.h)
 // ---------------------------------------------------------------------------
 
-// C[b] = alpha * opA(A[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n] + beta * R[b]
+// C[b] = alpha * (opA(A[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]
 //   transA == 0: A is [M,K] row-major (lda);  transA == 1: A is stored [K,M] (lda)
 //   transB == 0: B is [K,N] row-major (ldb);  transB == 1: B is stored [N,K] (ldb)
 INDM_API int indm_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int transA,

@@ -339,6 +339,66 @@ __global__ void colreduce_final_kernel(const float* __restrict__ part, float* __
   out[c] = alpha * s + (beta != 0.f ? beta * out[c] : 0.f);
 }
 
+// ---- BatchNorm2d (training-mode batch statistics) + optional ELU, rows = N*H*W, NHWC ----------
+// y = act((x - mean[c]) * rstd[c] * gamma[c] + beta[c])
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y, long n,
+                                                        int C, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float u = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+    if (act == 2) u = u > 0.f ? u : expm1f(u);
+    y[i] = u;
+  }
+}
+// dyu = dy * act'(u)
+__global__ __launch_bounds__(256) void bn_dyu_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ dyu, long n, int C, int act) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float d = dy[i];
+    if (act == 2) {
+      const float u = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+      d *= u > 0.f ? 1.f : expf(u);
+    }
+    dyu[i] = d;
+  }
+}
+// dx = gamma*rstd * (dyu - sdy[c]/R - xhat * sdyx[c]/R);  sdy = sum dyu, sdyx = sum dyu*xhat
+__global__ __launch_bounds__(256) void bn_dx_kernel(const float* __restrict__ dyu, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ sdy,
+                                                     const float* __restrict__ sdyx, float* __restrict__ dx, long n,
+                                                     int C, float invR) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float xh = (x[i] - mean[c]) * rstd[c];
+    dx[i] = gamma[c] * rstd[c] * (dyu[i] - sdy[c] * invR - xh * sdyx[c] * invR);
+  }
+}
+// mean/var from column sums; also emits dgamma = rstd*(sum(dyu*x) - mean*sum(dyu)) for the backward
+__global__ void bn_stats_final_kernel(const float* __restrict__ s1, const float* __restrict__ s2, float* __restrict__ mean,
+                                      float* __restrict__ var, float* __restrict__ rstd, int C, float invR, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = s1[c] * invR;
+  float v = s2[c] * invR - m * m;
+  v = fmaxf(v, 0.f);
+  mean[c] = m;
+  var[c] = v;
+  rstd[c] = rsqrtf(v + eps);
+}
+__global__ void bn_dgamma_kernel(const float* __restrict__ sdy, const float* __restrict__ sdyx_raw,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 float* __restrict__ dgamma, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] = rstd[c] * (sdyx_raw[c] - mean[c] * sdy[c]);
+}
+
 int gn_split(int N, int HW) {
   int S = (GN_SPLIT_TARGET + N - 1) / N;
   if (S > HW / 4) S = HW / 4;
@@ -438,6 +498,57 @@ INDM_API int indm_colreduce_f32(const float* x, const float* y, float* out, long
   hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C, 256), (int)P), dim3(256), 0, st, x, y, ws, R, C, mode, rpb);
   INDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, ws, out, C, (int)P, alpha, beta);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+// BatchNorm statistics over rows: mean[c], var[c] (biased), rstd[c] = rsqrt(var+eps).  ws >= colreduce ws + 2C.
+INDM_API int indm_bn_stats_f32(const float* x, float* mean, float* var, float* rstd, long R, int C, float eps,
+                               float* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  float* s1 = ws;
+  float* s2 = ws + C;
+  float* cws = ws + 2 * C;
+  int rc = indm_colreduce_f32(x, nullptr, s1, R, C, 0, 1.f, 0.f, cws, stream);
+  if (rc) return rc;
+  rc = indm_colreduce_f32(x, nullptr, s2, R, C, 2, 1.f, 0.f, cws, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, s1, s2, mean, var, rstd, C,
+                     1.f / (float)R, eps);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+// y = act(BN(x)) with given statistics; act: 0 none, 2 ELU
+INDM_API int indm_bn_apply_f32(const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, float* y, long R, int C, int act, void* stream) {
+  const long n = R * C;
+  if (n <= 0) return INDM_OK;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
+                     beta, y, n, C, act);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+// Backward of y = act(BN_batchstats(x)): dx, dgamma, dbeta.  ws >= colreduce ws + R*C + 2C floats.
+INDM_API int indm_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, float* dx, float* dgamma, float* dbeta, long R, int C, int act,
+                             float* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long n = R * C;
+  if (n <= 0) return INDM_OK;
+  float* dyu = ws;
+  float* sdyx = ws + n;
+  float* cws = sdyx + 2 * C;
+  hipLaunchKernelGGL(bn_dyu_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, dyu, n, C,
+                     act);
+  INDM_CHECK_LAUNCH();
+  int rc = indm_colreduce_f32(dyu, nullptr, dbeta, R, C, 0, 1.f, 0.f, cws, stream);
+  if (rc) return rc;
+  rc = indm_colreduce_f32(dyu, x, sdyx, R, C, 1, 1.f, 0.f, cws, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_dgamma_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dbeta, sdyx, mean, rstd, dgamma, C);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_dx_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, st, dyu, x, mean, rstd, gamma, dbeta, dgamma,
+                     dx, n, C, 1.f / (float)R);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

@@ -146,6 +146,53 @@ __global__ __launch_bounds__(256) void langevin_step_kernel(const float* __restr
   }
 }
 
+// log|det W| and W^-1 of one n x n (n <= 64) matrix: Gauss-Jordan with partial pivoting, one wavefront,
+// the augmented [n][2n] system lives in LDS (lane i owns row i).
+__global__ __launch_bounds__(64) void slogdet_inv_kernel(const float* __restrict__ W, int n, float* __restrict__ logdet,
+                                                          float* __restrict__ inv) {
+  __shared__ float a[64][129];
+  const int lane = threadIdx.x;
+  const int n2 = 2 * n;
+  for (int j = 0; j < n2; ++j)
+    if (lane < n) a[lane][j] = j < n ? W[lane * n + j] : (j - n == lane ? 1.f : 0.f);
+  __syncthreads();
+  float ld = 0.f;
+  for (int k = 0; k < n; ++k) {
+    // pivot search over rows >= k
+    float v = (lane >= k && lane < n) ? fabsf(a[lane][k]) : -1.f;
+    int idx = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    const int p = idx;
+    if (p != k) {
+      for (int j = lane; j < n2; j += 64) {
+        const float t = a[k][j];
+        a[k][j] = a[p][j];
+        a[p][j] = t;
+      }
+    }
+    __syncthreads();
+    const float piv = a[k][k];
+    ld += logf(fabsf(piv));
+    __syncthreads();
+    for (int j = lane; j < n2; j += 64) a[k][j] /= piv;
+    __syncthreads();
+    if (lane < n && lane != k) {
+      const float f = a[lane][k];
+      if (f != 0.f)
+        for (int j = 0; j < n2; ++j) a[lane][j] -= f * a[k][j];
+    }
+    __syncthreads();
+  }
+  if (lane == 0) logdet[0] = ld;
+  for (int j = 0; j < n; ++j)
+    if (lane < n) inv[lane * n + j] = a[lane][n + j];
+}
+
 }  // namespace
 
 // out[b,:] = mc[b]*x[b,:] + sd[b]*noise[b,:]   (noise / sd may be null -> pure scaling)
@@ -245,6 +292,20 @@ INDM_API int indm_adamw_ema_f32(float* p, const float* g, float* m, float* v, fl
   a.clip = clip; a.ema_omd = ema_one_minus_decay; a.gscale = gscale;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(ew_grid(n >> 2, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema,
                      n, a, gnorm_sq);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+// s -= omd * (s - p)   (models/ema.py:49-51)
+INDM_API int indm_ema_update_f32(float* s, const float* p, long n, float one_minus_decay, void* stream) {
+  return ew2_launch(n, (hipStream_t)stream, [=] __device__(long i) { s[i] -= one_minus_decay * (s[i] - p[i]); });
+}
+
+// logdet[0] = log|det W|, inv = W^-1 for an n x n matrix, n <= 64 (replaces the reference's host-side
+// torch.slogdet(weight.to('cpu')), flows/permutation.py:107-108, and provides d logdet/dW = inv^T)
+INDM_API int indm_slogdet_inv_f32(const float* W, int n, float* logdet, float* inv, void* stream) {
+  if (n <= 0 || n > 64) return INDM_E_SHAPE;
+  hipLaunchKernelGGL(slogdet_inv_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, W, n, logdet, inv);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

@@ -1,0 +1,635 @@
+"""The INDM flow (wolf VAE shell around a conditional Residual Flow) on the HIP kernels.
+
+Mirror of flow_models/flow_model.py (flow_forward / create_flow_model), flow_models/wolf/wolf.py
+(WolfCore.forward :81-130) and flow_models/wolf/flows/resflow/** with the reference's state-dict
+names.  MI355X-first differences in HOW it is computed (results identical within fp32 tolerance):
+
+  * log-det engine: the reference differentiates the g-net with autograd (n+3 VJPs per block,
+    one of them create_graph=True -> double backward).  Here the VJP  v -> v^T dg/dx  is an explicit
+    forward chain of transposed MFMA convolutions / GEMMs and cos(2 pi p) gates saved by the fused
+    Sin kernel, so the Neumann series is a plain loop and the estimator's gradient is ordinary
+    first-order autograd through that chain (DESIGN.md "log-det engine").
+  * Lop weight normalisation is evaluated ONCE per flow call and shared by g and all VJPs
+    (the reference recomputes it in every conv call, lipschitz.py:350-363).
+  * the conditioning input (a1 + Linear(h)) W2 + b2 is folded into the GEMM epilogue as a per-image
+    bias  (Linear(h) W2 + b2).
+  * slogdet of the 64x64 prior matrix runs on the GPU (one-wavefront Gauss-Jordan) instead of a
+    host round trip (permutation.py:107-108).
+Tensors are NHWC inside; the NCHW boundary is converted once in flow_forward.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip, ops
+
+
+def poisson_1mcdf(lamb, k, offset):
+    """iresblock.py:309-318"""
+    if k <= offset:
+        return 1.0
+    k = k - offset
+    s = 1.0
+    for i in range(1, k):
+        s += lamb ** i / math.factorial(i)
+    return 1 - np.exp(-lamb) * s
+
+
+# ----------------------------------------------------------------------------- Lop convolutions
+class LopConv(nn.Module):
+    """LopConv2d / LopCondConv2d (layers/base/lipschitz.py:321-441); weight RSCK (3x3) or [Cin,Cout] (1x1)."""
+
+    def __init__(self, in_ch, out_ch, k, cond=False, coeff=0.98):
+        super().__init__()
+        ref = torch.nn.Conv2d(in_ch, out_ch, k, 1, k // 2)  # nn.Conv2d default init (kaiming-uniform)
+        w = ref.weight.detach()
+        self.k, self.coeff, self.in_ch, self.out_ch = k, coeff, in_ch, out_ch
+        self.weight = nn.Parameter(w.permute(2, 3, 1, 0).contiguous() if k == 3 else w[:, :, 0, 0].t().contiguous())
+        self.bias = nn.Parameter(ref.bias.detach().clone())
+        self.register_buffer("scale", torch.tensor(0.0))
+        if cond:
+            h_net = nn.Module()
+            net = nn.Module()
+            lin = torch.nn.Linear(64, in_ch)
+            net.weight = nn.Parameter(lin.weight.detach().clone())
+            net.bias = nn.Parameter(lin.bias.detach().clone())
+            h_net.net = net
+            self.h_net = h_net
+
+    def normalized(self):
+        wn, l1 = ops.lop_normalize(self.weight, self.coeff)
+        with torch.no_grad():
+            self.scale.copy_(l1.max())  # lipschitz.py:353-354
+        return wn
+
+
+class Placeholder(nn.Module):
+    """Stands in for the parameter-free Sin modules so nn.Sequential indices match the reference."""
+
+
+class IResBlock(nn.Module):
+    """iResBlock (layers/iresblock.py:14-174) with nnet = [Sin?] Lop3x3 Sin LopCond1x1 Sin Lop3x3."""
+
+    def __init__(self, ch, idim, preact):
+        super().__init__()
+        self.geom_p = nn.Parameter(torch.tensor(np.log(0.5) - np.log(1.0 - 0.5), dtype=torch.float32))
+        self.lamb = nn.Parameter(torch.tensor(2.0))
+        self.register_buffer("last_n_samples", torch.zeros(1))
+        self.register_buffer("last_firmom", torch.zeros(1))
+        self.register_buffer("last_secmom", torch.zeros(1))
+        mods = ([Placeholder()] if preact else []) + [LopConv(ch, idim, 3), Placeholder(), LopConv(idim, idim, 1, True),
+                                                     Placeholder(), LopConv(idim, ch, 3)]
+        self.nnet = nn.Sequential(*mods)
+        self.preact = preact
+        self.convs = [m for m in mods if isinstance(m, LopConv)]
+        self.lamb_value = 2.0  # lamb never receives a gradient (iresblock.py:110 uses .item())
+
+    def weights(self):
+        return [c.normalized() for c in self.convs]
+
+    def g(self, x, h, W, want_gates):
+        """g(x,h) and (optionally) the cos gates d0,d1,d2 for the VJP chain."""
+        c1, c2, c3 = self.convs
+        W1, W2, W3 = W
+        d0 = None
+        a0 = x
+        if self.preact:
+            a0, d0 = ops.sincos(x)
+        p1 = ops.conv2d(a0, W1, c1.bias)
+        a1, d1 = ops.sincos(p1)
+        cb = ops.linear(h, c2.h_net.net.weight, c2.h_net.net.bias)        # [B, idim]
+        cb = ops.gemm(cb, W2)                                              # Linear(h) W2 (conditioning folded)
+        p2 = ops.conv1x1(a1, W2, c2.bias, cb)
+        a2, d2 = ops.sincos(p2)
+        g = ops.conv2d(a2, W3, c3.bias)
+        return g, ((d0, d1, d2) if want_gates else None)
+
+    def vjp(self, v, W, gates, hw):
+        """v^T dg/dx as an explicit chain (replaces torch.autograd.grad(g, x, v), iresblock.py:257,269-271)."""
+        W1, W2, W3 = W
+        d0, d1, d2 = gates
+        t = ops.conv2d_t(v, W3, hw)
+        t = ops.mul(t, d2)
+        t = ops.conv1x1_t(t, W2)
+        t = ops.mul(t, d1)
+        t = ops.conv2d_t(t, W1, hw)
+        if d0 is not None:
+            t = ops.mul(t, d0)
+        return t
+
+    def forward_logdet(self, x, h, W, rng, stats):
+        """_logdetgrad iresblock.py:90-174 (poisson, n_samples=1, neumann_grad in training)."""
+        lamb = self.lamb_value
+        n = rng.poisson(lamb)
+        training = self.training
+        n_exact = 2 if training else 20
+        K = n + n_exact
+
+        def coeff(k):
+            return 1.0 / poisson_1mcdf(lamb, k, n_exact) * (1.0 if n >= k - n_exact else 0.0)
+
+        N, H, Wd, C = x.shape
+        eps = rng.randn_image(N, C, H, Wd)
+        g, gates = self.g(x, h, W, True)
+        hw = (H, Wd)
+        if training:  # neumann_logdet_estimator :264-273
+            with torch.no_grad():
+                vjp, nvjp = eps, eps
+                for k in range(1, K + 1):
+                    vjp = self.vjp(vjp, W, gates, hw)
+                    nvjp = ops.axpby(nvjp, vjp, 1.0, (-1) ** k * coeff(k))
+            vj = self.vjp(nvjp, W, gates, hw)
+            logdet = ops.rowdot(vj, eps)
+        else:  # basic_logdet_estimator :253-261 (create_graph=False)
+            with torch.no_grad():
+                vjp = eps
+                logdet = None
+                for k in range(1, K + 1):
+                    vjp = self.vjp(vjp, W, gates, hw)
+                    tr = hip.rowreduce(vjp, eps, 0, (-1) ** (k + 1) / k * coeff(k))
+                    logdet = tr if logdet is None else logdet + tr
+        if training and stats is not None:
+            stats.append((self, n, logdet.detach()))
+        return ops.axpby(x, g), logdet
+
+    def inverse(self, y, h, W, atol=1e-5, rtol=1e-5, iters=None):
+        """_inverse_fixed_point iresblock.py:78-88"""
+        g, _ = self.g(y, h, W, False)
+        x, x_prev = ops.axpby(y, g, 1.0, -1.0), y
+        i = 0
+        while float(hip.fixed_point_check(x, x_prev, y, atol, rtol)) != 0.0:
+            g, _ = self.g(x, h, W, False)
+            x, x_prev = ops.axpby(y, g, 1.0, -1.0), x
+            i += 1
+            if i > 1000:
+                break
+        if iters is not None:
+            iters.append(i)
+        return x
+
+
+class SqueezeLayer(nn.Module):
+    pass
+
+
+class StackediResBlocks(nn.Module):
+    def __init__(self, ch, idim, n_blocks, squeeze, first_resblock):
+        super().__init__()
+        chain = [IResBlock(ch, idim, preact=not (first_resblock and i == 0)) for i in range(n_blocks)]
+        if squeeze:
+            chain.append(SqueezeLayer())
+        self.chain = nn.ModuleList(chain)
+
+
+class ResidualFlow(nn.Module):
+    """flows/resflow/resflow_.py:20-335 with the options every shipped config uses."""
+
+    def __init__(self, in_ch, n_blocks, idim):
+        super().__init__()
+        tr = []
+        c = in_ch
+        for i, nb in enumerate(n_blocks):
+            tr.append(StackediResBlocks(c, idim, nb, squeeze=i < len(n_blocks) - 1, first_resblock=i == 0))
+            c *= 4
+        self.transforms = nn.ModuleList(tr)
+
+    def blocks(self):
+        return [[b for b in t.chain if isinstance(b, IResBlock)] for t in self.transforms]
+
+    def fwdpass(self, x, h, eval_logdet, rng, stats=None):
+        """:310-324 -- returns (z, logpx) with logpx = -sum logdet (as the reference)."""
+        scales = self.blocks()
+        logpx = None
+        for si, blocks in enumerate(scales):
+            for b in blocks:
+                W = b.weights()
+                if eval_logdet:
+                    x, ld = b.forward_logdet(x, h, W, rng, stats)
+                    logpx = -ld if logpx is None else logpx - ld
+                else:
+                    g, _ = b.g(x, h, W, False)
+                    x = ops.axpby(x, g)
+            if si < len(scales) - 1:
+                x = ops.squeeze2x(x)
+        for _ in range(len(scales) - 1):
+            x = ops.unsqueeze2x(x)
+        return (x, logpx) if eval_logdet else x
+
+    def bwdpass(self, z, h, iters=None):
+        """:326-335 + inverse :237-267"""
+        scales = self.blocks()
+        for _ in range(len(scales) - 1):
+            z = ops.squeeze2x(z)
+        for si in range(len(scales) - 1, -1, -1):
+            if si < len(scales) - 1:
+                z = ops.unsqueeze2x(z)
+            for b in reversed(scales[si]):
+                z = b.inverse(z, h, b.weights(), iters=iters)
+        return z
+
+
+# ----------------------------------------------------------------------------- encoder (discriminator)
+class _ConvNoBias(nn.Module):
+    def __init__(self, in_ch, out_ch, k, stride):
+        super().__init__()
+        ref = torch.nn.Conv2d(in_ch, out_ch, k, stride, k // 2, bias=False)
+        w = ref.weight.detach()
+        self.weight = nn.Parameter(w.permute(2, 3, 1, 0).contiguous())
+        self.k, self.stride = k, stride
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, None, None, None, self.stride, self.k // 2)
+
+
+class _BatchNorm(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(ch))
+        self.bias = nn.Parameter(torch.zeros(ch))
+        self.register_buffer("running_mean", torch.zeros(ch))
+        self.register_buffer("running_var", torch.ones(ch))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, elu):
+        stats = []
+        y = ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training, 1e-5,
+                               elu, stats)
+        if self.training:
+            mean, var = stats[0]
+            n = x.numel() // x.shape[-1]
+            with torch.no_grad():  # nn.BatchNorm2d momentum 0.1, unbiased running var
+                self.running_mean.mul_(0.9).add_(mean, alpha=0.1)
+                self.running_var.mul_(0.9).add_(var, alpha=0.1 * n / (n - 1))
+                self.num_batches_tracked.add_(1)
+        return y
+
+
+class ResNetBlockBatchNorm(nn.Module):
+    """nnet/resnets/resnet_batchnorm.py:18-76 (activation = ELU)"""
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        self.conv1 = _ConvNoBias(inplanes, planes, 3, stride)
+        self.bn1 = _BatchNorm(planes)
+        self.conv2 = _ConvNoBias(planes, planes, 3, 1)
+        self.bn2 = _BatchNorm(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(_ConvNoBias(inplanes, planes, 1, stride), _BatchNorm(planes))
+
+    def forward(self, x):
+        out = self.bn1(self.conv1(x), True)
+        out = self.bn2(self.conv2(out), False)
+        res = x
+        if self.downsample is not None:
+            res = self.downsample[1](self.downsample[0](x), False)
+        return ops.elu(ops.axpby(out, res))
+
+
+class _ResNet(nn.Module):
+    def __init__(self, inplanes, planes, strides):
+        super().__init__()
+        blocks = []
+        for p, s in zip(planes, strides):
+            blocks.append(ResNetBlockBatchNorm(inplanes, p, s))
+            inplanes = p
+        self.main = nn.Sequential(*blocks)
+
+
+class GlobalResNetEncoderBatchNorm(nn.Module):
+    """modules/encoders/global_encoder.py:12-44"""
+
+    def __init__(self, levels, in_planes, out_planes, hidden_planes, activation="elu"):
+        super().__init__()
+        net = nn.Module()
+        self.levels = levels
+        for lvl in range(levels):
+            setattr(net, f"resnet{lvl}", _ResNet(in_planes, [hidden_planes[lvl]] * 2, [1, 2]))
+            in_planes = hidden_planes[lvl]
+        ref = torch.nn.Conv2d(in_planes, out_planes, 1, bias=True)
+        top = nn.Module()
+        top.weight = nn.Parameter(ref.weight.detach()[:, :, 0, 0].t().contiguous())  # [Cin, Cout]
+        top.bias = nn.Parameter(ref.bias.detach().clone())
+        net.top = top
+        self.net = net
+
+    def forward(self, x):
+        for lvl in range(self.levels):
+            for blk in getattr(self.net, f"resnet{lvl}").main:
+                x = blk(x)
+        x = ops.elu(ops.conv1x1(x, self.net.top.weight, self.net.top.bias))
+        # reference flattens NCHW ([B, out_planes*h*w], global_encoder.py:36)
+        return ops.to_nchw(x).reshape(x.shape[0], -1)
+
+
+class LinearWeightNorm(nn.Module):
+    """nnet/weight_norm.py:8-40: nn.utils.weight_norm(Linear), init N(0, 0.05)."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        lin = nn.Module()
+        ref = torch.nn.Linear(in_f, out_f)
+        w = torch.nn.init.normal_(ref.weight.detach().clone(), mean=0.0, std=0.05)
+        lin.bias = nn.Parameter(torch.zeros(out_f))
+        lin.weight_g = nn.Parameter(w.norm(dim=1, keepdim=True))
+        lin.weight_v = nn.Parameter(w)
+        self.linear = lin
+
+    def forward(self, x):
+        v, g = self.linear.weight_v, self.linear.weight_g
+        w = v * (g / v.norm(dim=1, keepdim=True))  # [out,in] <= 64x256: host-sized glue
+        return ops.linear(x, w, self.linear.bias)
+
+
+# ----------------------------------------------------------------------------- prior flow on h (64-d)
+class _Lin(nn.Module):
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        ref = torch.nn.Linear(in_f, out_f)
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(torch.zeros(out_f))
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class NICEMLPBlock(nn.Module):
+    """flows/couplings/blocks.py:11-48"""
+
+    def __init__(self, in_f, out_f, hidden):
+        super().__init__()
+        self.fc1 = _Lin(in_f, hidden)
+        self.fc2 = _Lin(hidden, hidden)
+        self.fc3 = LinearWeightNorm(hidden, out_f)
+
+    def forward(self, x):
+        return self.fc3(ops.elu(self.fc2(ops.elu(self.fc1(x)))))
+
+
+class NICE1d(nn.Module):
+    """flows/couplings/coupling.py:13-177 with the Affine transform (transform.py:49-81)."""
+
+    def __init__(self, features, hidden, split_type, up):
+        super().__init__()
+        out_f = features // 2
+        in_f = features - out_f
+        self.split_type, self.up = split_type, up
+        self.z1_features = in_f if up else out_f
+        self.net = NICEMLPBlock(in_f, out_f * 2, hidden)
+
+    def _run(self, x, backward):
+        d = x.shape[-1]
+        if self.split_type == "continuous":
+            z1, z2 = x[..., :self.z1_features], x[..., self.z1_features:]
+        else:
+            z1, z2 = x[..., 0::2], x[..., 1::2]
+        z, zp = (z1, z2) if self.up else (z2, z1)
+        params = self.net(z.contiguous())
+        mu, ls = params.chunk(2, dim=-1)
+        scale = torch.sigmoid(ls + 2.0) + 1e-3
+        if not backward:
+            zp = scale * zp + mu
+            logdet = scale.log().reshape(x.shape[0], -1).sum(1)
+        else:
+            zp = (zp - mu) / (scale + 1e-12)
+            logdet = -scale.log().reshape(x.shape[0], -1).sum(1)
+        z1, z2 = (z, zp) if self.up else (zp, z)
+        if self.split_type == "continuous":
+            return torch.cat([z1, z2], dim=-1), logdet
+        return torch.stack([z1, z2], dim=-1).reshape(x.shape), logdet
+
+
+class ActNorm1dFlow(nn.Module):
+    """flows/normalization.py:13-75"""
+
+    def __init__(self, features):
+        super().__init__()
+        self.log_scale = nn.Parameter(torch.nn.init.normal_(torch.empty(features), mean=0, std=0.05))
+        self.bias = nn.Parameter(torch.zeros(features))
+
+    def _run(self, x, backward):
+        if not backward:
+            return x * self.log_scale.exp() + self.bias, self.log_scale.sum(0, keepdim=True)
+        return (x - self.bias) / (self.log_scale.exp() + 1e-8), -self.log_scale.sum(0, keepdim=True)
+
+
+class InvertibleLinearFlow(nn.Module):
+    """flows/permutation.py:75-136.  weight_inv is a buffer refreshed only by sync() -- the reference never
+    calls sync() from run_lib, so sampling uses whatever the constructor / checkpoint left there."""
+
+    def __init__(self, features):
+        super().__init__()
+        self.weight = nn.Parameter(torch.nn.init.orthogonal_(torch.empty(features, features)))
+        self.register_buffer("weight_inv", self.weight.data.inverse().clone())
+
+    def sync(self):
+        self.weight_inv.copy_(self.weight.data.inverse())
+
+    def _run(self, x, backward):
+        w = self.weight_inv if backward else self.weight
+        shp = x.shape
+        out = ops.gemm(x.reshape(-1, shp[-1]), w, trans_b=True, weight_b=True).reshape(shp)
+        return out, ops.slogdet(w)
+
+
+class PriorFlowUnit(nn.Module):
+    ORDER = ("coupling1_up", "coupling1_dn", "actnorm", "coupling2_up", "coupling2_dn")
+
+    def __init__(self, features, hidden):
+        super().__init__()
+        self.coupling1_up = NICE1d(features, hidden, "continuous", True)
+        self.coupling1_dn = NICE1d(features, hidden, "continuous", False)
+        self.actnorm = ActNorm1dFlow(features)
+        self.coupling2_up = NICE1d(features, hidden, "skip", True)
+        self.coupling2_dn = NICE1d(features, hidden, "skip", False)
+
+
+class PriorFlowStep(nn.Module):
+    def __init__(self, features, hidden):
+        super().__init__()
+        self.actnorm = ActNorm1dFlow(features)
+        self.linear = InvertibleLinearFlow(features)
+        self.unit = PriorFlowUnit(features, hidden)
+
+
+class PriorFlow(nn.Module):
+    """modules/discriminators/priors/flow.py:16-201 (inverse=True flow)."""
+
+    def __init__(self, num_steps, features, hidden):
+        super().__init__()
+        self.steps = nn.ModuleList([PriorFlowStep(features, hidden) for _ in range(num_steps)])
+
+    def run(self, x, backward):
+        logdet = x.new_zeros(x.shape[0])
+        steps = list(self.steps)
+        for st in (steps if not backward else reversed(steps)):
+            seq = [st.actnorm, st.linear] + [getattr(st.unit, n) for n in PriorFlowUnit.ORDER]
+            for m in (seq if not backward else reversed(seq)):
+                x, ld = m._run(x, backward)
+                logdet = logdet + ld
+        return x, logdet
+
+
+class FlowPrior(nn.Module):
+    def __init__(self, num_steps, in_features, hidden_features, **_):
+        super().__init__()
+        self.flow = PriorFlow(num_steps, in_features, hidden_features)
+
+    def calcKL(self, z, eps, mu, logvar):
+        """priors/flow.py:232-253"""
+        dim = z.size(2)
+        cc = math.log(math.pi * 2.0)
+        log_post = ((logvar.unsqueeze(1) + eps.pow(2)).sum(dim=2) + cc * dim).mean(dim=1) * -0.5
+        e, logdet = self.flow.run(z, backward=False)  # bwdpass of an inverse flow = Flow.forward
+        e = e.reshape(e.size(0), -1)
+        log_prior = ((e * e).sum(dim=1) + cc * e.size(1)) * -0.5 + logdet
+        return log_post - log_prior / z.size(1)
+
+    def sample(self, nsamples, dim, rng):
+        """priors/flow.py:226-230"""
+        eps = rng.randn(nsamples, dim)
+        z, _ = self.flow.run(eps, backward=True)
+        return z
+
+
+class GaussianDiscriminator(nn.Module):
+    """modules/discriminators/gaussian.py:14-100"""
+
+    def __init__(self, wolf_cfg):
+        super().__init__()
+        e = wolf_cfg.encoder
+        self.dim = wolf_cfg.dim
+        self.encoder = GlobalResNetEncoderBatchNorm(e.levels, e.in_planes, e.out_planes, list(e.hidden_planes))
+        self.fc = LinearWeightNorm(wolf_cfg.in_dim, 2 * wolf_cfg.dim)
+        p = wolf_cfg.prior
+        self.prior = FlowPrior(p.num_steps, p.in_features, p.hidden_features)
+
+    def sampling_and_KL(self, x, rng):
+        c = self.fc(self.encoder(x))
+        mu, logvar = c.chunk(2, dim=1)
+        eps = rng.randn(mu.shape[0], 1, mu.shape[1])
+        z = eps * logvar.mul(0.5).exp().unsqueeze(1) + mu.unsqueeze(1)
+        return z, self.prior.calcKL(z, eps, mu, logvar)
+
+
+class Generator(nn.Module):
+    def __init__(self, flow):
+        super().__init__()
+        self.flow = flow
+
+
+class WolfCore(nn.Module):
+    """flow_models/wolf/wolf.py:18-145 (NHWC in / NHWC out; see flow_forward for the NCHW boundary)."""
+
+    def __init__(self, config):
+        super().__init__()
+        c = config
+        in_ch = c.data.num_channels * (4 if c.flow.squeeze else 1)
+        self.generator = Generator(ResidualFlow(in_ch, list(map(int, c.flow.nblocks.split("-"))),
+                                                c.flow.intermediate_dim))
+        self.discriminator = GaussianDiscriminator(c.flow.wolf)
+        self.config = config
+
+    def forward(self, data, y=None, n_bits=8, nsamples=1, reverse=False, eval_logdet=True, rng=None, stats=None,
+                iters=None):
+        if rng is None:
+            from .rng import DeviceRng
+            rng = DeviceRng(data.device)
+        if reverse:
+            h = self.discriminator.prior.sample(data.shape[0], self.discriminator.dim, rng)
+            return self.generator.flow.bwdpass(data, h.contiguous(), iters)
+        z, kl = self.discriminator.sampling_and_KL(data, rng)
+        h = z.reshape(-1, z.size(2)).contiguous()
+        if eval_logdet:
+            st = [] if (self.training and stats is None) else stats
+            eps, logpx = self.generator.flow.fwdpass(data, h, True, rng, st)
+            if self.training and st:
+                self._update_moment_buffers(st)
+            return eps, -logpx - kl
+        return self.generator.flow.fwdpass(data, h, False, rng)
+
+    @staticmethod
+    def _update_moment_buffers(st):
+        """iresblock.py:169-173, batched: one stack + two reductions instead of 3 host syncs per block."""
+        with torch.no_grad():
+            L = torch.stack([ld for _, _, ld in st])  # [nblocks, B]
+            fir, sec = L.mean(1), (L * L).mean(1)
+            for i, (blk, n, _) in enumerate(st):
+                blk.last_n_samples.fill_(float(n))
+                blk.last_firmom.copy_(fir[i:i + 1])
+                blk.last_secmom.copy_(sec[i:i + 1])
+
+    # ------------------------------------------------------------------ checkpoint boundary
+    @staticmethod
+    def _to_native(k, v):
+        if v.dim() == 4:
+            if v.shape[2] == 1 and v.shape[3] == 1 and (".nnet." in k or k.endswith("net.top.weight")):
+                return v[:, :, 0, 0].t().contiguous()
+            return v.permute(2, 3, 1, 0).contiguous()
+        return v
+
+    def load_reference_state_dict(self, sd):
+        own = self.state_dict()
+        new = {}
+        for k, v in sd.items():
+            k2 = k[len("module."):] if k.startswith("module.") else k
+            if k2 not in own:
+                raise KeyError(k2)
+            v = self._to_native(k2, torch.as_tensor(v))
+            if tuple(v.shape) != tuple(own[k2].shape):
+                v = v.reshape(own[k2].shape)
+            new[k2] = v.to(own[k2].dtype)
+        missing = set(own) - set(new)
+        if missing:
+            raise KeyError(f"missing keys: {sorted(missing)[:5]}")
+        self.load_state_dict(new)
+        for m in self.modules():
+            if isinstance(m, IResBlock):
+                m.lamb_value = float(m.lamb)
+
+    @staticmethod
+    def to_reference_layout(k, v):
+        """Convert a tensor shaped like parameter `k` (weight, gradient, EMA shadow) to the reference layout."""
+        v = v.detach()
+        if v.dim() == 4:
+            return v.permute(3, 2, 0, 1).contiguous()
+        if v.dim() == 2 and (".nnet." in k and k.endswith(".weight") and "h_net" not in k
+                             or k.endswith("net.top.weight")):
+            return v.t().contiguous()[:, :, None, None]
+        return v
+
+    def reference_state_dict(self, prefix="module."):
+        return {prefix + k: self.to_reference_layout(k, v) for k, v in self.state_dict().items()}
+
+
+def create_flow_model(config):
+    """flow_models/flow_model.py:86-111 ('wolf' branch)."""
+    if config.flow.model != "wolf":
+        raise NotImplementedError(config.flow.model)
+    return WolfCore(config)
+
+
+def flow_forward(config, flow_model, x, log_det=0, reverse=False, rng=None, stats=None, iters=None):
+    """flow_models/flow_model.py:7-69 ('wolf' branch :53-67).  x, z are NCHW like the reference."""
+    if config.flow.model != "wolf":
+        raise NotImplementedError(config.flow.model)
+    m = flow_model.module if hasattr(flow_model, "module") else flow_model
+    h = ops.to_nhwc(x)
+    if config.flow.squeeze:
+        h = ops.squeeze2x(h)
+    if not reverse:
+        if log_det == 0:
+            z, logdet_kl = m(h, y=None, n_bits=config.flow.n_bits, nsamples=config.flow.train_k, reverse=False,
+                             eval_logdet=True, rng=rng, stats=stats)
+        else:
+            z = m(h, y=None, n_bits=config.flow.n_bits, nsamples=config.flow.train_k, reverse=False,
+                  eval_logdet=False, rng=rng)
+            logdet_kl = -1
+    else:
+        z = m(h, reverse=True, rng=rng, iters=iters)
+        logdet_kl = -1
+    if config.flow.squeeze:
+        z = ops.unsqueeze2x(z)
+    return ops.to_nchw(z), logdet_kl

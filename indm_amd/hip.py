@@ -46,7 +46,7 @@ _SIGS = {
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
     "indm_act_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
-    "indm_axpby_f32": [c_p, c_p, c_p, c_f, c_f, c_l, c_p],
+    "indm_axpby_f32": [c_p, c_p, c_p, c_f, c_f, c_f, c_l, c_p],
     "indm_mul_f32": [c_p, c_p, c_p, c_f, c_l, c_p],
     "indm_scale_rows_f32": [c_p, c_p, c_p, c_l, c_l, c_p],
     "indm_rowreduce_ws_floats": [c_l, c_l],
@@ -67,6 +67,12 @@ _SIGS = {
     "indm_sqnorm_ws_floats": [],
     "indm_sqnorm_f32": [c_p, c_l, c_p, c_p, c_p],
     "indm_adamw_ema_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p, c_f, c_f, c_p],
+    "indm_fixed_point_check_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p, c_p],
+    "indm_ema_update_f32": [c_p, c_p, c_l, c_f, c_p],
+    "indm_slogdet_inv_f32": [c_p, c_i, c_p, c_p, c_p],
+    "indm_bn_stats_f32": [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_p, c_p],
+    "indm_bn_apply_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p],
+    "indm_bn_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p],
     "indm_upfirdn2d_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                            c_p],
     "indm_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
@@ -138,7 +144,7 @@ SPLITK_WS_FLOATS = 1 << 25  # 128 MiB of fp32 partial slabs for weight-grad spli
 # --------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, rows_per_group=1, res=None,
          beta=1.0, splitk=False):
-    """C[(batch),M,N] = alpha * op(a) @ op(b) + bias[N] + bias2[M//rows_per_group, N] + beta*res.
+    """C[(batch),M,N] = alpha * (op(a) @ op(b) + bias[N] + bias2[M//rows_per_group, N]) + beta*res.
 
     a: [..,M,K] (or stored [..,K,M] when trans_a); b: [..,K,N] (or stored [..,N,K] when trans_b).
     2-D operands broadcast over the batch of the other one.
@@ -169,7 +175,7 @@ def conv_out_size(h, k, stride, pad):
 
 
 def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
-    """NHWC cross-correlation. x [N,H,W,Ci], w [KH,KW,Ci,Co] -> [N,OH,OW,Co] (+bias[Co] +bias2[N,Co] +beta*res)."""
+    """NHWC cross-correlation. x [N,H,W,Ci], w [KH,KW,Ci,Co] -> alpha*(conv + bias[Co] + bias2[N,Co]) + beta*res."""
     N, H, W, Ci = x.shape
     KH, KW, Ci2, Co = w.shape
     if Ci != Ci2:
@@ -263,6 +269,40 @@ def colreduce(x, y=None, mode=0, alpha=1.0):
     return out
 
 
+def bn_stats(x, eps):
+    """Per-channel batch statistics over all leading dims of NHWC x: mean, biased var, rstd."""
+    C = x.shape[-1]
+    R = x.numel() // C
+    mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    rstd = torch.empty_like(mean)
+    ws = _ws(lib().indm_colreduce_ws_floats(R, C) + 2 * C, x.device)
+    _chk(lib().indm_bn_stats_f32(_ptr(x), _ptr(mean), _ptr(var), _ptr(rstd), R, C, eps, _ptr(ws), _stream()),
+         "indm_bn_stats_f32")
+    return mean, var, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, act=0):
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    _chk(lib().indm_bn_apply_f32(_ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(y), x.numel() // C, C,
+                                 act, _stream()), "indm_bn_apply_f32")
+    return y
+
+
+def bn_bwd(dy, x, mean, rstd, gamma, beta, act=0):
+    """Backward of act(BN(x)) with batch statistics -> dx, dgamma, dbeta."""
+    C = x.shape[-1]
+    R = x.numel() // C
+    dx = torch.empty_like(x)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(gamma)
+    ws = _ws(lib().indm_colreduce_ws_floats(R, C) + R * C + 2 * C, x.device)
+    _chk(lib().indm_bn_bwd_f32(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(dx),
+                               _ptr(dgamma), _ptr(dbeta), R, C, act, _ptr(ws), _stream()), "indm_bn_bwd_f32")
+    return dx, dgamma, dbeta
+
+
 # --------------------------------------------------------------------------- elementwise
 def sincos_fwd(p, want_d=True):
     a = torch.empty_like(p)
@@ -293,9 +333,10 @@ def act_bwd(dy, x, act):
     return dx
 
 
-def axpby(x, y, a, b):
+def axpby(x, y, a, b, c=0.0):
+    """a*x + b*y + c (y may be None)."""
     out = torch.empty_like(x)
-    _chk(lib().indm_axpby_f32(_ptr(x), _ptr(y), _ptr(out), a, b, x.numel(), _stream()), "indm_axpby_f32")
+    _chk(lib().indm_axpby_f32(_ptr(x), _ptr(y), _ptr(out), a, b, c, x.numel(), _stream()), "indm_axpby_f32")
     return out
 
 
@@ -444,6 +485,27 @@ def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, wd, step, clip, gnorm_sq, 
     _chk(lib().indm_adamw_ema_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), lr, beta1, beta2, eps, wd,
                                   step, clip, _ptr(gnorm_sq), gscale, ema_one_minus_decay, _stream()),
          "indm_adamw_ema_f32")
+
+
+def fixed_point_check(x, xp, y, atol, rtol):
+    """[1] tensor: count of elements with (x-xp)^2/(atol+|y|rtol) >= 1 (0 => converged)."""
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_fixed_point_check_f32(_ptr(x), _ptr(xp), _ptr(y), x.numel(), atol, rtol, _ptr(out), _stream()),
+         "indm_fixed_point_check_f32")
+    return out
+
+
+def ema_update(s, p, one_minus_decay):
+    _chk(lib().indm_ema_update_f32(_ptr(s), _ptr(p), s.numel(), one_minus_decay, _stream()), "indm_ema_update_f32")
+
+
+def slogdet_inv(w):
+    """log|det w| (shape [1]) and w^-1 for a square matrix with n <= 64."""
+    n = w.shape[0]
+    ld = torch.empty((1,), dtype=torch.float32, device=w.device)
+    inv = torch.empty_like(w)
+    _chk(lib().indm_slogdet_inv_f32(_ptr(w), n, _ptr(ld), _ptr(inv), _stream()), "indm_slogdet_inv_f32")
+    return ld, inv
 
 
 # --------------------------------------------------------------------------- reference native ops

@@ -1,0 +1,222 @@
+"""Loss / step-function factories with the reference's API (losses.py:30-420, models/utils.py:96-197).
+
+    get_optimizer, optimization_manager, get_sde_loss_fn, get_step_fn, get_score_fn, get_model_fn
+keep the reference signatures (plus an optional `rng=` noise source for parity tests).  The work inside a
+step is HIP kernels end to end: flow forward + explicit-VJP log-det, fused SDE perturbation, NCSN++ on MFMA
+implicit GEMMs, fused DSM loss, ordinary first-order autograd backward through the same kernels, then one
+flat-buffer all-reduce (if distributed) and one fused clip+AdamW+EMA pass per network.
+"""
+import numpy as np
+import torch
+
+from . import ops, sde_lib
+from .flow import flow_forward
+from .optim import FusedAdamW
+from .rng import DeviceRng
+from .sde_lib import VESDE, VPSDE
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def get_optimizer(config, flat, lr=None, beta1=None, eps=None, weight_decay=None):
+    """losses.py:30-45 (takes the FlatParams of a model instead of an iterator of parameters)."""
+    lr = config.optim.lr if lr is None else lr
+    beta1 = config.optim.beta1 if beta1 is None else beta1
+    eps = config.optim.eps if eps is None else eps
+    weight_decay = config.optim.weight_decay if weight_decay is None else weight_decay
+    if config.optim.optimizer == "AdamW":
+        return FusedAdamW(flat, lr=lr, beta1=beta1, beta2=0.99, eps=eps, weight_decay=weight_decay,
+                          amsgrad=config.optim.amsgrad)
+    raise NotImplementedError(f"Optimizer {config.optim.optimizer} not supported yet!")
+
+
+def optimization_manager(config):
+    """losses.py:48-62: warm-up, clip_grad_norm_, step -- clip and step are one fused kernel here."""
+
+    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup,
+                    grad_clip=config.optim.grad_clip, ema=None, grad_scale=1.0):
+        if warmup > 0:
+            for g in optimizer.param_groups:
+                g["lr"] = lr * np.minimum(step / warmup, 1.0)
+        optimizer.step(grad_clip=grad_clip, ema=ema, grad_scale=grad_scale)
+
+    return optimize_fn
+
+
+# ----------------------------------------------------------------------------- model / score wrappers
+def get_model_fn(model, train=False):
+    """models/utils.py:96-125"""
+
+    def model_fn(x, labels, **kw):
+        model.train() if train else model.eval()
+        return model(x, labels, **kw)
+
+    return model_fn
+
+
+def get_score_fn(config, sde, model, gamma_t=None, train=False, continuous=False, rng=None):
+    """models/utils.py:140-197 (continuous=True branches; every shipped config trains continuously)."""
+    model_fn = get_model_fn(model, train=train)
+    if not continuous:
+        raise NotImplementedError("discrete-time score functions are not used by the INDM configs")
+    if isinstance(sde, VPSDE):
+        def score_fn(x, t):
+            th = t.detach().cpu()
+            out = model_fn(x, (th * 999).to(x.device), rng=rng)
+            if config.training.ddpm_score:
+                std = sde.marginal_coeffs(th)[1]
+                out = ops.scale_rows(out, (-1.0 / std).to(x.device))
+            return out
+    elif isinstance(sde, VESDE):
+        def score_fn(x, t):
+            labels = sde.marginal_coeffs(t.detach().cpu())[1]
+            return model_fn(x, labels.to(x.device), rng=rng)
+    else:
+        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+    return score_fn
+
+
+def _host_schedule(sde, t):
+    """[B] fp32 host vectors the fused kernels need for a batch of times t."""
+    mc, std = sde.marginal_coeffs(t)
+    return mc, std, sde.model_labels(t)
+
+
+def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
+    """losses.py:65-144.  loss_fn(model, batch_nchw) -> per-image losses [B] (device)."""
+    reduce_mean = bool(config.training.reduce_mean)
+    kind = 0 if (isinstance(sde, VPSDE) and config.training.ddpm_score) else 1
+
+    def loss_fn(model, batch, st=False, recon_loss=None, importance_sampling=None, rng=None):
+        if recon_loss is None:
+            recon_loss = config.training.reconstruction_loss
+        if recon_loss:
+            raise NotImplementedError("reconstruction_loss is off in every shipped config")
+        if importance_sampling is None:
+            importance_sampling = config.training.importance_sampling
+        rng = rng or DeviceRng(batch.device)
+        dev = batch.device
+        B, C, H, W = batch.shape
+        t_min = sde.get_t_min(config, st)
+        t, Z = sde.get_diffusion_time(config, B, "cpu", t_min, importance_sampling=importance_sampling, rng=rng)
+        mc, std, labels = _host_schedule(sde, t)
+        z = rng.randn_image(B, C, H, W)                                    # losses.py:103 (NHWC here)
+        net = _unwrap(model)
+        net.train() if train else net.eval()
+        xt = ops.sde_perturb(ops.to_nhwc(batch), z, mc.to(dev), std.to(dev))
+        out = net(xt, labels.to(dev), rng=rng, nhwc=True)
+        if importance_sampling or not config.training.likelihood_weighting:
+            w = (0.5 * Z) * torch.ones(B)
+            mode = 0
+        else:
+            g2 = sde.diffusion(t) ** 2
+            w = 0.5 * Z * g2
+            mode = 1
+        return ops.dsm_loss(out, z, std.to(dev), w.float().to(dev), kind, mode, reduce_mean)
+
+    return loss_fn
+
+
+# ----------------------------------------------------------------------------- step functions
+def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1, allreduce=None):
+    """losses.py:194-420.  Returns step_fn(state, flow_state, batch[, rng]) -> 4 per-image loss vectors on
+    the CPU, exactly like the reference.  `state` / `flow_state` are dicts(optimizer, model, ema, step)."""
+    if not config.training.continuous:
+        raise NotImplementedError("discrete SMLD/DDPM losses are not used by the INDM configs")
+    loss_fn = get_sde_loss_fn(config, sde, train)
+    if optimize_fn is None:
+        optimize_fn = optimization_manager(config)
+
+    def calculate_logp(batch, rng):  # losses.py:219-225
+        B, C, H, W = batch.shape
+        Ts = torch.ones(B) * sde.T
+        mc, std = sde.marginal_coeffs(Ts)
+        z = rng.randn_image(B, C, H, W)
+        yT = ops.sde_perturb(ops.to_nhwc(batch), z, mc.to(batch.device), std.to(batch.device))
+        return sde_lib.prior_logp(sde, yT)
+
+    def _zero(state):
+        state["optimizer"].zero_grad()
+
+    def _reduce_and_step(states):
+        if allreduce is not None and world_size > 1:
+            allreduce()
+        for s in states:
+            optimize_fn(s["optimizer"], None, step=s["step"],
+                        lr=s["optimizer"].param_groups[0].get("base_lr", s["optimizer"].param_groups[0]["lr"]),
+                        ema=s["ema"], grad_scale=1.0 / world_size)
+
+    def _nll_losses(state, flow_state, mini_batch, rng, importance_sampling=None):
+        flow_model = flow_state["model"]
+        _unwrap(flow_model).train()
+        z, losses_flow = flow_forward(config, flow_model, mini_batch, reverse=False, rng=rng)
+        losses_score = loss_fn(state["model"], z, st=config.training.st, importance_sampling=importance_sampling,
+                               rng=rng)
+        losses_logp = calculate_logp(z, rng)
+        D = float(np.prod(mini_batch.shape[1:]))
+        if config.training.reduce_mean:
+            losses_flow, losses_logp = -losses_flow / D, -losses_logp / D
+        else:
+            losses_flow, losses_logp = -losses_flow, -losses_logp
+        assert losses_score.shape == losses_flow.shape == losses_logp.shape == torch.Size([z.shape[0]])
+        return losses_score, losses_flow, losses_logp
+
+    def flow_step_fn_nll(state, flow_state, batch, rng=None):
+        """losses.py:258-320"""
+        rng = rng or DeviceRng(batch.device, seed=state["step"] + 1)
+        B = batch.shape[0]
+        nmb = config.optim.num_micro_batch
+        outs = [[], [], [], []]
+        _zero(state)
+        _zero(flow_state)
+        if train:
+            for k in range(nmb):
+                mb = batch[B // nmb * k: B // nmb * (k + 1)]
+                ls, lf, lp = _nll_losses(state, flow_state, mb, rng)
+                losses = ls + lf + lp
+                torch.mean(losses).backward()
+                for o, v in zip(outs, (losses, ls, lf, lp)):
+                    o.append(v.detach())
+            _reduce_and_step([state, flow_state])
+        state["step"] += 1
+        flow_state["step"] += 1
+        return tuple(torch.cat(o).cpu() if o else torch.zeros(B) for o in outs)
+
+    def flow_step_fn_fid(state, flow_state, batch, rng=None):
+        """losses.py:322-406 (training.st=False)"""
+        if config.training.st:
+            raise NotImplementedError("training.st=True is not used by any shipped config")
+        rng = rng or DeviceRng(batch.device, seed=state["step"] + 1)
+        B = batch.shape[0]
+        nmb = config.optim.num_micro_batch
+        outs = [[], [], [], []]
+        _zero(state)
+        _zero(flow_state)
+        if train:
+            for k in range(nmb):
+                mb = batch[B // nmb * k: B // nmb * (k + 1)]
+                ls, lf, lp = _nll_losses(state, flow_state, mb, rng, importance_sampling=True)
+                losses = ls + lf + lp
+                torch.mean(losses).backward()
+                outs[0].append(losses.detach()); outs[2].append(lf.detach()); outs[3].append(lp.detach())
+            _reduce_and_step([flow_state])
+            _zero(state)
+            for k in range(nmb):
+                mb = batch[B // nmb * k: B // nmb * (k + 1)]
+                with torch.no_grad():
+                    z, _ = flow_forward(config, flow_state["model"], mb, log_det=None, reverse=False, rng=rng)
+                la = loss_fn(state["model"], z.detach(), st=config.training.st, recon_loss=False, rng=rng)
+                torch.mean(la).backward()
+                outs[1].append(la.detach())
+            _reduce_and_step([state])
+            state["step"] += 1
+            flow_state["step"] += 1
+        return tuple(torch.cat(o).cpu() if o else torch.zeros(B) for o in outs)
+
+    if config.flow.model == "identity":
+        raise NotImplementedError("flow.model='identity' (score-only training) is outside the INDM hot path")
+    if not config.training.likelihood_weighting:
+        return flow_step_fn_fid
+    return flow_step_fn_nll

@@ -1,0 +1,548 @@
+"""Differentiable operators built on the HIP kernels (indm_amd.hip).
+
+Every op is a torch.autograd.Function whose forward AND backward call the C ABI -- autograd is
+used only for bookkeeping.  Activations are NHWC ([N,H,W,C] contiguous); convolution weights are
+RSCK ([KH,KW,Cin,Cout]).  Transposed convolutions / transposed GEMMs are first-class forward ops
+(they are what the explicit vector-Jacobian chains of the residual flow are made of), so nothing
+here needs double backward: see flow.py and DESIGN.md "log-det engine".
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import hip
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- dense contractions
+class _Gemm(Function):
+    """C = alpha*(op(A) op(B) + bias + bias2[row // rpg]) + beta*res"""
+
+    @staticmethod
+    def forward(ctx, a, b, bias, bias2, res, trans_a, trans_b, alpha, beta, rpg, wgrad_b_splitk):
+        a, b, res = _c(a), _c(b), _c(res)
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (trans_a, trans_b, alpha, beta, rpg, wgrad_b_splitk, bias is not None, bias2 is not None,
+                   res is not None)
+        return hip.gemm(a, b, trans_a, trans_b, alpha, _c(bias), _c(bias2), rpg, res, beta)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        ta, tb, alpha, beta, rpg, sk, has_bias, has_bias2, has_res = ctx.cfg
+        dc = _c(dc)
+        da = db = dbias = dbias2 = dres = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                da = hip.gemm(dc, b, False, not tb, alpha)            # dC op(B)^T
+            else:
+                da = hip.gemm(b, dc, tb, True, alpha)                 # op(B) dC^T  (stored [K,M])
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                db = hip.gemm(a, dc, not ta, False, alpha, splitk=sk)  # op(A)^T dC
+            else:
+                db = hip.gemm(dc, a, True, ta, alpha, splitk=sk)       # dC^T op(A)  (stored [N,K])
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = hip.colreduce(dc, None, 0, alpha)
+        if has_bias2 and ctx.needs_input_grad[3]:
+            n = dc.shape[-1]
+            g = dc.reshape(-1, rpg, n)
+            ones = torch.ones((1, rpg), dtype=torch.float32, device=dc.device)
+            dbias2 = hip.gemm(ones, g, False, False, alpha).reshape(-1, n)
+        if has_res and ctx.needs_input_grad[4]:
+            dres = hip.axpby(dc, None, beta, 0.0)
+        return da, db, dbias, dbias2, dres, None, None, None, None, None, None
+
+
+def gemm(a, b, bias=None, bias2=None, res=None, trans_a=False, trans_b=False, alpha=1.0, beta=1.0, rows_per_group=1,
+         weight_b=False):
+    """weight_b=True marks b as a weight: its gradient reduces over all rows of a (split-K)."""
+    return _Gemm.apply(a, b, bias, bias2, res, trans_a, trans_b, alpha, beta, rows_per_group, weight_b)
+
+
+def linear(x, w, bias=None):
+    """torch-layout Linear: w is [out, in]; x is [..., in]."""
+    shp = x.shape
+    y = gemm(x.reshape(-1, shp[-1]), w, bias, trans_b=True, weight_b=True)
+    return y.reshape(*shp[:-1], w.shape[0])
+
+
+def conv1x1(x, w, bias=None, bias2=None, res=None, alpha=1.0, beta=1.0):
+    """1x1 convolution / NIN on NHWC as a plain GEMM; w is [Cin, Cout]; bias2 is [N, Cout]."""
+    N, H, W, C = x.shape
+    r = res.reshape(-1, w.shape[1]) if res is not None else None
+    y = gemm(x.reshape(-1, C), w, bias, bias2, r, alpha=alpha, beta=beta, rows_per_group=H * W, weight_b=True)
+    return y.reshape(N, H, W, w.shape[1])
+
+
+def conv1x1_t(v, w):
+    """Transpose of conv1x1 w.r.t. its input: v [N,H,W,Cout] -> [N,H,W,Cin]  (v @ w^T)."""
+    N, H, W, C = v.shape
+    y = gemm(v.reshape(-1, C), w, trans_b=True, weight_b=True)
+    return y.reshape(N, H, W, w.shape[0])
+
+
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, bias2, res, stride, pad, alpha, beta):
+        x, w, res = _c(x), _c(w), _c(res)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, alpha, beta, bias is not None, bias2 is not None, res is not None)
+        return hip.conv2d(x, w, stride, pad, alpha, _c(bias), _c(bias2), res, beta)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, alpha, beta, has_bias, has_bias2, has_res = ctx.cfg
+        dy = _c(dy)
+        dx = dw = dbias = dbias2 = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), stride, pad, alpha)
+        if ctx.needs_input_grad[1]:
+            dw = hip.conv2d_wgrad(x, dy, w.shape[0], w.shape[1], stride, pad, alpha)
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = hip.colreduce(dy, None, 0, alpha)
+        if has_bias2 and ctx.needs_input_grad[3]:
+            N, OH, OW, Co = dy.shape
+            ones = torch.ones((1, OH * OW), dtype=torch.float32, device=dy.device)
+            dbias2 = hip.gemm(ones, dy.reshape(N, OH * OW, Co), False, False, alpha).reshape(N, Co)
+        if has_res and ctx.needs_input_grad[4]:
+            dres = hip.axpby(dy, None, beta, 0.0)
+        return dx, dw, dbias, dbias2, dres, None, None, None, None
+
+
+def conv2d(x, w, bias=None, bias2=None, res=None, stride=1, pad=1, alpha=1.0, beta=1.0):
+    """y = alpha*(conv(x, w) + bias + bias2[n]) + beta*res ; x NHWC, w RSCK."""
+    return _Conv2d.apply(x, w, bias, bias2, res, stride, pad, alpha, beta)
+
+
+class _Conv2dT(Function):
+    """t = d<conv(x,w), v>/dx : the transposed convolution as a forward op."""
+
+    @staticmethod
+    def forward(ctx, v, w, in_hw, stride, pad):
+        v, w = _c(v), _c(w)
+        ctx.save_for_backward(v, w)
+        ctx.cfg = (in_hw, stride, pad)
+        return hip.conv2d_dgrad(v, w, in_hw, stride, pad)
+
+    @staticmethod
+    def backward(ctx, dt):
+        v, w = ctx.saved_tensors
+        in_hw, stride, pad = ctx.cfg
+        dt = _c(dt)
+        dv = dw = None
+        if ctx.needs_input_grad[0]:
+            dv = hip.conv2d(dt, w, stride, pad)
+        if ctx.needs_input_grad[1]:
+            dw = hip.conv2d_wgrad(dt, v, w.shape[0], w.shape[1], stride, pad)
+        return dv, dw, None, None, None
+
+
+def conv2d_t(v, w, in_hw, stride=1, pad=1):
+    return _Conv2dT.apply(v, w, in_hw, stride, pad)
+
+
+# ----------------------------------------------------------------------------- normalisation / softmax
+class _GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, act, drop_p, seed):
+        x = _c(x)
+        y, mean, rstd = hip.groupnorm_fwd(x, gamma, beta, G, eps, act, drop_p, seed)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (G, act, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, act, drop_p, seed = ctx.cfg
+        dx, dg, db = hip.groupnorm_bwd(_c(dy), x, gamma, beta, mean, rstd, G, act, drop_p, seed)
+        return dx, dg, db, None, None, None, None, None
+
+
+def group_norm(x, gamma, beta, eps=1e-6, silu=False, drop_p=0.0, seed=0):
+    """nn.GroupNorm(min(C/4,32), C, eps) [+ SiLU] [+ dropout], fused (models/layerspp.py:232-279)."""
+    C = x.shape[-1]
+    return _GroupNorm.apply(x, gamma, beta, min(C // 4, 32), eps, 1 if silu else 0, float(drop_p), int(seed))
+
+
+class _BatchNormAct(Function):
+    """Training-mode BatchNorm2d (+ELU).  Returns y; batch mean / biased var are stashed on ctx.stats."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act, stats_out):
+        x = _c(x)
+        mean, var, rstd = hip.bn_stats(x, eps)
+        stats_out.append((mean, var))
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.act = act
+        return hip.bn_apply(x, mean, rstd, gamma, beta, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, dg, db = hip.bn_bwd(_c(dy), x, mean, rstd, gamma, beta, ctx.act)
+        return dx, dg, db, None, None, None
+
+
+class _BatchNormEval(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, rstd, act):
+        x = _c(x)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.act = act
+        return hip.bn_apply(x, mean, rstd, gamma, beta, act)
+
+    @staticmethod
+    def backward(ctx, dy):  # statistics are constants
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        dyu = _c(dy)
+        if ctx.act == 2:
+            u = hip.bn_apply(x, mean, rstd, gamma, beta, 0)
+            dyu = hip.act_bwd(dyu, u, hip.ACT_ELU)
+        xh = hip.bn_apply(x, mean, rstd, torch.ones_like(gamma), torch.zeros_like(beta), 0)
+        dg = hip.colreduce(dyu, xh, 1)
+        db = hip.colreduce(dyu, None, 0)
+        dx = hip.bn_apply(dyu, torch.zeros_like(mean), torch.ones_like(rstd), gamma * rstd, torch.zeros_like(beta), 0)
+        return dx, dg, db, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, eps=1e-5, elu=False, stats_out=None):
+    act = 2 if elu else 0
+    if training:
+        return _BatchNormAct.apply(x, gamma, beta, eps, act, stats_out if stats_out is not None else [])
+    rstd = torch.rsqrt(running_var + eps)
+    return _BatchNormEval.apply(x, gamma, beta, running_mean, rstd, act)
+
+
+class _Softmax(Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        y = hip.softmax_fwd(_c(x), scale)
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return hip.softmax_bwd(_c(dy), y, ctx.scale), None
+
+
+def softmax(x, scale=1.0):
+    """softmax(scale * x) over the last dim."""
+    return _Softmax.apply(x, scale)
+
+
+# ----------------------------------------------------------------------------- elementwise
+class _SinCos(Function):
+    """(a, d) = (sin(2 pi p)/(2 pi), cos(2 pi p)) -- the Sin activation and its derivative in one pass."""
+
+    @staticmethod
+    def forward(ctx, p):
+        a, d = hip.sincos_fwd(_c(p), True)
+        ctx.save_for_backward(a, d)
+        return a, d
+
+    @staticmethod
+    def backward(ctx, da, dd):
+        a, d = ctx.saved_tensors
+        return hip.sincos_bwd(_c(da), _c(dd), a, d)
+
+
+def sincos(p):
+    return _SinCos.apply(p)
+
+
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return hip.act_fwd(x, kind)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return hip.act_bwd(_c(dy), x, ctx.kind), None
+
+
+def silu(x):
+    return _Act.apply(x, hip.ACT_SILU)
+
+
+def elu(x):
+    return _Act.apply(x, hip.ACT_ELU)
+
+
+class _Axpby(Function):
+    @staticmethod
+    def forward(ctx, x, y, a, b, c):
+        ctx.ab = (a, b)
+        return hip.axpby(_c(x), _c(y), a, b, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.ab
+        g = _c(g)
+        gx = hip.axpby(g, None, a, 0.0) if ctx.needs_input_grad[0] else None
+        gy = hip.axpby(g, None, b, 0.0) if ctx.needs_input_grad[1] else None
+        return gx, gy, None, None, None
+
+
+def axpby(x, y, a=1.0, b=1.0, c=0.0):
+    """a*x + b*y + c"""
+    return _Axpby.apply(x, y, a, b, c)
+
+
+class _Mul(Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _c(x), _c(y)
+        ctx.save_for_backward(x, y)
+        return hip.mul(x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = _c(g)
+        return (hip.mul(g, y) if ctx.needs_input_grad[0] else None,
+                hip.mul(g, x) if ctx.needs_input_grad[1] else None)
+
+
+def mul(x, y):
+    return _Mul.apply(x, y)
+
+
+class _RowDot(Function):
+    """out[b] = <x[b], y[b]>"""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _c(x), _c(y)
+        ctx.save_for_backward(x, y)
+        return hip.rowreduce(x, y, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = _c(g)
+        return (hip.scale_rows(y, g) if ctx.needs_input_grad[0] else None,
+                hip.scale_rows(x, g) if ctx.needs_input_grad[1] else None)
+
+
+def rowdot(x, y):
+    return _RowDot.apply(x, y)
+
+
+class _RowSumSq(Function):
+    """out[b] = alpha * sum x[b]^2"""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        ctx.alpha = alpha
+        return hip.rowreduce(x, None, 1, alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return hip.scale_rows(x, _c(g) * (2.0 * ctx.alpha)), None
+
+
+def rowsumsq(x, alpha=1.0):
+    return _RowSumSq.apply(x, alpha)
+
+
+class _ScaleRows(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _c(x), _c(s)
+        ctx.save_for_backward(x, s)
+        return hip.scale_rows(x, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        g = _c(g)
+        gx = hip.scale_rows(g, s) if ctx.needs_input_grad[0] else None
+        gs = hip.rowreduce(g, x, 0) if ctx.needs_input_grad[1] else None
+        return gx, gs
+
+
+def scale_rows(x, s):
+    """x[b,...] * s[b]"""
+    return _ScaleRows.apply(x, s)
+
+
+# ----------------------------------------------------------------------------- resampling / layout
+class _Resample(Function):
+    """kind: 'up' (nearest x2), 'down' (2x2 mean), 'squeeze', 'unsqueeze', 'to_nhwc', 'to_nchw'."""
+    INV = {"squeeze": "unsqueeze", "unsqueeze": "squeeze", "to_nhwc": "to_nchw", "to_nchw": "to_nhwc"}
+
+    @staticmethod
+    def run(kind, x, alpha=None):
+        if kind == "up":
+            return hip.upsample2x(x, 1.0 if alpha is None else alpha)
+        if kind == "down":
+            return hip.downsample2x(x, 0.25 if alpha is None else alpha)
+        return {"squeeze": hip.squeeze2x, "unsqueeze": hip.unsqueeze2x, "to_nhwc": hip.nchw_to_nhwc,
+                "to_nchw": hip.nhwc_to_nchw}[kind](x)
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        ctx.kind = kind
+        return _Resample.run(kind, _c(x))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        k = ctx.kind
+        if k == "up":      # adjoint of replication = 2x2 sum
+            return _Resample.run("down", g, 1.0), None
+        if k == "down":    # adjoint of 2x2 mean = replicate / 4
+            return _Resample.run("up", g, 0.25), None
+        return _Resample.run(_Resample.INV[k], g), None
+
+
+def upsample2x(x):
+    return _Resample.apply(x, "up")
+
+
+def downsample2x(x):
+    return _Resample.apply(x, "down")
+
+
+def squeeze2x(x):
+    return _Resample.apply(x, "squeeze")
+
+
+def unsqueeze2x(x):
+    return _Resample.apply(x, "unsqueeze")
+
+
+def to_nhwc(x):
+    return _Resample.apply(x, "to_nhwc")
+
+
+def to_nchw(x):
+    return _Resample.apply(x, "to_nchw")
+
+
+class _UpFirDn2d(Function):
+    """NHWC up-FIR-down with the gradient relations of the reference op (op/upfirdn2d.py:19-142):
+    grad = the same op with up<->down, flipped kernel and g_pad."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, up, down, pad):
+        x = _c(x)
+        px0, px1, py0, py1 = pad
+        N, H, W, C = x.shape
+        kh, kw = kernel.shape
+        y = hip.upfirdn2d(x, kernel, up[0], up[1], down[0], down[1], px0, px1, py0, py1, 1)
+        oh, ow = y.shape[1], y.shape[2]
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, (H, W), (kw - px0 - 1, W * up[0] - ow * down[0] + px0 - up[0] + 1,
+                                     kh - py0 - 1, H * up[1] - oh * down[1] + py0 - up[1] + 1))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (kernel,) = ctx.saved_tensors
+        up, down, _, gp = ctx.cfg
+        gk = torch.flip(kernel, [0, 1]).contiguous()
+        gx = hip.upfirdn2d(_c(gy), gk, down[0], down[1], up[0], up[1], gp[0], gp[1], gp[2], gp[3], 1)
+        return gx, None, None, None, None
+
+
+def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
+    """Reference call convention (op/upfirdn2d.py:145-156) on NHWC tensors."""
+    return _UpFirDn2d.apply(x, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+# ----------------------------------------------------------------------------- flow / SDE specials
+class _LopNormalize(Function):
+    @staticmethod
+    def forward(ctx, w, coeff):
+        w = _c(w)
+        wn, l1 = hip.lop_normalize_fwd(w, coeff)
+        ctx.save_for_backward(w, l1)
+        ctx.coeff = coeff
+        ctx.mark_non_differentiable(l1)
+        return wn, l1
+
+    @staticmethod
+    def backward(ctx, dwn, _):
+        w, l1 = ctx.saved_tensors
+        return hip.lop_normalize_bwd(_c(dwn), w, l1, ctx.coeff), None
+
+
+def lop_normalize(w, coeff=0.98):
+    """w / max(1, ||w[..., co]||_1 / coeff)  (layers/base/lipschitz.py:350-359 on RSCK weights) -> (wn, l1)."""
+    return _LopNormalize.apply(w, coeff)
+
+
+class _SdePerturb(Function):
+    @staticmethod
+    def forward(ctx, x, noise, mc, sd):
+        ctx.save_for_backward(mc)
+        return hip.sde_perturb(_c(x), _c(noise), mc, sd)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mc,) = ctx.saved_tensors
+        return hip.scale_rows(_c(g), mc), None, None, None
+
+
+def sde_perturb(x, noise, mean_coef, std):
+    """mean_coef[b]*x + std[b]*noise (sde_lib.py:153-157 + losses.py:105); differentiable in x only."""
+    return _SdePerturb.apply(x, noise, mean_coef, std)
+
+
+class _DsmLoss(Function):
+    @staticmethod
+    def forward(ctx, out, z, std, w, kind, mode, reduce_mean):
+        out, z = _c(out), _c(z)
+        ctx.save_for_backward(out, z, std, w)
+        ctx.cfg = (kind, mode, reduce_mean)
+        return hip.dsm_loss_fwd(out, z, std, w, kind, mode, reduce_mean)
+
+    @staticmethod
+    def backward(ctx, gl):
+        out, z, std, w = ctx.saved_tensors
+        kind, mode, rm = ctx.cfg
+        return hip.dsm_loss_bwd(_c(gl), out, z, std, w, kind, mode, rm), None, None, None, None, None, None
+
+
+def dsm_loss(out, z, std, w, kind, mode, reduce_mean):
+    """Per-image denoising score matching loss from the raw network output (losses.py:106-118)."""
+    return _DsmLoss.apply(out, z, std, w, kind, mode, reduce_mean)
+
+
+class _SlogdetInv(Function):
+    @staticmethod
+    def forward(ctx, w):
+        ld, inv = hip.slogdet_inv(_c(w))
+        ctx.save_for_backward(inv)
+        return ld
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return inv.t().contiguous() * g
+
+
+def slogdet(w):
+    """log|det w| as a [1] tensor, differentiable (d/dw = w^-T)."""
+    return _SlogdetInv.apply(w)
+
+
+INV_SQRT2 = 1.0 / math.sqrt(2.0)

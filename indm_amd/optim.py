@@ -1,0 +1,180 @@
+"""Flat-buffer parameters, fused clip+AdamW+EMA, and the EMA object of the reference API.
+
+Reference: losses.py:30-62 (get_optimizer / optimization_manager), models/ema.py:10-97.
+MI355X design: all trainable parameters of BOTH networks are views into one flat fp32 buffer and
+all their gradients are views into one flat gradient buffer, so
+  * the data-parallel exchange is ONE RCCL all-reduce over xGMI per step (parallel.py),
+  * zero_grad is one memset,
+  * clip_grad_norm_ + AdamW + EMA is one read-modify-write pass per network
+    (indm_adamw_ema_f32; the global norm comes from indm_sqnorm_f32 and stays on the device).
+Parameters that never receive a gradient in the reference (iResBlock.lamb / geom_p, which are only
+read through .item(); GaussianFourierProjection.W has requires_grad=False) are kept out of the flat
+buffers: torch's AdamW skips them because their .grad is None.
+"""
+import torch
+
+from . import hip
+
+_NO_GRAD_SUFFIXES = (".lamb", ".geom_p")
+
+
+def _receives_grad(name, p):
+    return p.requires_grad and not name.endswith(_NO_GRAD_SUFFIXES)
+
+
+class FlatParams:
+    """Re-homes a module's trainable parameters (and grads) into slices of flat buffers."""
+
+    def __init__(self, module, flat_p=None, flat_g=None, offset=0):
+        self.module = module
+        self.named = [(n, p) for n, p in module.named_parameters() if _receives_grad(n, p)]
+        self.other = [(n, p) for n, p in module.named_parameters() if p.requires_grad and not _receives_grad(n, p)]
+        self.numel = sum(_pad4(p.numel()) for _, p in self.named)
+        dev = self.named[0][1].device
+        own = flat_p is None
+        if own:
+            flat_p = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+            flat_g = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.p = flat_p[offset:offset + self.numel]
+        self.g = flat_g[offset:offset + self.numel]
+        o = 0
+        for _, p in self.named:
+            n = p.numel()
+            self.p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + n].view(p.shape)
+            p.grad = self.g[o:o + n].view(p.shape)
+            o += _pad4(n)
+
+    def zero_grad(self):
+        self.g.zero_()
+        o = 0
+        for _, p in self.named:  # keep .grad pointing into the flat buffer
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.g[o:o + n].data_ptr():
+                p.grad = self.g[o:o + n].view(p.shape)
+            o += _pad4(n)
+
+    def parameters(self):
+        return [p for _, p in self.named]
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def flatten_models(modules):
+    """One joint flat parameter buffer and one joint gradient buffer for several modules."""
+    sizes = []
+    for m in modules:
+        sizes.append(sum(_pad4(p.numel()) for n, p in m.named_parameters() if _receives_grad(n, p)))
+    dev = next(modules[0].parameters()).device
+    flat_p = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    flat_g = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    out, off = [], 0
+    for m, s in zip(modules, sizes):
+        out.append(FlatParams(m, flat_p, flat_g, off))
+        off += s
+    return out, flat_p, flat_g
+
+
+class FusedAdamW:
+    """torch.optim.AdamW(lr, betas=(beta1, 0.99), eps, weight_decay) semantics (losses.py:40) on a FlatParams."""
+
+    def __init__(self, flat, lr, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=0.01, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad=True is not used by any reference config")
+        self.flat = flat
+        self.param_groups = [dict(lr=lr, betas=(beta1, beta2), eps=eps, weight_decay=weight_decay)]
+        self.m = torch.zeros_like(flat.p)
+        self.v = torch.zeros_like(flat.p)
+        self.t = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self, grad_clip=-1.0, ema=None, grad_scale=1.0):
+        """clip_grad_norm_(grad_clip) -> AdamW -> (optional) EMA update, one fused pass.
+        grad_scale multiplies the raw gradient first (1/world_size after a SUM all-reduce)."""
+        g = self.param_groups[0]
+        self.t += 1
+        gn = hip.sqnorm(self.flat.g) if grad_clip >= 0 else None
+        omd = 0.0
+        shadow = None
+        if ema is not None:
+            omd = ema.advance()
+            shadow = ema.shadow
+        hip.adamw_ema(self.flat.p, self.flat.g, self.m, self.v, shadow, g["lr"], g["betas"][0], g["betas"][1],
+                      g["eps"], g["weight_decay"], self.t, float(grad_clip), gn, float(grad_scale), float(omd))
+        self.last_grad_sqnorm = gn
+
+    def state_dict(self):
+        return dict(step=self.t, exp_avg=self.m, exp_avg_sq=self.v, param_groups=self.param_groups)
+
+    def load_state_dict(self, sd):
+        self.t = sd["step"]
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.param_groups = sd["param_groups"]
+
+
+class ExponentialMovingAverage:
+    """models/ema.py:10-97 on the flat buffer.  `shadow_params` (state_dict) keeps the reference's list order
+    (= module.parameters() order of requires_grad params, including lamb / geom_p)."""
+
+    def __init__(self, flat, decay, use_num_updates=True):
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.flat = flat
+        self.decay = decay
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow = flat.p.clone()
+        self.other_shadow = [p.detach().clone() for _, p in flat.other]
+        self.collected = None
+
+    def advance(self):
+        """Increment num_updates and return (1 - decay) with the reference's warm-up (ema.py:43-48)."""
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        return 1.0 - decay
+
+    def update(self, parameters=None):
+        omd = self.advance()
+        hip.ema_update(self.shadow, self.flat.p, omd)
+        # lamb / geom_p never change; their shadow stays equal
+
+    def copy_to(self, parameters=None):
+        self.flat.p.copy_(self.shadow)
+        for (_, p), s in zip(self.flat.other, self.other_shadow):
+            p.data.copy_(s)
+
+    def store(self, parameters=None):
+        self.collected = (self.flat.p.clone(), [p.detach().clone() for _, p in self.flat.other])
+
+    def restore(self, parameters=None):
+        self.flat.p.copy_(self.collected[0])
+        for (_, p), s in zip(self.flat.other, self.collected[1]):
+            p.data.copy_(s)
+
+    def _shadow_views(self):
+        views, o = {}, 0
+        for n, p in self.flat.named:
+            views[n] = self.shadow[o:o + p.numel()].view(p.shape)
+            o += _pad4(p.numel())
+        for (n, _), s in zip(self.flat.other, self.other_shadow):
+            views[n] = s
+        return views
+
+    def shadow_params(self):
+        v = self._shadow_views()
+        return [v[n] for n, p in self.flat.module.named_parameters() if p.requires_grad]
+
+    def state_dict(self):
+        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params())
+
+    def load_state_dict(self, sd):
+        self.decay = sd["decay"]
+        self.num_updates = sd["num_updates"]
+        for dst, src in zip(self.shadow_params(), sd["shadow_params"]):
+            dst.copy_(src)

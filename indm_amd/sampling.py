@@ -1,0 +1,207 @@
+"""Samplers with the reference's API (sampling.py:86-133, 186-210, 263-292, 365-456, 547-621).
+
+    get_sampling_fn(config, sde, shape, inverse_scaler, eps) -> sampler(model, flow_model, temperature=1.,
+        data_mean=None, final_time=0., before_data=None, sample_dir=None, r=None) -> (before, after, nfe)
+
+Every predictor / corrector update is ONE fused kernel  x' = a[b]*x + b[b]*net_out + c[b]*z  whose per-image
+coefficients come from the host-side SDE schedule (sde_lib.py); the Langevin step size (two batch-mean norms)
+is computed on the device without a host round trip.  The state stays NHWC in HBM for the whole loop.
+"""
+import numpy as np
+import torch
+
+from . import hip, ops
+from .flow import flow_forward
+from .rng import DeviceRng
+from .sde_lib import VESDE, VPSDE
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+class _Stepper:
+    """Shared machinery: raw network output + per-image coefficient vectors."""
+
+    def __init__(self, config, sde, model, rng):
+        self.cfg, self.sde, self.net, self.rng = config, sde, _unwrap(model), rng
+        self.net.eval()
+        self.vp = isinstance(sde, VPSDE)
+        self.ddpm = self.vp and config.training.ddpm_score
+
+    def net_out(self, x, t):
+        """raw model output and the factor k[b] with score = k * out"""
+        labels = self.sde.model_labels(t)
+        out = self.net(x, labels.to(x.device), nhwc=True)
+        if self.ddpm:
+            k = -1.0 / self.sde.marginal_coeffs(t)[1]
+        else:
+            k = torch.ones_like(t)
+        return out, k
+
+    def em(self, x, t):
+        """EulerMaruyamaPredictor.update_fn sampling.py:191-197 with RSDE.sde sde_lib.py:96-103"""
+        sde = self.sde
+        dt = -1.0 / sde.N
+        out, k = self.net_out(x, t)
+        g = sde.diffusion(t)
+        if self.vp:
+            a = 1.0 + (-0.5 * sde.beta_t(t)) * dt
+        else:
+            a = torch.ones_like(t)
+        b = -(g ** 2) * k * dt
+        c = g * np.sqrt(-dt)
+        z = self.rng.randn_image(*_nchw(x))
+        return hip.affine_update(x, out, z, _d(a, x), _d(b, x), _d(c, x))
+
+    def rd(self, x, t, next_t=None, probability_flow=False):
+        """ReverseDiffusionPredictor.update_fn sampling.py:205-210 with RSDE.discretize sde_lib.py:105-118"""
+        sde = self.sde
+        out, k = self.net_out(x, t)
+        pf = 0.5 if probability_flow else 1.0
+        if next_t is None or next_t[0].item() > 0:
+            a_f, G = sde.discretize_coeffs(t, next_t)      # f = (a_f - 1) x
+            a = 2.0 - a_f                                   # x - f
+        else:
+            a = torch.ones_like(t)
+            G = sde.diffusion(t) * torch.sqrt(t - next_t)
+        b = (G ** 2) * k * pf
+        c = torch.zeros_like(G) if probability_flow else G
+        z = self.rng.randn_image(*_nchw(x))
+        return hip.affine_update(x, out, z, _d(a, x), _d(b, x), _d(c, x))
+
+    def langevin(self, x, t, snr, n_steps):
+        """LangevinCorrector.update_fn sampling.py:272-292"""
+        sde = self.sde
+        if self.vp:
+            alpha = sde.alphas[(t * (sde.N - 1) / sde.T).long()]
+        else:
+            alpha = torch.ones_like(t)
+        alpha = _d(alpha, x)
+        x_mean = x
+        for _ in range(n_steps):
+            out, k = self.net_out(x, t)
+            grad = out if not self.ddpm else hip.scale_rows(out, _d(k, x))
+            noise = self.rng.randn_image(*_nchw(x))
+            gsq, nsq = hip.rowreduce(grad, None, 1), hip.rowreduce(noise, None, 1)
+            step, ncoef = hip.langevin_step(gsq, nsq, alpha, float(snr))
+            x, x_mean = hip.affine_update(x, grad, noise, torch.ones_like(step), step, ncoef)
+        return x, x_mean
+
+
+def _nchw(x):
+    n, h, w, c = x.shape
+    return n, c, h, w
+
+
+def _d(v, x):
+    return v.float().contiguous().to(x.device)
+
+
+def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1,
+                   probability_flow=False, continuous=False, denoise=True, eps=1e-3, device="cuda"):
+    """sampling.py:365-456.  predictor in {'euler_maruyama','reverse_diffusion','none'}, corrector in
+    {'langevin','none'} (the registries of sampling.py:36-83 reduced to what the configs select)."""
+
+    def pc_sampler(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
+                   sample_dir=None, r=None, rng=None, iters=None):
+        rng = rng or DeviceRng(device)
+        with torch.no_grad():
+            num_scales = config.sampling.num_scales if config.sampling.num_scales != sde.N else sde.N
+            B, C, H, W = shape
+            x = rng.randn_image(B, C, H, W)                       # sde.prior_sampling (sde_lib.py:159-163/289-293)
+            if isinstance(sde, VESDE):
+                x = hip.axpby(x, None, float(sde.sigma_max), 0.0, float(data_mean or 0.0))
+            elif data_mean:
+                x = hip.axpby(x, None, 1.0, 0.0, float(data_mean))
+            timesteps = torch.linspace(sde.T, eps, num_scales)
+            st = _Stepper(config, sde, model, rng)
+            x_mean = x
+            for i in range(num_scales):
+                vec_t = torch.ones(B) * timesteps[i]
+                if config.sampling.snr_scheduling == "none":
+                    snr_temp = config.sampling.snr
+                else:
+                    snr_temp = config.sampling.begin_snr + (config.sampling.end_snr - config.sampling.begin_snr) * i / num_scales
+                if corrector == "langevin":
+                    x, x_mean = st.langevin(x, vec_t, snr_temp, n_steps)
+                if predictor == "euler_maruyama":
+                    x, x_mean = st.em(x, vec_t)
+                elif predictor == "reverse_diffusion":
+                    x, x_mean = st.rd(x, vec_t, None, probability_flow)
+            before = x_mean if denoise else x
+            before = ops.to_nchw(before)
+            if config.flow.model != "identity":
+                after, _ = flow_forward(config, flow_model, hip.axpby(before, None, float(temperature), 0.0),
+                                        log_det=None, reverse=True, rng=rng, iters=iters)
+            else:
+                after = before
+            return inverse_scaler(before), inverse_scaler(after), sde.N * (n_steps + 1)
+
+    return pc_sampler
+
+
+def get_ode_sampler(config, sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method="RK45",
+                    eps=1e-3, device="cuda"):
+    """sampling.py:547-621: SciPy RK45 over the probability-flow ODE (float64 host state, device RHS)."""
+    from scipy import integrate
+
+    def ode_sampler(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
+                    sample_dir=None, r=None, rng=None, iters=None):
+        rng = rng or DeviceRng(device)
+        with torch.no_grad():
+            B, C, H, W = shape
+            st = _Stepper(config, sde, model, rng)
+            x = rng.randn_image(B, C, H, W)
+            if isinstance(sde, VESDE):
+                x = hip.axpby(x, None, float(sde.sigma_max), 0.0, float(data_mean or 0.0))
+
+            def drift(xd, t):
+                """RSDE(probability_flow).sde: f - 0.5 g^2 score  (sde_lib.py:96-103)"""
+                out, k = st.net_out(xd, t)
+                g = sde.diffusion(t)
+                a = -0.5 * sde.beta_t(t) if st.vp else torch.zeros_like(t)
+                b = -(g ** 2) * k * 0.5
+                return hip.affine_update(xd, out, None, _d(a, xd), _d(b, xd), _d(b, xd), want_mean=False)[0]
+
+            def ode_func(t, xf):
+                xd = torch.from_numpy(xf.reshape(B, C, H, W)).float().to(device)
+                d = drift(ops.to_nhwc(xd), torch.ones(B) * t)
+                return ops.to_nchw(d).cpu().numpy().reshape(-1).astype(np.float64)
+
+            sol = integrate.solve_ivp(ode_func, (sde.T, eps), ops.to_nchw(x).cpu().numpy().reshape(-1),
+                                      rtol=rtol, atol=atol, method=method)
+            x = ops.to_nhwc(torch.tensor(sol.y[:, -1]).reshape(shape).float().to(device))
+            if denoise:  # denoise_update_fn :568-574
+                vec_eps = torch.ones(B) * eps
+                _, x = st.rd(x, vec_eps, torch.zeros_like(vec_eps), probability_flow=False)
+            before = ops.to_nchw(x)
+            if config.flow.model != "identity":
+                after, _ = flow_forward(config, flow_model, hip.axpby(before, None, float(temperature), 0.0),
+                                        log_det=None, reverse=True, rng=rng, iters=iters)
+            else:
+                after = before
+            return inverse_scaler(before), inverse_scaler(after), sol.nfev
+
+    return ode_sampler
+
+
+def get_sampling_fn(config, sde, shape, inverse_scaler, eps, device=None):
+    """sampling.py:86-133"""
+    device = device or getattr(config, "device", "cuda")
+    name = config.sampling.method.lower()
+    if name == "ode":
+        return get_ode_sampler(config=config, sde=sde, shape=shape, inverse_scaler=inverse_scaler,
+                               denoise=config.sampling.noise_removal, eps=eps, rtol=config.eval.rtol,
+                               atol=config.eval.atol, device=device)
+    if name == "pc":
+        pred, corr = config.sampling.predictor.lower(), config.sampling.corrector.lower()
+        if pred not in ("euler_maruyama", "reverse_diffusion", "none") or corr not in ("langevin", "none"):
+            raise ValueError(f"predictor {pred} / corrector {corr} not supported")
+        return get_pc_sampler(config=config, sde=sde, shape=shape, predictor=pred, corrector=corr,
+                              inverse_scaler=inverse_scaler, snr=config.sampling.snr,
+                              n_steps=config.sampling.n_steps_each,
+                              probability_flow=config.sampling.probability_flow,
+                              continuous=config.training.continuous, denoise=config.sampling.noise_removal,
+                              eps=eps, device=device)
+    raise ValueError(f"Sampler name {name} unknown.")

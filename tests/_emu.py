@@ -17,11 +17,12 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
          beta=1.0, splitk=False):
     A = a.transpose(-1, -2) if trans_a else a
     Bm = b.transpose(-1, -2) if trans_b else b
-    out = alpha * torch.matmul(A, Bm)
+    out = torch.matmul(A, Bm)
     if bias is not None:
         out = out + bias
     if bias2 is not None:
         out = out + bias2.repeat_interleave(rows_per_group, dim=0)
+    out = alpha * out
     if res is not None:
         out = out + beta * res
     return out.contiguous()
@@ -37,11 +38,11 @@ def _w_oihw(w):
 
 def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
     y = F.conv2d(x.permute(0, 3, 1, 2), _w_oihw(w), None, stride, pad).permute(0, 2, 3, 1)
-    y = alpha * y
     if bias is not None:
         y = y + bias
     if bias2 is not None:
         y = y + bias2[:, None, None, :]
+    y = alpha * y
     if res is not None:
         y = y + beta * res
     return y.contiguous()
@@ -109,6 +110,30 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
     return dx.reshape(x.shape).contiguous(), dgamma, dbeta
 
 
+def bn_stats(x, eps):
+    v = x.reshape(-1, x.shape[-1])
+    mean = v.mean(0)
+    var = v.var(0, unbiased=False)
+    return mean, var, torch.rsqrt(var + eps)
+
+
+def bn_apply(x, mean, rstd, gamma, beta, act=0):
+    u = (x - mean) * rstd * gamma + beta
+    return F.elu(u) if act == 2 else u
+
+
+def bn_bwd(dy, x, mean, rstd, gamma, beta, act=0):
+    xh = (x - mean) * rstd
+    u = xh * gamma + beta
+    d = dy * torch.where(u > 0, torch.ones_like(u), torch.exp(u)) if act == 2 else dy
+    red = tuple(range(x.dim() - 1))
+    R = x.numel() // x.shape[-1]
+    dbeta = d.sum(red)
+    dgamma = (d * xh).sum(red)
+    dx = gamma * rstd * (d - dbeta / R - xh * dgamma / R)
+    return dx, dgamma, dbeta
+
+
 def softmax_fwd(x, scale=1.0):
     return torch.softmax(x * scale, dim=-1)
 
@@ -150,8 +175,8 @@ def act_bwd(dy, x, act):
     return dy * torch.where(x > 0, torch.ones_like(x), torch.exp(x))
 
 
-def axpby(x, y, a, b):
-    return a * x + (b * y if y is not None else 0)
+def axpby(x, y, a, b, c=0.0):
+    return a * x + (b * y if y is not None else 0) + c
 
 
 def mul(x, y, alpha=1.0):
@@ -283,6 +308,19 @@ def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, wd, step, clip, gnorm_sq, 
     p.addcdiv_(m, denom, value=-lr / bc1)
     if ema is not None:
         ema.sub_(ema_one_minus_decay * (ema - p))
+
+
+def fixed_point_check(x, xp, y, atol, rtol):
+    tol = atol + y.abs() * rtol
+    return (~((x - xp) ** 2 / tol < 1)).sum().float().reshape(1)
+
+
+def ema_update(s, p, one_minus_decay):
+    s.sub_(one_minus_decay * (s - p))
+
+
+def slogdet_inv(w):
+    return torch.slogdet(w)[1].reshape(1), torch.linalg.inv(w)
 
 
 def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, layout):

@@ -1,0 +1,175 @@
+"""Parity cases shared by the CPU host-logic tests (HIP layer emulated by tests/_emu.py) and the
+GPU parity tests (real kernels through the C ABI).  Each case replays the noise the reference drew,
+runs the PRODUCT path (indm_amd/*) and compares with the golden outputs of the reference."""
+import numpy as np
+import torch
+
+import golden_utils as gu
+from indm_amd import flow as iflow
+from indm_amd import likelihood, losses, ncsnpp, sampling, sde_lib, utils
+from indm_amd.rng import ReplayRng
+
+FIXTURES = ["mini_vp_nll", "mini_vp_fid", "mini_ve"]
+
+
+def build(fx, device):
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    cfg.device = torch.device(device)
+    score = ncsnpp.NCSNpp(cfg)
+    score.load_reference_state_dict(gu.state_dict(d, "score"))
+    fl = iflow.create_flow_model(cfg)
+    fl.load_reference_state_dict(gu.state_dict(d, "flow"))
+    return d, cfg, score.to(device), fl.to(device)
+
+
+def case_state_dict_roundtrip(fx, device):
+    d, cfg, score, fl = build(fx, device)
+    for model, pre in ((score, "score"), (fl, "flow")):
+        ref = gu.state_dict(d, pre)
+        out = model.reference_state_dict(prefix="")
+        assert set(out) == set(ref), (sorted(set(out) ^ set(ref))[:5])
+        for k in ref:
+            assert tuple(out[k].shape) == tuple(ref[k].shape), k
+            assert torch.equal(out[k].cpu().to(ref[k].dtype), ref[k]), k
+    assert [n for n, p in fl.named_parameters() if p.requires_grad] == list(d["flow_param_order"])
+    assert [n for n, p in score.named_parameters() if p.requires_grad] == list(d["score_param_order"])
+
+
+def case_score_network(fx, device, tol=1.0):
+    d, cfg, score, _ = build(fx, device)
+    sde = sde_lib.get_sde(cfg)
+    x = torch.from_numpy(d["x"]).to(device).requires_grad_(True)
+    t = torch.from_numpy(d["score/t"])
+    names = [k[len("score/grad/"):] for k in d if k.startswith("score/grad/")]
+    params = dict(score.named_parameters())
+    s = losses.get_score_fn(cfg, sde, score, train=False, continuous=True)(x, t)
+    gu.assert_close(s, d["score/out"], 1e-4 * tol, 1e-5 * tol, "score out")
+    grads = torch.autograd.grad(s, [x] + [params[n] for n in names], torch.from_numpy(d["score/gy"]).to(device))
+    gu.assert_close(grads[0], d["score/gx"], 1e-4 * tol, 1e-5 * tol, "score gx")
+    for n, g in zip(names, grads[1:]):
+        gu.assert_close(score.to_reference_layout(n, g), d[f"score/grad/{n}"], 2e-4 * tol, 1e-5 * tol, n)
+
+
+def case_flow_forward_modes(fx, device, tol=1.0):
+    d, cfg, _, fl = build(fx, device)
+    x = torch.from_numpy(d["x"]).to(device)
+    params = dict(fl.named_parameters())
+    for mode in ("train", "eval"):
+        fl.load_reference_state_dict(gu.state_dict(d, "flow"))
+        fl.train() if mode == "train" else fl.eval()
+        rng = ReplayRng(gu.events(d, f"flow_{mode}"), device)
+        z, ld = iflow.flow_forward(cfg, fl, x.clone(), reverse=False, rng=rng)
+        assert rng.done()
+        gu.assert_close(z, d[f"flow_{mode}/z"], 2e-5 * tol, 2e-5 * tol, f"flow {mode} z")
+        gu.assert_close(ld, d[f"flow_{mode}/logdet_kl"], 5e-5 * tol, 2e-4 * tol, f"flow {mode} logdet")
+        if mode == "train":
+            names = [k[len("flow_train/grad/"):] for k in d if k.startswith("flow_train/grad/")]
+            gr = torch.autograd.grad([z, ld], [params[n] for n in names],
+                                     [torch.from_numpy(d["flow_train/gz"]).to(device),
+                                      torch.tensor([1.0, -0.5], device=device)])
+            for n, g in zip(names, gr):
+                gu.assert_close(fl.to_reference_layout(n, g), d[f"flow_train/grad/{n}"], 5e-4 * tol, 5e-5 * tol,
+                                "grad " + n)
+            sd = fl.reference_state_dict(prefix="")
+            for k, v in gu.sub(d, "flow_train/buffers").items():
+                gu.assert_close(sd[k].float(), v.float(), 1e-4 * tol, 1e-5 * tol, "buffer " + k)
+    fl.load_reference_state_dict(gu.state_dict(d, "flow"))
+    fl.eval()
+    rng = ReplayRng(gu.events(d, "flow_nologdet"), device)
+    with torch.no_grad():
+        z, _ = iflow.flow_forward(cfg, fl, x.clone(), log_det=None, reverse=False, rng=rng)
+    gu.assert_close(z, d["flow_nologdet/z"], 2e-5 * tol, 2e-5 * tol, "flow nologdet")
+    rng = ReplayRng(gu.events(d, "flow_reverse"), device)
+    with torch.no_grad():
+        xr, _ = iflow.flow_forward(cfg, fl, torch.from_numpy(d["flow_eval/z"]).to(device), log_det=None,
+                                   reverse=True, rng=rng)
+    assert rng.done()
+    gu.assert_close(xr, d["flow_reverse/x"], 2e-4 * tol, 2e-4 * tol, "flow reverse")
+
+
+def case_nelbo(fx, device, tol=1.0):
+    d, cfg, score, fl = build(fx, device)
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    fn = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=utils.get_data_inverse_scaler(cfg))
+    rng = ReplayRng(gu.events(d, "nelbo"), device)
+    b1, b2 = fn(score, fl, torch.from_numpy(d["x"]).to(device), rng=rng)
+    assert rng.done()
+    gu.assert_close(b1, d["nelbo/bpd"], 2e-4 * tol, 2e-4 * tol, "nelbo")
+    gu.assert_close(b2, d["nelbo/bpd_residual"], 2e-4 * tol, 2e-4 * tol, "nelbo residual")
+
+
+def case_pc_sampler(fx, device, tol=1.0):
+    d, cfg, score, fl = build(fx, device)
+    cfg.sampling.method = "pc"
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    shape = tuple(d["x"].shape)
+    fn = sampling.get_sampling_fn(cfg, sde, shape, utils.get_data_inverse_scaler(cfg), cfg.sampling.truncation_time,
+                                  device=device)
+    rng = ReplayRng(gu.events(d, "pc"), device)
+    before, after, nfe = fn(score, fl, rng=rng)
+    assert rng.done() and nfe == int(d["pc/nfe"])
+    gu.assert_close(before, d["pc/before"], 2e-4 * tol, 2e-4 * tol, "pc before")
+    gu.assert_close(after, d["pc/after"], 2e-3 * tol, 2e-3 * tol, "pc after")
+
+
+def case_pf_ode(fx, device, tol=1.0):
+    d, cfg, score, fl = build(fx, device)
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    inv = utils.get_data_inverse_scaler(cfg)
+    x = torch.from_numpy(d["x"]).to(device)
+    from indm_amd import ops
+    from indm_amd.sampling import _Stepper
+    st = _Stepper(cfg, sde, score, None)
+    eps = torch.from_numpy(d["ode_rhs/eps"]).to(device)
+    drift, div = likelihood.get_div_fn(st, sde)(ops.to_nhwc(x), torch.from_numpy(d["ode_rhs/t"]), ops.to_nhwc(eps))
+    gu.assert_close(ops.to_nchw(drift), d["ode_rhs/drift"], 2e-4 * tol, 2e-5 * tol, "pf-ode drift")
+    gu.assert_close(div, d["ode_rhs/div"], 2e-4 * tol, 2e-3 * tol, "pf-ode div")
+    fn = likelihood.get_likelihood_fn(cfg, sde, inv, rtol=1e-3, atol=1e-3)
+    rng = ReplayRng(gu.events(d, "nll"), device)
+    bpd, z, nfe = fn(score, fl, x, rng=rng)
+    assert rng.done()
+    assert abs(nfe - int(d["nll/nfe"])) <= 12, (nfe, int(d["nll/nfe"]))
+    gu.assert_close(bpd, d["nll/bpd"], 1e-3 * tol, 3e-3 * tol, "nll bpd")
+    cfg.sampling.method = "ode"
+    cfg.eval.rtol, cfg.eval.atol = 1e-3, 1e-3
+    fn = sampling.get_sampling_fn(cfg, sde, tuple(x.shape), inv, cfg.sampling.truncation_time, device=device)
+    rng = ReplayRng(gu.events(d, "ode"), device)
+    before, after, nfe = fn(score, fl, rng=rng)
+    assert rng.done()
+    gu.assert_close(before, d["ode/before"], 5e-3 * tol, 5e-3 * tol, "ode before")
+    gu.assert_close(after, d["ode/after"], 5e-3 * tol, 5e-3 * tol, "ode after")
+
+
+def case_two_training_steps(fx, device, tol=1.0):
+    d, cfg, score, fl = build(fx, device)
+    sde = sde_lib.get_sde(cfg)
+    state, flow_state, flat_g = utils.build_states(cfg, score, fl, device)
+    step_fn = losses.get_step_fn(cfg, sde, train=True)
+    score.train(); fl.train()
+    for it in range(2):
+        rng = ReplayRng(gu.events(d, f"step{it}"), device)
+        out = step_fn(state, flow_state, torch.from_numpy(d[f"step{it}/x"]).to(device), rng=rng)
+        assert rng.done()
+        for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+            assert not v.is_cuda
+            gu.assert_close(v, d[f"step{it}/{nm}"], 5e-4 * tol, 2e-5 * tol, f"step{it} {nm}")
+    for pre, model, st in (("score", score, state), ("flow", fl, flow_state)):
+        ema = dict(zip([n for n, p in model.named_parameters() if p.requires_grad], st["ema"].shadow_params()))
+        for n, p in model.named_parameters():
+            gu.assert_close(gu.stat(p), d[f"after2/{pre}/stat/{n}"], 2e-5 * tol, 2e-6 * tol, "param " + n)
+            if p.requires_grad:
+                gu.assert_close(gu.stat(ema[n]), d[f"after2/{pre}/emastat/{n}"], 2e-5 * tol, 2e-6 * tol, "ema " + n)
+        sd = model.reference_state_dict(prefix="")
+        for k, v in gu.sub(d, f"after2/{pre}/full").items():
+            gu.assert_close(sd[k], v, 2e-4 * tol, 5e-6 * tol, "full " + k)
+    sd = fl.reference_state_dict(prefix="")
+    for k, v in gu.sub(d, "after2/flow/buffers").items():
+        gu.assert_close(sd[k].float(), v.float(), 1e-4 * tol, 1e-5 * tol, k)
+    assert [state["step"], flow_state["step"], state["ema"].num_updates] == list(d["after2/steps"])
+
+
+ALL_CASES = [case_state_dict_roundtrip, case_score_network, case_flow_forward_modes, case_nelbo, case_pc_sampler,
+             case_two_training_steps]

@@ -48,7 +48,7 @@ def test_gemm(M, N, K, ta, tb):
 def test_gemm_epilogue_batched_splitk():
     a, b = rnd(6, 64, 48), rnd(6, 48, 40, seed=2)
     bias, res = rnd(40, seed=3), rnd(6, 64, 40, seed=4)
-    out, ref = run_both("gemm", a, b, alpha=0.5, bias=bias, res=res, beta=-2.0)
+    out, ref = run_both("gemm", a, b, alpha=0.5, bias=bias, res=res, beta=-2.0)  # alpha*(ab+bias)+beta*res
     close(out, ref, name="gemm batched")
     a, b = rnd(512, 96), rnd(96, 72, seed=5)
     bias2 = rnd(4, 72, seed=6)
@@ -83,7 +83,7 @@ CONV_CASES = [
 def test_conv2d_fwd_dgrad_wgrad(N, H, W, Ci, Co, k, s, p):
     x, w = rnd(N, H, W, Ci), rnd(k, k, Ci, Co, seed=1, scale=0.2)
     bias, bias2 = rnd(Co, seed=2), rnd(N, Co, seed=3)
-    out, ref = run_both("conv2d", x, w, stride=s, pad=p, bias=bias, bias2=bias2)
+    out, ref = run_both("conv2d", x, w, stride=s, pad=p, bias=bias, bias2=bias2, alpha=0.7, res=rnd(N, (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1, Co, seed=9), beta=0.3)
     close(out, ref, rtol=1e-5, atol=1e-4, name="conv fwd")
     dy = rnd(*ref.shape, seed=4)
     res = rnd(N, H, W, Ci, seed=5)
@@ -166,7 +166,7 @@ def test_reductions_elementwise():
         close(o, r, name="act")
         o, r = run_both("act_bwd", da, p, act)
         close(o, r, name="act bwd")
-    o, r = run_both("axpby", da, dd, 0.7, -1.3)
+    o, r = run_both("axpby", da, dd, 0.7, -1.3, 0.25)
     close(o, r, name="axpby")
     o, r = run_both("axpby", da.reshape(-1)[:1001].clone(), dd.reshape(-1)[:1001].clone(), 0.7, -1.3)
     close(o, r, name="axpby odd")
@@ -265,6 +265,36 @@ def test_optimizer_kernels():
         hip.adamw_ema(P2, gs.to(DEV), M2, V2, None, 2e-4, 0.9, 0.99, 1e-8, 0.01, step, 1.0, hip.sqnorm(gs.to(DEV)),
                       1.0, 0.0)
     close(P2, pt.data, rtol=1e-6, atol=1e-6, name="adamw vs torch")
+
+
+def test_batchnorm_slogdet_ema():
+    x = rnd(4, 8, 8, 48) * 2 + 0.5
+    (m, v, r), (mr, vr, rr) = run_both("bn_stats", x, 1e-5)
+    close(m, mr, name="bn mean"); close(v, vr, rtol=1e-4, name="bn var"); close(r, rr, rtol=1e-4, name="bn rstd")
+    gamma, beta = rnd(48, seed=1) + 1.2, rnd(48, seed=2)
+    for act in (0, 2):
+        y, yr = run_both("bn_apply", x, mr.float(), rr.float(), gamma, beta, act=act)
+        close(y, yr, name="bn apply")
+        dy = rnd(4, 8, 8, 48, seed=3)
+        outs, refs = run_both("bn_bwd", dy, x, mr.float(), rr.float(), gamma, beta, act=act)
+        for o, r_, nm in zip(outs, refs, ("dx", "dgamma", "dbeta")):
+            close(o, r_, rtol=1e-4, atol=1e-4, name="bn " + nm)
+    for n in (64, 17):
+        w = torch.linalg.qr(rnd(n, n))[0] + 0.05 * rnd(n, n, seed=4)
+        (ld, inv), (ldr, invr) = run_both("slogdet_inv", w.contiguous())
+        close(ld, ldr, rtol=1e-4, atol=1e-4, name="slogdet")
+        close(inv, invr, rtol=1e-4, atol=1e-4, name="inverse")
+    xa, xb, yy = rnd(3000), rnd(3000) + rnd(3000, seed=2) * 4e-3, rnd(3000, seed=3)
+    c, cr = run_both("fixed_point_check", xa, xb, yy, 1e-5, 1e-5)
+    assert float(c) == float(cr) and float(cr) > 0
+    c, cr = run_both("fixed_point_check", xa, xa.clone(), yy, 1e-5, 1e-5)
+    assert float(c) == 0.0
+    s_, p_ = rnd(1001), rnd(1001, seed=1)
+    S = s_.clone().to(DEV)
+    hip.ema_update(S, p_.to(DEV), 0.25)
+    sr = s_.double()
+    _emu.ema_update(sr, p_.double(), 0.25)
+    close(S, sr, name="ema")
 
 
 UFD_CASES = [  # C, H, W, up, down, pad0, pad1  (the 9 VE call signatures, SURVEY App. B, + crops)
