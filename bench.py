@@ -1,0 +1,151 @@
+"""Headline benchmark: INDM (VP, NLL) training images/s on synthetic CIFAR-10-shaped batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one call of the reference-API train_step_fn (flow forward + log-det, score loss, backward, one
+flat-gradient all-reduce when N > 1, fused clip+AdamW+EMA for both networks) on configs/vp/CIFAR10/indm_nll
+at batch 128 PER GPU (weak scaling), fp32, dropout 0.1, random-init weights of the full architecture
+(61.8 M + 13.2 M parameters).  Rank 0 prints ONE JSON line; see DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def synthetic_batch(B, size, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, 3, size, size, generator=g)
+    x = (255.0 * x + torch.rand(x.shape, generator=g)) / 256.0   # run_lib.py:86 uniform dequantisation
+    return (x * 2.0 - 1.0).to(device)                             # data.centered scaler (datasets.py:58-60)
+
+
+def cpu_baseline(cfg, score, flow, batch=8):
+    """The CPU oracle (a port of the reference's step, pinned to reference goldens) timed on this box's host
+    cores on a bounded sample: one full-size training step at a small batch."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import indm_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in flow.reference_state_dict(prefix="").items()}
+    ocfg = cfg
+    st = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, ocfg)
+    fst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, ocfg)
+    x = synthetic_batch(batch, cfg.data.image_size, 999, "cpu")
+    drop = cfg.model.dropout
+    t0 = time.time()
+    O.flow_step_fn_nll(ocfg, O.get_sde(ocfg), st, fst, x, O.Rng())
+    dt = time.time() - t0
+    cfg.model.dropout = drop
+    return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full-size vp/CIFAR10/indm_nll train step at batch {batch} on the CPU oracle "
+                      f"(oracle/indm_oracle.py, torch CPU fp32), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from indm_amd import configs, hip, losses, parallel, sde_lib, utils
+    from indm_amd.flow import create_flow_model
+    from indm_amd.rng import DeviceRng
+
+    rank, world, local = parallel.init_distributed()
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    hip.lib()
+
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.training.batch_size = args.batch * world
+    cfg.device = dev
+    torch.manual_seed(cfg.seed)                     # default_cifar10_configs.py:126
+    score = utils.create_model(cfg, dev)
+    flow = create_flow_model(cfg).to(dev)
+    state, flow_state, flat_g = utils.build_states(cfg, score, flow, dev)
+    if world > 1:
+        parallel.broadcast_parameters(state["optimizer"].flat.p)
+        parallel.broadcast_parameters(flow_state["optimizer"].flat.p)
+    sde = sde_lib.get_sde(cfg)
+    step_fn = losses.get_step_fn(cfg, sde, train=True, world_size=world,
+                                 allreduce=parallel.make_allreduce(flat_g, world))
+    score.train(); flow.train()
+    batches = [synthetic_batch(args.batch, cfg.data.image_size, 1234 + rank + 1000 * i, dev)
+               for i in range(args.steps + args.warmup)]
+    rng = DeviceRng(dev, seed=1234 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    dominant = None
+    for i in range(args.warmup):
+        if i == args.warmup - 1:
+            hip.profile_start()
+        step_fn(state, flow_state, batches[i], rng=rng)
+        if i == args.warmup - 1:
+            prof = hip.profile_stop()
+            if prof:
+                dominant = max(prof, key=lambda k: prof[k]["ms"])
+    barrier()
+    hip.profile_start(only=dominant) if dominant else None
+    t0 = time.time()
+    last = None
+    for i in range(args.steps):
+        last = step_fn(state, flow_state, batches[args.warmup + i], rng=rng)
+    barrier()
+    elapsed = time.time() - t0
+    prof = hip.profile_stop() if dominant else {}
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        out = {
+            "metric": "training images/sec, CIFAR-10 INDM (VP, NLL)",
+            "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs/vp/CIFAR10/indm_nll.py train step (flow 16-16 idim 512 + NCSN++ nf128), "
+                                   f"batch {args.batch}/GPU, 32x32x3, fp32, dropout 0.1, random-init weights",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "last_loss_mean": float(last[0].mean()) if last is not None else None},
+        }
+        if dominant and dominant in prof and prof[dominant]["ms"] > 0:
+            p = prof[dominant]
+            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
+                               "algorithmic_gflop_per_launch": p["flops"] / p["launches"] / 1e9}
+        else:
+            out["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, score, flow)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,56 @@ def _ws(nfloats, device):
 SPLITK_WS_FLOATS = 1 << 25  # 128 MiB of fp32 partial slabs for weight-grad split-K
 
 
+# --------------------------------------------------------------------------- live per-kernel timing (bench.py)
+class _Profile:
+    """HIP-event timing of the dense (igemm) launches on the stream they are launched on.  Keys name the kernel
+    template instantiation, e.g. 'igemm<A_ROW,B_ROW,128x128>'.  Used by bench.py for the roofline line."""
+    enabled = False
+    only = None
+    rec = {}
+
+
+def profile_start(only=None):
+    _Profile.enabled, _Profile.only, _Profile.rec = True, only, {}
+
+
+def profile_stop():
+    """-> {key: dict(launches, flops, ms)} (synchronises)."""
+    _Profile.enabled = False
+    torch.cuda.synchronize()
+    out = {}
+    for k, (flops, evs) in _Profile.rec.items():
+        out[k] = dict(launches=len(evs), flops=flops, ms=sum(a.elapsed_time(b) for a, b in evs))
+    _Profile.rec = {}
+    return out
+
+
+def _tile(M, N):
+    return "128x32" if (N <= 32 and M > 32) else ("32x128" if M <= 32 else "128x128")
+
+
+class _timed:
+    def __init__(self, amode, bmode, M, N, K, batch=1):
+        self.key = f"igemm<{amode},{bmode},{_tile(M, N)}>"
+        self.flops = 2.0 * M * N * K * batch
+        self.on = _Profile.enabled and (_Profile.only is None or _Profile.only == self.key)
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            r = _Profile.rec.setdefault(self.key, [0.0, []])
+            r[0] += self.flops
+            r[1].append((self.e0, self.e1))
+        return False
+
+
 # --------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, rows_per_group=1, res=None,
          beta=1.0, splitk=False):
@@ -162,10 +212,11 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     sA = a.shape[-1] * a.shape[-2] if a.dim() == 3 else 0
     sB = b.shape[-1] * b.shape[-2] if b.dim() == 3 else 0
     ws = _ws(SPLITK_WS_FLOATS, a.device) if splitk else None
-    st = lib().indm_gemm_f32(_ptr(a), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
-                             b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
-                             _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
-                             _ptr(ws), SPLITK_WS_FLOATS if splitk else 0, _stream())
+    with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch):
+        st = lib().indm_gemm_f32(_ptr(a), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
+                                 b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
+                                 _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
+                                 _ptr(ws), SPLITK_WS_FLOATS if splitk else 0, _stream())
     _chk(st, "indm_gemm_f32")
     return out
 
@@ -182,8 +233,9 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
         raise RuntimeError("conv2d: channel mismatch")
     OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
     y = torch.empty((N, OH, OW, Co), dtype=torch.float32, device=x.device)
-    st = lib().indm_conv2d_fwd_f32(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, KH, KW, stride, pad, 1, OH, OW,
-                                   alpha, _ptr(bias), _ptr(bias2), _ptr(res), beta, _stream())
+    with _timed("A_CONV", "B_ROW", N * OH * OW, Co, KH * KW * Ci):
+        st = lib().indm_conv2d_fwd_f32(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, KH, KW, stride, pad, 1, OH, OW,
+                                       alpha, _ptr(bias), _ptr(bias2), _ptr(res), beta, _stream())
     _chk(st, "indm_conv2d_fwd_f32")
     return y
 
@@ -197,8 +249,9 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0):
         raise RuntimeError("conv2d_dgrad: channel mismatch")
     H, W = in_hw
     dx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=dy.device)
-    st = lib().indm_conv2d_dgrad_f32(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride, H,
-                                     W, alpha, _ptr(res), beta, _stream())
+    with _timed("A_CONV", "B_DGRAD", N * H * W, Ci, KH * KW * Co):
+        st = lib().indm_conv2d_dgrad_f32(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride,
+                                         H, W, alpha, _ptr(res), beta, _stream())
     _chk(st, "indm_conv2d_dgrad_f32")
     return dx
 
@@ -209,8 +262,9 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
     _, OH, OW, Co = dy.shape
     dw = torch.empty((kh, kw, Ci, Co), dtype=torch.float32, device=x.device)
     ws = _ws(SPLITK_WS_FLOATS, x.device)
-    st = lib().indm_conv2d_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), N, H, W, Ci, Co, kh, kw, stride, pad, OH, OW,
-                                     alpha, None, 0.0, _ptr(ws), SPLITK_WS_FLOATS, _stream())
+    with _timed("A_WGRAD", "B_ROW", kh * kw * Ci, Co, N * OH * OW):
+        st = lib().indm_conv2d_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), N, H, W, Ci, Co, kh, kw, stride, pad, OH, OW,
+                                         alpha, None, 0.0, _ptr(ws), SPLITK_WS_FLOATS, _stream())
     _chk(st, "indm_conv2d_wgrad_f32")
     return dw
 
