@@ -29,26 +29,59 @@ def synthetic_batch(B, size, seed, device):
     return (x * 2.0 - 1.0).to(device)                             # data.centered scaler (datasets.py:58-60)
 
 
-def cpu_baseline(cfg, score, flow, batch=8):
-    """The CPU oracle (a port of the reference's step, pinned to reference goldens) timed on this box's host
-    cores on a bounded sample: one full-size training step at a small batch."""
+def _usable_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # honour a cgroup CPU quota (otherwise torch oversubscribes the cores it may not use)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline_child(path, batch):
+    """Child process: one full-size oracle training step on the host cores (bounded sample)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import indm_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
-    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
-    sd_f = {k: v.cpu() for k, v in flow.reference_state_dict(prefix="").items()}
-    ocfg = cfg
-    st = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, ocfg)
-    fst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, ocfg)
+    from indm_amd import configs
+    torch.set_num_threads(_usable_cores())
+    blob = torch.load(path)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    st = O.OracleState(blob["score"], cfg.optim.lr, cfg.model.ema_rate, cfg)
+    fst = O.OracleState(blob["flow"], cfg.flow.lr, cfg.flow.ema_rate, cfg)
     x = synthetic_batch(batch, cfg.data.image_size, 999, "cpu")
-    drop = cfg.model.dropout
     t0 = time.time()
-    O.flow_step_fn_nll(ocfg, O.get_sde(ocfg), st, fst, x, O.Rng())
+    O.flow_step_fn_nll(cfg, O.get_sde(cfg), st, fst, x, O.Rng())
     dt = time.time() - t0
-    cfg.model.dropout = drop
-    return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+    print(json.dumps({"dt": dt, "threads": torch.get_num_threads()}))
+
+
+def cpu_baseline(cfg, score, flow, batch=16, timeout=420):
+    """The CPU oracle (a port of the reference's step, pinned to reference goldens) timed on this box's host
+    cores on a bounded sample: ONE full-size training step at a small batch, in a child process with a hard
+    timeout so the default bench run stays within minutes."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "weights.pt")
+        torch.save({"score": {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()},
+                    "flow": {k: v.cpu() for k, v in flow.reference_state_dict(prefix="").items()}}, path)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", path,
+                                "--batch", str(batch)], capture_output=True, text=True, timeout=timeout, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+            res = json.loads(line)
+        except Exception as e:  # noqa: BLE001
+            return {"value": None, "unit": "images/s", "cores": _usable_cores(), "kind": "port",
+                    "sample": f"oracle step at batch {batch} did not finish within {timeout}s ({type(e).__name__})"}
+    return {"value": batch / res["dt"], "unit": "images/s", "cores": res["threads"], "kind": "port",
             "sample": f"1 full-size vp/CIFAR10/indm_nll train step at batch {batch} on the CPU oracle "
-                      f"(oracle/indm_oracle.py, torch CPU fp32), {dt:.1f} s"}
+                      f"(oracle/indm_oracle.py, torch CPU fp32, {res['threads']} threads): {res['dt']:.1f} s"}
 
 
 def main():
@@ -58,7 +91,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.cpu_baseline_child, args.batch)
 
     from indm_amd import configs, hip, losses, parallel, sde_lib, utils
     from indm_amd.flow import create_flow_model
@@ -118,6 +154,7 @@ def main():
         elapsed = float(t)
 
     if rank == 0:
+        print(f"[bench] {args.steps} steps in {elapsed:.2f}s on {world} GPU(s)", file=sys.stderr, flush=True)
         imgs = args.batch * world * args.steps
         out = {
             "metric": "training images/sec, CIFAR-10 INDM (VP, NLL)",

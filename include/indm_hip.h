@@ -1,0 +1,175 @@
+/* indm_hip.h -- C ABI of libindm_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the INDM hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated; tensors are dense/contiguous
+ *   - activations are NHWC ([N,H,W,C]); convolution weights are RSCK ([KH,KW,Cin,Cout]); 1x1 weights [Cin,Cout]
+ *   - the caller owns all memory (outputs and `ws` scratch); nothing is allocated or freed here
+ *   - `stream` is a hipStream_t (NULL = default stream); kernels are only enqueued, never synchronised
+ *   - return value: 0 = ok, INDM_E_SHAPE (-1), INDM_E_DTYPE (-2), INDM_E_LAUNCH (-3), INDM_E_ARG (-4)
+ *   - no global state: every entry point is re-entrant per stream
+ *
+ * Each entry point names the reference interface (byeonghu-na/INDM, file:line) whose work it replaces.
+ * The reference binds its two native ops through pybind11 (op/upfirdn2d.cpp:21-23, op/fused_bias_act.cpp:19-21)
+ * and reaches everything else through ATen/cuDNN; see INTEGRATION.md for the reference-side bindings.
+ */
+#ifndef INDM_HIP_H
+#define INDM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INDM_OK 0
+#define INDM_E_SHAPE (-1)
+#define INDM_E_DTYPE (-2)
+#define INDM_E_LAUNCH (-3)
+#define INDM_E_ARG (-4)
+
+/* ---- reference native ops ------------------------------------------------------------------------------ */
+
+/* up-FIR-down resampling.  Replaces upfirdn2d_op.upfirdn2d(input, kernel, up_x, up_y, down_x, down_y,
+ * pad_x0, pad_x1, pad_y0, pad_y1) -- op/upfirdn2d.cpp:12-23, op/upfirdn2d_kernel.cu:107-369; semantics pinned
+ * by upfirdn2d_native, op/upfirdn2d.py:159-200.  layout 0: x is [N,C,H,W] (the reference's [major,H,W,1] view),
+ * layout 1: x is [N,H,W,C].  Output spatial size (in*up + pad0 + pad1 - k)/down + 1. */
+int indm_upfirdn2d_f32(const float* x, const float* kernel, float* y, int N, int C, int in_h, int in_w, int kh,
+                       int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                       int pad_y1, int layout, void* stream);
+
+/* y = act(x + bias[(i/step_b) % size_b]) * scale.  Replaces fused.fused_bias_act(input, bias, refer, act, grad,
+ * alpha, scale) -- op/fused_bias_act.cpp:11-21, op/fused_bias_act_kernel.cu:18-99 (act 1 linear, 3 leaky-ReLU;
+ * grad 0/1/2).  bias / ref may be NULL. */
+int indm_fused_bias_act_f32(const float* x, const float* bias, const float* ref, float* y, long n, long step_b,
+                            int size_b, int act, int grad, float alpha, float scale, void* stream);
+
+/* ---- dense contractions (fp32 MFMA implicit-GEMM engine) ----------------------------------------------- */
+
+/* C[b] = alpha*(opA(A[b]) opB(B[b]) + bias[n] + bias2[m/rows_per_group][n]) + beta*R[b].
+ * Replaces ATen matmul/linear/einsum call sites: NIN models/layers.py:546-556, Dense models/layerspp.py:239-261,
+ * attention einsums models/layerspp.py:95-99, LopCondConv2d 1x1 lipschitz.py:429-435, NICEMLPBlock blocks.py:36-43.
+ * transA: A stored [K,M]; transB: B stored [N,K].  ws/ws_floats: optional split-K scratch (NULL = no split-K). */
+int indm_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int transA, int transB, long lda,
+                  long ldb, long ldc, int batch, long strideA, long strideB, long strideC, float alpha,
+                  const float* bias, const float* bias2, int rows_per_group, const float* R, long ldr,
+                  long strideR, float beta, float* ws, long ws_floats, void* stream);
+
+/* y = alpha*(conv(x,w) + bias[co] + bias2[n][co]) + beta*R.  Replaces F.conv2d call sites: ddpm_conv3x3
+ * models/layers.py:113-124, LopConv2d.forward lipschitz.py:361-363, encoder convs resnet_batchnorm.py:8-10,
+ * conv_downsample_2d up_or_down_sampling.py:178.  in_dil > 1 treats x as zero-inserted. */
+int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int Nimg, int H, int W, int Cin, int Cout, int KH,
+                        int KW, int stride, int pad, int in_dil, int OH, int OW, float alpha, const float* bias,
+                        const float* bias2, const float* R, float beta, void* stream);
+
+/* dx = alpha * conv_transpose(dy, w) + beta*R: the data gradient of indm_conv2d_fwd_f32 (autograd of F.conv2d in
+ * the reference) and, as a forward op, the explicit vector-Jacobian product of the residual-flow g-net that
+ * replaces torch.autograd.grad(g, x, v) at iresblock.py:257,269-271.  pad_t = K-1-pad_fwd, in_dil = fwd stride. */
+int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, int H, int W, int Cin, int Cout,
+                          int KH, int KW, int pad_t, int in_dil, int OH, int OW, float alpha, const float* R,
+                          float beta, void* stream);
+
+/* dw[kh,kw,ci,co] = alpha * sum_pixels x * dy (+ beta*R): weight gradient of the convolution (autograd of
+ * F.conv2d); the pixel reduction is split-K into ws. */
+int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad, int OH, int OW, float alpha, const float* R,
+                          float beta, float* ws, long ws_floats, void* stream);
+
+/* ---- normalisation / softmax / reductions --------------------------------------------------------------- */
+
+/* GroupNorm(G, C, eps) [+SiLU] [+Philox dropout], fused.  Replaces nn.GroupNorm + nn.SiLU + nn.Dropout at
+ * models/layerspp.py:232,244,256,277-278, models/layers.py:38-39.  act 0 none / 1 SiLU. */
+long indm_groupnorm_ws_floats(int N, int HW, int C, int G);
+int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                           float* rstd, int N, int HW, int C, int G, float eps, int act, float drop_p,
+                           unsigned long long seed, float* ws, void* stream);
+int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
+                           const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, int N,
+                           int HW, int C, int G, int act, float drop_p, unsigned long long seed, float* ws,
+                           void* stream);
+
+/* Training-mode BatchNorm2d (+ELU) of the flow encoder: nnet/resnets/resnet_batchnorm.py:23-76. */
+int indm_bn_stats_f32(const float* x, float* mean, float* var, float* rstd, long R, int C, float eps, float* ws,
+                      void* stream);
+int indm_bn_apply_f32(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      float* y, long R, int C, int act, void* stream);
+int indm_bn_bwd_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, float* dx, float* dgamma, float* dbeta, long R, int C, int act, float* ws,
+                    void* stream);
+
+/* softmax(scale*x) over the last dim and its gradient: F.softmax at models/layerspp.py:97. */
+int indm_softmax_fwd_f32(const float* x, float* y, long rows, int T, float scale, void* stream);
+int indm_softmax_bwd_f32(const float* dy, const float* y, float* dx, long rows, int T, float scale, void* stream);
+
+/* out[c] = alpha * sum_r f(x[r,c], y[r,c]) + beta*out[c]  (mode 0: x, 1: x*y, 2: x*x): bias gradients. */
+long indm_colreduce_ws_floats(long R, int C);
+int indm_colreduce_f32(const float* x, const float* y, float* out, long R, int C, int mode, float alpha, float beta,
+                       float* ws, void* stream);
+
+/* out[b] = alpha * sum_i f(x[b,i], y[b,i])  (mode 0: x*y, 1: x*x, 2: x): Hutchinson traces
+ * (iresblock.py:258,272; likelihood.py:37,206-213), prior_logp (sde_lib.py:165-169), Langevin norms. */
+long indm_rowreduce_ws_floats(long B, long D);
+int indm_rowreduce_f32(const float* x, const float* y, float* out, long B, long D, int mode, float alpha, float* ws,
+                       void* stream);
+
+/* ---- elementwise / layout -------------------------------------------------------------------------------- */
+
+/* Sin activation of the residual flow and its derivative in one pass: a = sin(2 pi p)/(2 pi), d = cos(2 pi p)
+ * (layers/base/activations.py:7-12); bwd: dp = da*d - 4 pi^2 * a * dd. */
+int indm_sincos_act_fwd_f32(const float* p, float* a, float* d, long n, void* stream);
+int indm_sincos_act_bwd_f32(const float* da, const float* dd, const float* a, const float* d, float* dp, long n,
+                            void* stream);
+/* act 1 SiLU (models/layers.py:38-39), 2 ELU (resnet_batchnorm.py:27) */
+int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);
+int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);
+int indm_axpby_f32(const float* x, const float* y, float* out, float a, float b, float c, long n, void* stream);
+int indm_mul_f32(const float* x, const float* y, float* out, float alpha, long n, void* stream);
+int indm_scale_rows_f32(const float* x, const float* s, float* out, long B, long D, void* stream);
+/* naive_upsample_2d / naive_downsample_2d, models/up_or_down_sampling.py:59-69 (NHWC) */
+int indm_upsample2x_f32(const float* x, float* y, int N, int H, int W, int C, float alpha, void* stream);
+int indm_downsample2x_f32(const float* x, float* y, int N, int H, int W, int C, float alpha, void* stream);
+/* squeeze / unsqueeze (pixel_shuffle), flows/resflow/layers/squeeze.py:27-45, NHWC with channel = c*4+dy*2+dx */
+int indm_squeeze2x_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int indm_unsqueeze2x_f32(const float* x, float* y, int N, int H, int W, int C4, void* stream);
+/* NCHW <-> NHWC at the API edge (dir 0: NCHW->NHWC, 1: NHWC->NCHW) */
+int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, int dir, void* stream);
+/* Lop weight normalisation w / max(1, ||w[:,co]||_1 / coeff) and its gradient: LopConv2d.compute_weight,
+ * layers/base/lipschitz.py:350-359 (domain = codomain = inf) */
+int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff, void* stream);
+int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const float* l1, float* dw, float* dot, int R,
+                               int Co, float coeff, void* stream);
+/* stop test of the fixed-point inverse: count of elements with (x-xp)^2/(atol+|y|rtol) >= 1, iresblock.py:81-82 */
+int indm_fixed_point_check_f32(const float* x, const float* xp, const float* y, long n, float atol, float rtol,
+                               float* out, void* stream);
+/* log|det W| and W^-1, n <= 64: torch.slogdet(weight.to('cpu')), flows/permutation.py:107-108,131-132 */
+int indm_slogdet_inv_f32(const float* W, int n, float* logdet, float* inv, void* stream);
+
+/* ---- SDE / loss / sampler / optimiser --------------------------------------------------------------------- */
+
+/* out = mc[b]*x + sd[b]*noise: sde.marginal_prob + perturbation, sde_lib.py:153-157,284-287; losses.py:103-105 */
+int indm_sde_perturb_f32(const float* x, const float* noise, const float* mc, const float* sd, float* out, long B,
+                         long D, void* stream);
+/* per-image DSM loss from the raw network output and its gradient: losses.py:106-118 with
+ * score = -out/std (kind 0, models/utils.py:175-177) or out (kind 1) */
+long indm_dsm_ws_floats(long B, long D);
+int indm_dsm_loss_fwd_f32(const float* out, const float* z, const float* std, const float* w, float* loss, long B,
+                          long D, int kind, int mode, int reduce_mean, float* ws, void* stream);
+int indm_dsm_loss_bwd_f32(const float* gl, const float* out, const float* z, const float* std, const float* w,
+                          float* dout, long B, long D, int kind, int mode, int reduce_mean, void* stream);
+/* x_mean = a[b]*x + b[b]*s ; x_new = x_mean + c[b]*z: EulerMaruyama / ReverseDiffusion / Langevin updates,
+ * sampling.py:191-197,205-210,289-290 */
+int indm_affine_update_f32(const float* x, const float* s, const float* z, const float* a, const float* b,
+                           const float* c, float* x_new, float* x_mean, long B, long D, void* stream);
+/* Langevin step size from batch-mean norms, sampling.py:284-288 */
+int indm_langevin_step_f32(const float* grad_sq, const float* noise_sq, const float* alpha, float* step,
+                           float* noise_coef, int B, float snr, void* stream);
+/* sum g^2 -> device scalar (torch.nn.utils.clip_grad_norm_, losses.py:58-59) */
+long indm_sqnorm_ws_floats(void);
+int indm_sqnorm_f32(const float* g, long n, float* out, float* ws, void* stream);
+/* fused clip_grad_norm_ + AdamW + EMA on flat buffers: losses.py:30-62, models/ema.py:32-51 */
+int indm_adamw_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int step, float clip, const float* gnorm_sq,
+                       float gscale, float ema_one_minus_decay, void* stream);
+int indm_ema_update_f32(float* s, const float* p, long n, float one_minus_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INDM_HIP_H */

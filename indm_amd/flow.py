@@ -587,7 +587,7 @@ class WolfCore(nn.Module):
         self.load_state_dict(new)
         for m in self.modules():
             if isinstance(m, IResBlock):
-                m.lamb_value = float(m.lamb)
+                m.lamb_value = float(m.lamb.detach())
 
     @staticmethod
     def to_reference_layout(k, v):

@@ -492,7 +492,7 @@ def iresblock_g(P, pre, x, h):
 
 def iresblock_logdet(P, pre, x, h, training, rng, stats=None):
     """_logdetgrad iresblock.py:90-174 (poisson, n_samples=1, exact_trace=False, n_power_series=None)."""
-    lamb = float(P[pre + ".lamb"])
+    lamb = float(P[pre + ".lamb"].detach())
     n = rng.poisson(lamb)
     n_exact = 2 if training else 20  # :118, :129
     K = n + n_exact
