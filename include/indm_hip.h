@@ -135,6 +135,12 @@ int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, int dir, 
 int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff, void* stream);
 int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const float* l1, float* dw, float* dot, int R,
                                int Co, float coeff, void* stream);
+/* 3x3 convolutions with a skinny channel side (flow edges 512 <-> 3/12, resflow_.py:442-476) are computed as ONE
+ * MFMA GEMM against the tap-major weight ([pixels,wide] x [wide, 9*C]) followed by this gather over the 9 shifted
+ * taps (sign +1 forward conv, -1 transposed conv); tap_spread is its adjoint (used for the weight gradient). */
+int indm_tap_gather_f32(const float* P, const float* bias, float* y, int N, int H, int W, int C, int sign,
+                        float alpha, void* stream);
+int indm_tap_spread_f32(const float* y, float* P, int N, int H, int W, int C, int sign, float alpha, void* stream);
 /* stop test of the fixed-point inverse: count of elements with (x-xp)^2/(atol+|y|rtol) >= 1, iresblock.py:81-82 */
 int indm_fixed_point_check_f32(const float* x, const float* xp, const float* y, long n, float atol, float rtol,
                                float* out, void* stream);

@@ -54,19 +54,23 @@ __global__ void rowreduce_final_kernel(const float* __restrict__ part, float* __
   out[b] = alpha * s;
 }
 
-// Lop normalisation over RSCK weight viewed as [R, Co]: per-column L1 norm.
+// Lop normalisation over RSCK weight viewed as [R, Co]: per-column L1 norm.  grid (Co/64, RB): each workgroup
+// owns 64 columns x one row-block (4 row lanes inside) and adds its partial with ONE atomic per column.
+// (<= 16 partials per column; fp32 add order may vary by 1 ulp between runs.)
 __global__ __launch_bounds__(256) void lop_colnorm_kernel(const float* __restrict__ w, float* __restrict__ l1, int R,
                                                           int Co) {
-  // one block per 64 columns; 4 row-lanes x 64 col-lanes
   __shared__ float sh[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
+  const int rows = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows, r1 = min(R, r0 + rows);
   float s = 0.f;
   if (c < Co)
-    for (int r = rl; r < R; r += 4) s += fabsf(w[(long)r * Co + c]);
+    for (int r = r0 + rl; r < r1; r += 4) s += fabsf(w[(long)r * Co + c]);
   sh[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < Co) l1[c] = sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63];
+  if (rl == 0 && c < Co)
+    atomicAdd(&l1[c], sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63]);
 }
 // dot[c] = sum_r dwn[r,c]*w[r,c]
 __global__ __launch_bounds__(256) void lop_coldot_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -74,12 +78,15 @@ __global__ __launch_bounds__(256) void lop_coldot_kernel(const float* __restrict
   __shared__ float sh[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
+  const int rows = (R + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows, r1 = min(R, r0 + rows);
   float s = 0.f;
   if (c < Co)
-    for (int r = rl; r < R; r += 4) s += a[(long)r * Co + c] * b[(long)r * Co + c];
+    for (int r = r0 + rl; r < r1; r += 4) s += a[(long)r * Co + c] * b[(long)r * Co + c];
   sh[rl][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rl == 0 && c < Co) out[c] = sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63];
+  if (rl == 0 && c < Co)
+    atomicAdd(&out[c], sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63] + sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63]);
 }
 
 // counts elements violating (x-xp)^2 / (atol + |y|*rtol) < 1  (iresblock.py:81-82)
@@ -95,6 +102,58 @@ __global__ __launch_bounds__(256) void fp_check_kernel(const float* __restrict__
   }
   c = block_sum(c, sh);
   if (threadIdx.x == 0 && c != 0.f) atomicAdd(out, c);
+}
+
+// Tap gather for 3x3 convolutions with a skinny channel side (flow edges C = 3 / 12):
+//   y[n,h,w,c] = alpha * ( sum_{kh,kw} P[n, h + s*(kh-1), w + s*(kw-1), (kh*3+kw)*C + c] + bias[c] )
+// P is the [pixels, 9*C] product of the wide side with the tap-major weight (an MFMA GEMM with N = 9C instead
+// of nine N = C ones).  s = +1: forward conv; s = -1: data-grad / transposed conv.
+__global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ P, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int N, int H, int W, int C, int s,
+                                                         float alpha) {
+  const long total = (long)N * H * W * C;
+  const int C9 = 9 * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + s * (kh - 1);
+      if (hh < 0 || hh >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ww = w + s * (kw - 1);
+        if (ww < 0 || ww >= W) continue;
+        acc += P[(((long)n * H + hh) * W + ww) * C9 + (kh * 3 + kw) * C + c];
+      }
+    }
+    y[i] = alpha * acc;
+  }
+}
+// adjoint of the gather: Pout[n,h',w',(tap,c)] = alpha * y[n, h' - s*(kh-1), w' - s*(kw-1), c]  (0 outside)
+__global__ __launch_bounds__(256) void tap_spread_kernel(const float* __restrict__ y, float* __restrict__ P, int N,
+                                                         int H, int W, int C, int s, float alpha) {
+  const int C9 = 9 * C;
+  const long total = (long)N * H * W * C9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % C9);
+    long r = i / C9;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    const int tap = j / C, c = j - tap * C;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int hh = h - s * (kh - 1), ww = w - s * (kw - 1);
+    float v = 0.f;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = alpha * y[(((long)n * H + hh) * W + ww) * C + c];
+    P[i] = v;
+  }
 }
 
 }  // namespace
@@ -277,7 +336,9 @@ INDM_API int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, 
 INDM_API int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff,
                                         void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(lop_colnorm_kernel, dim3(cdiv(Co, 64)), dim3(256), 0, st, w, l1, R, Co);
+  const int RB = R >= 1024 ? 16 : (R >= 64 ? 4 : 1);  // row-blocks: more workgroups for tall, skinny weights
+  if (hipMemsetAsync(l1, 0, sizeof(float) * Co, st) != hipSuccess) return INDM_E_LAUNCH;
+  hipLaunchKernelGGL(lop_colnorm_kernel, dim3(cdiv(Co, 64), RB), dim3(256), 0, st, w, l1, R, Co);
   INDM_CHECK_LAUNCH();
   return ew_launch((long)R * Co, st, [=] __device__(long i) {
     const int c = (int)(i % Co);
@@ -288,7 +349,9 @@ INDM_API int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, in
 INDM_API int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const float* l1, float* dw, float* dot,
                                         int R, int Co, float coeff, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(lop_coldot_kernel, dim3(cdiv(Co, 64)), dim3(256), 0, st, dwn, w, dot, R, Co);
+  const int RB = R >= 1024 ? 16 : (R >= 64 ? 4 : 1);
+  if (hipMemsetAsync(dot, 0, sizeof(float) * Co, st) != hipSuccess) return INDM_E_LAUNCH;
+  hipLaunchKernelGGL(lop_coldot_kernel, dim3(cdiv(Co, 64), RB), dim3(256), 0, st, dwn, w, dot, R, Co);
   INDM_CHECK_LAUNCH();
   return ew_launch((long)R * Co, st, [=] __device__(long i) {
     const int c = (int)(i % Co);
@@ -311,6 +374,25 @@ INDM_API int indm_fixed_point_check_f32(const float* x, const float* xp, const f
   if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return INDM_E_LAUNCH;
   if (n <= 0) return INDM_OK;
   hipLaunchKernelGGL(fp_check_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, st, x, xp, y, n, atol, rtol, out);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+INDM_API int indm_tap_gather_f32(const float* P, const float* bias, float* y, int N, int H, int W, int C, int sign,
+                                 float alpha, void* stream) {
+  const long total = (long)N * H * W * C;
+  if (total <= 0) return INDM_OK;
+  hipLaunchKernelGGL(tap_gather_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, P, bias, y, N, H,
+                     W, C, sign, alpha);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+INDM_API int indm_tap_spread_f32(const float* y, float* P, int N, int H, int W, int C, int sign, float alpha,
+                                 void* stream) {
+  const long total = (long)N * H * W * C * 9;
+  if (total <= 0) return INDM_OK;
+  hipLaunchKernelGGL(tap_spread_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, P, N, H, W, C,
+                     sign, alpha);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

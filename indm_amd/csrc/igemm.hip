@@ -19,7 +19,10 @@
 
 namespace {
 
-constexpr int BK = 16;
+#ifndef INDM_BK
+#define INDM_BK 32
+#endif
+constexpr int BK = INDM_BK;
 
 enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_WGRAD = 3 };
 enum { B_ROW = 0, B_COL = 1, B_DGRAD = 2 };
@@ -46,6 +49,7 @@ struct IgemmParams {
   int splitk, kps;
   float* ws;
   int a_vec, b_vec;
+  int a_tap_uniform, b_tap_uniform;  // reduction slab of BK never straddles a tap (Cin % BK == 0)
 };
 
 struct PixDec {
@@ -110,7 +114,8 @@ __device__ __forceinline__ float b_elem(const IgemmParams& p, const float* B, in
 // ---- vectorised group loads -------------------------------------------------
 // K-contiguous group: (row, k..k+3).  Row-contiguous group: (row..row+3, k).
 template <int AM>
-__device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, int row, int k, int kend) {
+__device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, int row, int k, int kend,
+                                          const PixDec& rowdec, const int3& tapdec, int kbase) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (AM == A_ROW) {
     if (p.a_vec && row < p.M && k + 3 < kend) return *(const float4*)(A + (long)row * p.lda + k);
@@ -127,10 +132,16 @@ __device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, 
   } else if constexpr (AM == A_CONV) {
     if (p.a_vec) {
       if (row >= p.M || k >= kend) return v;
-      const PixDec d = decode_pix(row, p.OH, p.OW);
-      const int tap = k / p.Cin, ci = k - tap * p.Cin;
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      int ih = d.oh * p.stride + kh - p.pad, iw = d.ow * p.stride + kw - p.pad;
+      // rowdec = (img, oh, ow) hoisted out of the K loop; tapdec = (kh, kw, ci) uniform per slab when aligned
+      int kh, kw, ci;
+      if (p.a_tap_uniform) {
+        kh = tapdec.x; kw = tapdec.y; ci = tapdec.z + (k - kbase);
+      } else {
+        const int tap = k / p.Cin;
+        ci = k - tap * p.Cin;
+        kh = tap / p.KW; kw = tap - kh * p.KW;
+      }
+      int ih = rowdec.oh * p.stride + kh - p.pad, iw = rowdec.ow * p.stride + kw - p.pad;
       if (ih < 0 || iw < 0) return v;
       if (p.dil > 1) {
         if ((ih % p.dil) | (iw % p.dil)) return v;
@@ -138,21 +149,19 @@ __device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, 
         iw /= p.dil;
       }
       if (ih >= p.H || iw >= p.W) return v;
-      return *(const float4*)(A + (((long)d.img * p.H + ih) * p.W + iw) * p.Cin + ci);
+      return *(const float4*)(A + (((long)rowdec.img * p.H + ih) * p.W + iw) * p.Cin + ci);
     }
     v.x = a_elem<AM>(p, A, row, k, kend);
     v.y = a_elem<AM>(p, A, row, k + 1, kend);
     v.z = a_elem<AM>(p, A, row, k + 2, kend);
     v.w = a_elem<AM>(p, A, row, k + 3, kend);
-  } else {  // A_WGRAD, row-contiguous over ci
+  } else {  // A_WGRAD, row-contiguous over ci; rowdec = (kh, kw, ci) of this row group (hoisted)
     if (p.a_vec) {
       if (row >= p.M || k >= kend) return v;
       const PixDec d = decode_pix(k, p.OH, p.OW);
-      const int tap = row / p.Cin, ci = row - tap * p.Cin;
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      const int ih = d.oh * p.stride + kh - p.pad, iw = d.ow * p.stride + kw - p.pad;
+      const int ih = d.oh * p.stride + rowdec.img - p.pad, iw = d.ow * p.stride + rowdec.oh - p.pad;
       if (ih < 0 || iw < 0 || ih >= p.H || iw >= p.W) return v;
-      return *(const float4*)(A + (((long)d.img * p.H + ih) * p.W + iw) * p.Cin + ci);
+      return *(const float4*)(A + (((long)d.img * p.H + ih) * p.W + iw) * p.Cin + rowdec.ow);
     }
     v.x = a_elem<AM>(p, A, row, k, kend);
     v.y = a_elem<AM>(p, A, row + 1, k, kend);
@@ -163,7 +172,8 @@ __device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, 
 }
 
 template <int BMODE>
-__device__ __forceinline__ float4 b_group(const IgemmParams& p, const float* B, int row, int k, int kend) {
+__device__ __forceinline__ float4 b_group(const IgemmParams& p, const float* B, int row, int k, int kend,
+                                          const int2& btap, int kbase) {
   float4 v;
   if constexpr (BMODE == B_ROW) {
     if (p.b_vec && k < kend && row + 3 < p.N) return *(const float4*)(B + (long)k * p.ldb + row);
@@ -179,7 +189,12 @@ __device__ __forceinline__ float4 b_group(const IgemmParams& p, const float* B, 
     v.w = b_elem<BMODE>(p, B, k + 3, row, kend);
   } else {
     if (p.b_vec && row < p.N && k + 3 < kend) {
-      const int tap = k / p.Cout, co = k - tap * p.Cout;
+      int tap, co;
+      if (p.b_tap_uniform) {
+        tap = btap.x; co = btap.y + (k - kbase);
+      } else {
+        tap = k / p.Cout; co = k - tap * p.Cout;
+      }
       const int T = p.KH * p.KW;
       return *(const float4*)(B + ((long)(T - 1 - tap) * p.N + row) * p.Cout + co);
     }
@@ -242,17 +257,54 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 
   float4 ra[NGA], rb[NGB];
 
+  // loop-invariant per-thread coordinates of the A row groups
+  PixDec rowdec[NGA];
+#pragma unroll
+  for (int j = 0; j < NGA; ++j) {
+    const int g = tid + j * 256;
+    rowdec[j].img = rowdec[j].oh = rowdec[j].ow = 0;
+    if constexpr (AM == A_CONV) {
+      const int row = m0 + (g >> 2);
+      if (g < TM * 4 && row < p.M) rowdec[j] = decode_pix(row, p.OH, p.OW);
+    } else if constexpr (AM == A_WGRAD) {
+      constexpr int Q = TM / 4;
+      const int row = m0 + (g % Q) * 4;
+      if (g < TM * 4 && row < p.M) {
+        const int tap = row / p.Cin;
+        rowdec[j].ow = row - tap * p.Cin;       // ci
+        rowdec[j].img = tap / p.KW;             // kh
+        rowdec[j].oh = tap - rowdec[j].img * p.KW;  // kw
+      }
+    }
+  }
+
   auto gload = [&](int kt) {
     const int k0 = kbeg + kt * BK;
+    int3 tapdec = make_int3(0, 0, 0);
+    int2 btap = make_int2(0, 0);
+    if constexpr (AM == A_CONV) {
+      if (p.a_tap_uniform) {
+        const int tap = k0 / p.Cin;
+        tapdec.z = k0 - tap * p.Cin;
+        tapdec.x = tap / p.KW;
+        tapdec.y = tap - tapdec.x * p.KW;
+      }
+    }
+    if constexpr (BMODE == B_DGRAD) {
+      if (p.b_tap_uniform) {
+        btap.x = k0 / p.Cout;
+        btap.y = k0 - btap.x * p.Cout;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NGA; ++j) {
       const int g = tid + j * 256;
       if (g < TM * 4) {
         if constexpr (a_kcontig<AM>()) {
-          ra[j] = a_group<AM>(p, A, m0 + (g >> 2), k0 + (g & 3) * 4, kend);
+          ra[j] = a_group<AM>(p, A, m0 + (g >> 2), k0 + (g & 3) * 4, kend, rowdec[j], tapdec, k0);
         } else {
           constexpr int Q = TM / 4;
-          ra[j] = a_group<AM>(p, A, m0 + (g % Q) * 4, k0 + g / Q, kend);
+          ra[j] = a_group<AM>(p, A, m0 + (g % Q) * 4, k0 + g / Q, kend, rowdec[j], tapdec, k0);
         }
       }
     }
@@ -261,10 +313,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
       const int g = tid + j * 256;
       if (g < TN * 4) {
         if constexpr (b_kcontig<BMODE>()) {
-          rb[j] = b_group<BMODE>(p, B, n0 + (g >> 2), k0 + (g & 3) * 4, kend);
+          rb[j] = b_group<BMODE>(p, B, n0 + (g >> 2), k0 + (g & 3) * 4, kend, btap, k0);
         } else {
           constexpr int Q = TN / 4;
-          rb[j] = b_group<BMODE>(p, B, n0 + (g % Q) * 4, k0 + g / Q, kend);
+          rb[j] = b_group<BMODE>(p, B, n0 + (g % Q) * 4, k0 + g / Q, kend, btap, k0);
         }
       }
     }
@@ -500,6 +552,7 @@ INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int N
   p.R = R; p.ldr = Cout;
   p.a_vec = al16(x) && (Cin % 4 == 0);
   p.b_vec = al16(w) && (Cout % 4 == 0);
+  p.a_tap_uniform = (Cin % BK == 0);
   return run(p, A_CONV, B_ROW, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -519,6 +572,7 @@ INDM_API int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, i
   p.alpha = alpha; p.beta = beta; p.rpg = 1; p.R = R; p.ldr = Cin;
   p.a_vec = al16(dy) && (Cout % 4 == 0);
   p.b_vec = al16(w) && (Cout % 4 == 0);
+  p.a_tap_uniform = p.b_tap_uniform = (Cout % BK == 0);
   return run(p, A_CONV, B_DGRAD, nullptr, 0, (hipStream_t)stream);
 }
 

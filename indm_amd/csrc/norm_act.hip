@@ -197,28 +197,37 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
   }
 }
 
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ gpart, const float* __restrict__ cpart,
-                                       float* __restrict__ gsum, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int N, int C, int G, int S) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N * G) {
-    const int n = i / G, g = i - n * G;
-    float a = 0.f, b = 0.f;
-    for (int s = 0; s < S; ++s) {
-      a += gpart[((long)(n * S + s)) * 2 * G + g];
-      b += gpart[((long)(n * S + s)) * 2 * G + G + g];
+// one workgroup per output element: blocks [0, N*G) reduce the group sums over the S splits, blocks
+// [N*G, N*G + C) reduce dbeta/dgamma over all N*S partial rows (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ gpart, const float* __restrict__ cpart,
+                                                               float* __restrict__ gsum, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int N, int C, int G, int S) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  if (b < N * G) {
+    if (threadIdx.x == 0) {
+      const int n = b / G, g = b - n * G;
+      float a0 = 0.f, a1 = 0.f;
+      for (int s = 0; s < S; ++s) {
+        a0 += gpart[((long)(n * S + s)) * 2 * G + g];
+        a1 += gpart[((long)(n * S + s)) * 2 * G + G + g];
+      }
+      gsum[2 * b] = a0;
+      gsum[2 * b + 1] = a1;
     }
-    gsum[2 * i] = a;
-    gsum[2 * i + 1] = b;
+    return;
   }
-  if (i < C) {
-    float db = 0.f, dg = 0.f;
-    for (int b = 0; b < N * S; ++b) {
-      db += cpart[(long)b * 2 * C + i];
-      dg += cpart[(long)b * 2 * C + C + i];
-    }
-    dbeta[i] = db;
-    dgamma[i] = dg;
+  const int c = b - N * G;
+  float db = 0.f, dg = 0.f;
+  for (int r = threadIdx.x; r < N * S; r += blockDim.x) {
+    db += cpart[(long)r * 2 * C + c];
+    dg += cpart[(long)r * 2 * C + C + c];
+  }
+  db = block_sum(db, sh);
+  dg = block_sum(dg, sh);
+  if (threadIdx.x == 0) {
+    dbeta[c] = db;
+    dgamma[c] = dg;
   }
 }
 
@@ -316,18 +325,52 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 }
 
 // ---- column reductions over a [R, C] matrix ------------------------------------------
-// mode 0: sum x ; mode 1: sum x*y ; mode 2: sum x^2.  Two-stage, deterministic.
+// mode 0: sum x ; mode 1: sum x*y ; mode 2: sum x^2 ; mode 3: sum |x|.  Two-stage, deterministic.
 __global__ __launch_bounds__(256) void colreduce_part_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               float* __restrict__ part, long R, int C, int mode,
                                                               long rows_per_block) {
+  // thread = (column-quad, row-lane): float4 loads along C, 4 independent row streams per thread, LDS combine
+  __shared__ float4 sh[256];
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) {
-      const float v = x[r * C + c];
-      s += mode == 0 ? v : mode == 1 ? v * y[r * C + c] : v * v;
+  const int C4 = (C + 3) >> 2;
+  const int qpb = min(C4, 64);             // column quads per block
+  const int lanes = 256 / qpb;             // row lanes per block
+  const int q = blockIdx.x * qpb + (threadIdx.x % qpb);
+  const int rl = threadIdx.x / qpb;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool vec = (C & 3) == 0;
+  if (q < C4 && rl < lanes) {
+    for (long r = r0 + rl; r < r1; r += lanes) {
+      float4 v, w = make_float4(0.f, 0.f, 0.f, 0.f);
+      const long off = r * C + (long)q * 4;
+      if (vec) {
+        v = *(const float4*)(x + off);
+        if (mode == 1) w = *(const float4*)(y + off);
+      } else {
+        const int c = q * 4;
+        v.x = x[off]; v.y = c + 1 < C ? x[off + 1] : 0.f; v.z = c + 2 < C ? x[off + 2] : 0.f; v.w = c + 3 < C ? x[off + 3] : 0.f;
+        if (mode == 1) { w.x = y[off]; w.y = c + 1 < C ? y[off + 1] : 0.f; w.z = c + 2 < C ? y[off + 2] : 0.f; w.w = c + 3 < C ? y[off + 3] : 0.f; }
+      }
+      if (mode == 0) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      else if (mode == 1) { acc.x += v.x * w.x; acc.y += v.y * w.y; acc.z += v.z * w.z; acc.w += v.w * w.w; }
+      else if (mode == 2) { acc.x += v.x * v.x; acc.y += v.y * v.y; acc.z += v.z * v.z; acc.w += v.w * v.w; }
+      else { acc.x += fabsf(v.x); acc.y += fabsf(v.y); acc.z += fabsf(v.z); acc.w += fabsf(v.w); }
     }
-    part[(long)blockIdx.y * C + c] = s;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0 && q < C4) {
+    float4 s = sh[threadIdx.x];
+    for (int l = 1; l < lanes; ++l) {
+      const float4 t = sh[threadIdx.x + l * qpb];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const int c = q * 4;
+    float* o = part + (long)blockIdx.y * C + c;
+    o[0] = s.x;
+    if (c + 1 < C) o[1] = s.y;
+    if (c + 2 < C) o[2] = s.z;
+    if (c + 3 < C) o[3] = s.w;
   }
 }
 __global__ void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int P,
@@ -450,9 +493,8 @@ INDM_API int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(S, N), dim3(256), (2 * (256 / (C / 4)) * C + 2 * C) * sizeof(float), st, dy, x, gamma,
                      beta, mean, rstd, gpart, cpart, HW, C, G, S, act, drop_p, (uint64_t)seed);
   INDM_CHECK_LAUNCH();
-  const int nfin = N * G > C ? N * G : C;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(nfin, 256)), dim3(256), 0, st, gpart, cpart, gsum, dgamma,
-                     dbeta, N, C, G, S);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N * G + C), dim3(256), 0, st, gpart, cpart, gsum, dgamma, dbeta, N, C,
+                     G, S);
   INDM_CHECK_LAUNCH();
   const long total4 = (long)N * HW * C / 4;
   const float inv_cnt = 1.f / ((float)HW * (float)(C / G));
@@ -480,22 +522,27 @@ INDM_API int indm_softmax_bwd_f32(const float* dy, const float* y, float* dx, lo
   return INDM_OK;
 }
 
-INDM_API long indm_colreduce_ws_floats(long R, int C) {
-  long P = (R + 255) / 256;
-  if (P > 512) P = 512;
+static long colreduce_parts(long R, int C) {
+  // enough row-blocks to fill the chip (~2048 workgroups with the column blocks), at most 256 partial rows
+  const int C4 = (C + 3) / 4;
+  const int cb = (C4 + 63) / 64;
+  long P = 2048 / cb;
+  if (P > 256) P = 256;
+  const long maxp = (R + 63) / 64;
+  if (P > maxp) P = maxp;
   if (P < 1) P = 1;
-  return P * C;
+  return P;
 }
+INDM_API long indm_colreduce_ws_floats(long R, int C) { return colreduce_parts(R, C) * C; }
 // out[c] = alpha * sum_r f(x[r,c], y[r,c]) + beta*out[c]; mode 0: x, 1: x*y, 2: x*x
 INDM_API int indm_colreduce_f32(const float* x, const float* y, float* out, long R, int C, int mode, float alpha,
                                 float beta, float* ws, void* stream) {
   if (C <= 0) return INDM_OK;
   hipStream_t st = (hipStream_t)stream;
-  long P = (R + 255) / 256;
-  if (P > 512) P = 512;
-  if (P < 1) P = 1;
+  const long P = colreduce_parts(R, C);
   const long rpb = (R + P - 1) / P;
-  hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C, 256), (int)P), dim3(256), 0, st, x, y, ws, R, C, mode, rpb);
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C4, 64), (int)P), dim3(256), 0, st, x, y, ws, R, C, mode, rpb);
   INDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, ws, out, C, (int)P, alpha, beta);
   INDM_CHECK_LAUNCH();

@@ -13,7 +13,7 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libindm_hip.so")
+_LIB_PATH = os.environ.get("INDM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libindm_hip.so")
 _lib = None
 
 c_f = ctypes.c_float
@@ -67,6 +67,8 @@ _SIGS = {
     "indm_sqnorm_ws_floats": [],
     "indm_sqnorm_f32": [c_p, c_l, c_p, c_p, c_p],
     "indm_adamw_ema_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p, c_f, c_f, c_p],
+    "indm_tap_gather_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "indm_tap_spread_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "indm_fixed_point_check_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p, c_p],
     "indm_ema_update_f32": [c_p, c_p, c_l, c_f, c_p],
     "indm_slogdet_inv_f32": [c_p, c_i, c_p, c_p, c_p],
@@ -221,6 +223,28 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     return out
 
 
+def _skinny(kh, kw, stride, pad, c_small, c_wide):
+    return kh == 3 and kw == 3 and stride == 1 and pad == 1 and c_small <= 16 and c_wide >= 64
+
+
+def tap_gather(P, bias, sign, alpha=1.0):
+    """y[n,h,w,c] = alpha*(sum_taps P[n, h+s(kh-1), w+s(kw-1), tap*C+c] + bias[c]);  P: [N,H,W,9C]."""
+    N, H, W, C9 = P.shape
+    C = C9 // 9
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=P.device)
+    _chk(lib().indm_tap_gather_f32(_ptr(P), _ptr(bias), _ptr(y), N, H, W, C, sign, alpha, _stream()),
+         "indm_tap_gather_f32")
+    return y
+
+
+def tap_spread(y, sign, alpha=1.0):
+    """Adjoint of tap_gather: P[n,h,w,tap*C+c] = alpha*y[n, h-s(kh-1), w-s(kw-1), c]."""
+    N, H, W, C = y.shape
+    P = torch.empty((N, H, W, 9 * C), dtype=torch.float32, device=y.device)
+    _chk(lib().indm_tap_spread_f32(_ptr(y), _ptr(P), N, H, W, C, sign, alpha, _stream()), "indm_tap_spread_f32")
+    return P
+
+
 def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
@@ -231,6 +255,19 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
     KH, KW, Ci2, Co = w.shape
     if Ci != Ci2:
         raise RuntimeError("conv2d: channel mismatch")
+    if _skinny(KH, KW, stride, pad, Co, Ci) and bias2 is None and res is None:
+        # 3x3 conv with a skinny output (flow edges 512 -> 3 / 12): one MFMA GEMM with N = 9*Co + a tap gather
+        wr = w.permute(2, 0, 1, 3).reshape(Ci, 9 * Co).contiguous()
+        P = gemm(x.reshape(-1, Ci), wr)
+        return tap_gather(P.view(N, H, W, 9 * Co), bias, 1, alpha)
+    if _skinny(KH, KW, stride, pad, Ci, Co):
+        # skinny INPUT (flow edges 3 / 12 -> 512): spread x over the 9 taps (a [pixels, 9*Ci] panel, a few MB) and
+        # run one plain MFMA GEMM; keeps every epilogue fusion of the GEMM
+        xcol = tap_spread(x, -1)
+        r = res.reshape(-1, Co) if res is not None else None
+        y2 = gemm(xcol.reshape(-1, 9 * Ci), w.reshape(9 * Ci, Co), alpha=alpha, bias=bias, bias2=bias2,
+                  rows_per_group=H * W, res=r, beta=beta)
+        return y2.view(N, H, W, Co)
     OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
     y = torch.empty((N, OH, OW, Co), dtype=torch.float32, device=x.device)
     with _timed("A_CONV", "B_ROW", N * OH * OW, Co, KH * KW * Ci):
@@ -248,6 +285,16 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0):
     if Co != Co2:
         raise RuntimeError("conv2d_dgrad: channel mismatch")
     H, W = in_hw
+    if _skinny(KH, KW, stride, pad, Ci, Co) and res is None:
+        # transposed 3x3 conv with a skinny output: P = dy @ w[(tap,ci), co]^T, then gather with flipped shifts
+        P = gemm(dy.reshape(-1, Co), w.reshape(9 * Ci, Co), trans_b=True)
+        return tap_gather(P.view(N, H, W, 9 * Ci), None, -1, alpha)
+    if _skinny(KH, KW, stride, pad, Co, Ci):
+        # transposed conv with a skinny INPUT dy: spread dy (+1), then [pixels, 9*Co] x [(tap,co), ci]
+        dycol = tap_spread(dy, 1)
+        wt = w.permute(0, 1, 3, 2).reshape(9 * Co, Ci).contiguous()
+        r = res.reshape(-1, Ci) if res is not None else None
+        return gemm(dycol.reshape(-1, 9 * Co), wt, alpha=alpha, res=r, beta=beta).view(N, H, W, Ci)
     dx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=dy.device)
     with _timed("A_CONV", "B_DGRAD", N * H * W, Ci, KH * KW * Co):
         st = lib().indm_conv2d_dgrad_f32(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride,
@@ -260,6 +307,16 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
     """Gradient of conv2d w.r.t. its RSCK weight. x [N,H,W,Ci], dy [N,OH,OW,Co] -> [KH,KW,Ci,Co]."""
     N, H, W, Ci = x.shape
     _, OH, OW, Co = dy.shape
+    if _skinny(kh, kw, stride, pad, Co, Ci):
+        # weight grad with a skinny dy: spread dy over the 9 taps, then one [Ci x pixels] x [pixels x 9*Co] GEMM
+        dycol = tap_spread(dy, 1, alpha)
+        q = gemm(x.reshape(-1, Ci), dycol.reshape(-1, 9 * Co), trans_a=True, splitk=True)
+        return q.view(Ci, 3, 3, Co).permute(1, 2, 0, 3).contiguous()
+    if _skinny(kh, kw, stride, pad, Ci, Co):
+        # weight grad with a skinny x: xcol^T [9*Ci x pixels] x dy [pixels x Co] is already RSCK
+        xcol = tap_spread(x, -1)
+        return gemm(xcol.reshape(-1, 9 * Ci), dy.reshape(-1, Co), trans_a=True, alpha=alpha,
+                    splitk=True).view(3, 3, Ci, Co)
     dw = torch.empty((kh, kw, Ci, Co), dtype=torch.float32, device=x.device)
     ws = _ws(SPLITK_WS_FLOATS, x.device)
     with _timed("A_WGRAD", "B_ROW", kh * kw * Ci, Co, N * OH * OW):

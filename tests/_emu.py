@@ -28,6 +28,32 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     return out.contiguous()
 
 
+def tap_gather(P, bias, sign, alpha=1.0):
+    N, H, W, C9 = P.shape
+    C = C9 // 9
+    Pp = F.pad(P, (0, 0, 1, 1, 1, 1))
+    acc = torch.zeros((N, H, W, C), dtype=P.dtype)
+    for kh in range(3):
+        for kw in range(3):
+            dh, dw = sign * (kh - 1), sign * (kw - 1)
+            t = kh * 3 + kw
+            acc = acc + Pp[:, 1 + dh:1 + dh + H, 1 + dw:1 + dw + W, t * C:(t + 1) * C]
+    if bias is not None:
+        acc = acc + bias
+    return alpha * acc
+
+
+def tap_spread(y, sign, alpha=1.0):
+    N, H, W, C = y.shape
+    yp = F.pad(y, (0, 0, 1, 1, 1, 1))
+    outs = []
+    for kh in range(3):
+        for kw in range(3):
+            dh, dw = -sign * (kh - 1), -sign * (kw - 1)
+            outs.append(yp[:, 1 + dh:1 + dh + H, 1 + dw:1 + dw + W, :])
+    return alpha * torch.cat(outs, dim=-1).contiguous()
+
+
 def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 

@@ -70,8 +70,11 @@ CONV_CASES = [
     (3, 8, 8, 128, 128, 3, 1, 1),
     (2, 32, 32, 3, 64, 3, 1, 1),      # first conv / flow 3->512 style (scalar A path)
     (2, 16, 16, 12, 48, 3, 1, 1),
-    (2, 16, 16, 64, 3, 3, 1, 1),      # 512->3 style (skinny N, scalar B path)
+    (2, 16, 16, 64, 3, 3, 1, 1),      # 512->3 style: GEMM(N=9*Co) + tap-gather path
     (2, 16, 16, 64, 12, 3, 1, 1),
+    (2, 16, 16, 3, 64, 3, 1, 1),      # 3->512 style: its data-grad takes the skinny transposed path
+    (2, 16, 16, 12, 64, 3, 1, 1),
+    (2, 16, 16, 32, 3, 3, 1, 1),      # narrow wide-side: stays on the direct implicit GEMM (128x32 tiles)
     (2, 16, 16, 48, 96, 3, 2, 1),     # encoder stride-2
     (2, 16, 16, 48, 96, 1, 2, 0),     # encoder 1x1 stride-2 shortcut
     (2, 17, 17, 16, 32, 3, 2, 0),     # VE conv_downsample_2d: FIR-padded 17x17 -> 8x8
@@ -91,6 +94,21 @@ def test_conv2d_fwd_dgrad_wgrad(N, H, W, Ci, Co, k, s, p):
     close(out, r2, rtol=1e-5, atol=1e-4, name="conv dgrad")
     out, r3 = run_both("conv2d_wgrad", x, dy, k, k, stride=s, pad=p)
     close(out, r3, rtol=1e-5, atol=2e-4, name="conv wgrad")
+
+
+def test_tap_gather_spread():
+    P = rnd(2, 6, 5, 27)
+    bias = rnd(3, seed=1)
+    for sign in (1, -1):
+        o, r = run_both("tap_gather", P, bias, sign, 0.5)
+        close(o, r, name="tap_gather")
+        y = rnd(2, 6, 5, 3, seed=2)
+        o, r = run_both("tap_spread", y, sign, 2.0)
+        close(o, r, name="tap_spread")
+        # adjointness <gather(P), y> == <P, spread(y)>
+        a = (_emu.tap_gather(P.double(), None, sign) * y.double()).sum()
+        b = (P.double() * _emu.tap_spread(y.double(), sign)).sum()
+        assert abs(float(a - b)) < 1e-9
 
 
 def test_conv2d_big_wgrad_splitk():
