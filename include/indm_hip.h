@@ -43,11 +43,14 @@ int indm_fused_bias_act_f32(const float* x, const float* bias, const float* ref,
 
 /* ---- dense contractions (fp32 MFMA implicit-GEMM engine) ----------------------------------------------- */
 
-/* C[b] = alpha*(opA(A[b]) opB(B[b]) + bias[n] + bias2[m/rows_per_group][n]) + beta*R[b].
+/* C[b] = alpha*(opA(A[b] .* gateA[b]) opB(B[b]) + bias[n] + bias2[m/rows_per_group][n]) + beta*R[b].
+ * gateA (optional, A's layout) is multiplied into A inside the operand loader: the cos(2 pi p) gates of the explicit
+ * vector-Jacobian chain (iresblock.py:253-273) never make a round trip through HBM.
  * Replaces ATen matmul/linear/einsum call sites: NIN models/layers.py:546-556, Dense models/layerspp.py:239-261,
  * attention einsums models/layerspp.py:95-99, LopCondConv2d 1x1 lipschitz.py:429-435, NICEMLPBlock blocks.py:36-43.
  * transA: A stored [K,M]; transB: B stored [N,K].  ws/ws_floats: optional split-K scratch (NULL = no split-K). */
-int indm_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int transA, int transB, long lda,
+int indm_gemm_f32(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
+                  int transB, long lda,
                   long ldb, long ldc, int batch, long strideA, long strideB, long strideC, float alpha,
                   const float* bias, const float* bias2, int rows_per_group, const float* R, long ldr,
                   long strideR, float beta, float* ws, long ws_floats, void* stream);
@@ -57,14 +60,14 @@ int indm_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K,
  * conv_downsample_2d up_or_down_sampling.py:178.  in_dil > 1 treats x as zero-inserted. */
 int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int Nimg, int H, int W, int Cin, int Cout, int KH,
                         int KW, int stride, int pad, int in_dil, int OH, int OW, float alpha, const float* bias,
-                        const float* bias2, const float* R, float beta, void* stream);
+                        const float* bias2, const float* R, float beta, float* ws, long ws_floats, void* stream);
 
 /* dx = alpha * conv_transpose(dy, w) + beta*R: the data gradient of indm_conv2d_fwd_f32 (autograd of F.conv2d in
  * the reference) and, as a forward op, the explicit vector-Jacobian product of the residual-flow g-net that
  * replaces torch.autograd.grad(g, x, v) at iresblock.py:257,269-271.  pad_t = K-1-pad_fwd, in_dil = fwd stride. */
 int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, int H, int W, int Cin, int Cout,
                           int KH, int KW, int pad_t, int in_dil, int OH, int OW, float alpha, const float* R,
-                          float beta, void* stream);
+                          float beta, float* ws, long ws_floats, void* stream);
 
 /* dw[kh,kw,ci,co] = alpha * sum_pixels x * dy (+ beta*R): weight gradient of the convolution (autograd of
  * F.conv2d); the pixel reduction is split-K into ws. */

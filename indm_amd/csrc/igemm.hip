@@ -20,7 +20,7 @@
 namespace {
 
 #ifndef INDM_BK
-#define INDM_BK 32
+#define INDM_BK 16
 #endif
 constexpr int BK = INDM_BK;
 
@@ -29,6 +29,7 @@ enum { B_ROW = 0, B_COL = 1, B_DGRAD = 2 };
 
 struct IgemmParams {
   const float* A;
+  const float* G;  // optional elementwise gate on A (same layout): Aeff = A .* G (VJP chains of the flow)
   const float* B;
   float* C;
   int M, N, K;
@@ -114,21 +115,47 @@ __device__ __forceinline__ float b_elem(const IgemmParams& p, const float* B, in
 // ---- vectorised group loads -------------------------------------------------
 // K-contiguous group: (row, k..k+3).  Row-contiguous group: (row..row+3, k).
 template <int AM>
-__device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, int row, int k, int kend,
-                                          const PixDec& rowdec, const int3& tapdec, int kbase) {
+__device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, const float* G, int row, int k,
+                                          int kend, const PixDec& rowdec, const int3& tapdec, int kbase) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (AM == A_ROW) {
-    if (p.a_vec && row < p.M && k + 3 < kend) return *(const float4*)(A + (long)row * p.lda + k);
+    if (p.a_vec && row < p.M && k + 3 < kend) {
+      v = *(const float4*)(A + (long)row * p.lda + k);
+      if (G) {
+        const float4 g = *(const float4*)(G + (long)row * p.lda + k);
+        v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+      }
+      return v;
+    }
     v.x = a_elem<AM>(p, A, row, k, kend);
     v.y = a_elem<AM>(p, A, row, k + 1, kend);
     v.z = a_elem<AM>(p, A, row, k + 2, kend);
     v.w = a_elem<AM>(p, A, row, k + 3, kend);
+    if (G) {
+      v.x *= a_elem<AM>(p, G, row, k, kend);
+      v.y *= a_elem<AM>(p, G, row, k + 1, kend);
+      v.z *= a_elem<AM>(p, G, row, k + 2, kend);
+      v.w *= a_elem<AM>(p, G, row, k + 3, kend);
+    }
   } else if constexpr (AM == A_COL) {
-    if (p.a_vec && k < kend && row + 3 < p.M) return *(const float4*)(A + (long)k * p.lda + row);
+    if (p.a_vec && k < kend && row + 3 < p.M) {
+      v = *(const float4*)(A + (long)k * p.lda + row);
+      if (G) {
+        const float4 g = *(const float4*)(G + (long)k * p.lda + row);
+        v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+      }
+      return v;
+    }
     v.x = a_elem<AM>(p, A, row, k, kend);
     v.y = a_elem<AM>(p, A, row + 1, k, kend);
     v.z = a_elem<AM>(p, A, row + 2, k, kend);
     v.w = a_elem<AM>(p, A, row + 3, k, kend);
+    if (G) {
+      v.x *= a_elem<AM>(p, G, row, k, kend);
+      v.y *= a_elem<AM>(p, G, row + 1, k, kend);
+      v.z *= a_elem<AM>(p, G, row + 2, k, kend);
+      v.w *= a_elem<AM>(p, G, row + 3, k, kend);
+    }
   } else if constexpr (AM == A_CONV) {
     if (p.a_vec) {
       if (row >= p.M || k >= kend) return v;
@@ -225,11 +252,22 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 template <int AM, int BMODE, int TM, int TN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
+#ifndef INDM_WPE
+#define INDM_WPE 1
+#endif
+__global__ __launch_bounds__(256, INDM_WPE) void igemm_kernel(IgemmParams p) {
   constexpr int RM = TM / WAVES_M / 32, RN = TN / WAVES_N / 32;
+#if 1
+  // row-contiguous operands: +4 padding keeps every [k][row] slab row 16-byte aligned -> one ds_write_b128 per
+  // float4; k-contiguous operands keep +2 (conflict-free transposing ds_write_b32)
+  constexpr int LDA_S = TM + (a_kcontig<AM>() ? 2 : 4), LDB_S = TN + (b_kcontig<BMODE>() ? 2 : 4);
+#else
   constexpr int LDA_S = TM + 2, LDB_S = TN + 2;
-  constexpr int NGA = (TM * 4 + 255) / 256, NGB = (TN * 4 + 255) / 256;
-  __shared__ float smem[2 * BK * (LDA_S + LDB_S)];
+#endif
+  constexpr int KG = BK / 4;  // float4 groups along K per row
+  constexpr int GA = TM * KG, GB = TN * KG;  // float4 groups per operand slab
+  constexpr int NGA = (GA + 255) / 256, NGB = (GB + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA_S + LDB_S)];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDA_S;
 
@@ -242,6 +280,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
   const int z = blockIdx.y;
   const int bz = z / p.splitk, kz = z - bz * p.splitk;
   const float* A = p.A + (long)bz * p.sA;
+  const float* G = p.G ? p.G + (long)bz * p.sA : nullptr;
   const float* B = p.B + (long)bz * p.sB;
   const int kbeg = kz * p.kps;
   const int kend = min(p.K, kbeg + p.kps);
@@ -264,12 +303,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     const int g = tid + j * 256;
     rowdec[j].img = rowdec[j].oh = rowdec[j].ow = 0;
     if constexpr (AM == A_CONV) {
-      const int row = m0 + (g >> 2);
-      if (g < TM * 4 && row < p.M) rowdec[j] = decode_pix(row, p.OH, p.OW);
+      const int row = m0 + g / KG;
+      if (g < GA && row < p.M) rowdec[j] = decode_pix(row, p.OH, p.OW);
     } else if constexpr (AM == A_WGRAD) {
       constexpr int Q = TM / 4;
       const int row = m0 + (g % Q) * 4;
-      if (g < TM * 4 && row < p.M) {
+      if (g < GA && row < p.M) {
         const int tap = row / p.Cin;
         rowdec[j].ow = row - tap * p.Cin;       // ci
         rowdec[j].img = tap / p.KW;             // kh
@@ -299,21 +338,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NGA; ++j) {
       const int g = tid + j * 256;
-      if (g < TM * 4) {
+      if (g < GA) {
         if constexpr (a_kcontig<AM>()) {
-          ra[j] = a_group<AM>(p, A, m0 + (g >> 2), k0 + (g & 3) * 4, kend, rowdec[j], tapdec, k0);
+          ra[j] = a_group<AM>(p, A, G, m0 + g / KG, k0 + (g % KG) * 4, kend, rowdec[j], tapdec, k0);
         } else {
           constexpr int Q = TM / 4;
-          ra[j] = a_group<AM>(p, A, m0 + (g % Q) * 4, k0 + g / Q, kend, rowdec[j], tapdec, k0);
+          ra[j] = a_group<AM>(p, A, G, m0 + (g % Q) * 4, k0 + g / Q, kend, rowdec[j], tapdec, k0);
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < NGB; ++j) {
       const int g = tid + j * 256;
-      if (g < TN * 4) {
+      if (g < GB) {
         if constexpr (b_kcontig<BMODE>()) {
-          rb[j] = b_group<BMODE>(p, B, n0 + (g >> 2), k0 + (g & 3) * 4, kend, btap, k0);
+          rb[j] = b_group<BMODE>(p, B, n0 + g / KG, k0 + (g % KG) * 4, kend, btap, k0);
         } else {
           constexpr int Q = TN / 4;
           rb[j] = b_group<BMODE>(p, B, n0 + (g % Q) * 4, k0 + g / Q, kend, btap, k0);
@@ -327,9 +366,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NGA; ++j) {
       const int g = tid + j * 256;
-      if (g < TM * 4) {
+      if (g < GA) {
         if constexpr (a_kcontig<AM>()) {
-          const int row = g >> 2, k4 = (g & 3) * 4;
+          const int row = g / KG, k4 = (g % KG) * 4;
           as[(k4 + 0) * LDA_S + row] = ra[j].x;
           as[(k4 + 1) * LDA_S + row] = ra[j].y;
           as[(k4 + 2) * LDA_S + row] = ra[j].z;
@@ -337,18 +376,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         } else {
           constexpr int Q = TM / 4;
           const int k = g / Q, row = (g % Q) * 4;
+#if 1
+          *(float4*)(as + k * LDA_S + row) = ra[j];
+#else
           float2* d = (float2*)(as + k * LDA_S + row);
           d[0] = make_float2(ra[j].x, ra[j].y);
           d[1] = make_float2(ra[j].z, ra[j].w);
+#endif
         }
       }
     }
 #pragma unroll
     for (int j = 0; j < NGB; ++j) {
       const int g = tid + j * 256;
-      if (g < TN * 4) {
+      if (g < GB) {
         if constexpr (b_kcontig<BMODE>()) {
-          const int row = g >> 2, k4 = (g & 3) * 4;
+          const int row = g / KG, k4 = (g % KG) * 4;
           bs[(k4 + 0) * LDB_S + row] = rb[j].x;
           bs[(k4 + 1) * LDB_S + row] = rb[j].y;
           bs[(k4 + 2) * LDB_S + row] = rb[j].z;
@@ -356,9 +399,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
         } else {
           constexpr int Q = TN / 4;
           const int k = g / Q, row = (g % Q) * 4;
+#if 1
+          *(float4*)(bs + k * LDB_S + row) = rb[j];
+#else
           float2* d = (float2*)(bs + k * LDB_S + row);
           d[0] = make_float2(rb[j].x, rb[j].y);
           d[1] = make_float2(rb[j].z, rb[j].w);
+#endif
         }
       }
     }
@@ -378,19 +425,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmParams p) {
     if (kt + 1 < nk) gload(kt + 1);
     const float* as = As + buf * BK * LDA_S + mw + l31;
     const float* bs = Bs + buf * BK * LDB_S + nw + l31;
+    // software-pipelined fragment reads: the ds_reads of k-pair kk+1 are in flight while the MFMAs of kk issue
+    float a[2][RM], b[2][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) a[0][i] = as[lhi * LDA_S + i * 32];
+#pragma unroll
+    for (int j = 0; j < RN; ++j) b[0][j] = bs[lhi * LDB_S + j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      const int k = kk * 2 + lhi;
-      float a[RM], b[RN];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 2) {
+        const int k = (kk + 1) * 2 + lhi;
 #pragma unroll
-      for (int i = 0; i < RM; ++i) a[i] = as[k * LDA_S + i * 32];
+        for (int i = 0; i < RM; ++i) a[nxt][i] = as[k * LDA_S + i * 32];
 #pragma unroll
-      for (int j = 0; j < RN; ++j) b[j] = bs[k * LDB_S + j * 32];
+        for (int j = 0; j < RN; ++j) b[nxt][j] = bs[k * LDB_S + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < RM; ++i)
 #pragma unroll
         for (int j = 0; j < RN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      // pin the interleave: next k-pair's LDS reads first, then this k-pair's MFMAs (the LLVM scheduler otherwise
+      // sinks the reads to just before their use and exposes the LDS latency every 4 MFMAs)
+      if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, RM + RN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, RM * RN, 0);
     }
     if (kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
@@ -476,7 +535,7 @@ inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 int choose_splitk(int M, int N, int K, int batch, long ws_floats) {
   long tiles = (long)cdiv(M, (N <= 32 && M > 32) ? 128 : (M <= 32 ? 32 : 128)) *
                cdiv(N, (N <= 32 && M > 32) ? 32 : 128) * batch;
-  if (tiles >= 512 || K < 4 * BK * 8) return 1;
+  if (tiles >= 256 || K < 4 * BK * 8) return 1;
   long want = (1024 + tiles - 1) / tiles;
   long maxs = K / (BK * 8);
   if (want > maxs) want = maxs;
@@ -513,23 +572,23 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
 // C ABI (declared in include/indm_hip.h)
 // ---------------------------------------------------------------------------
 
-// C[b] = alpha * (opA(A[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]
+// C[b] = alpha * (opA(A[b] .* gateA[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]   (gateA optional)
 //   transA == 0: A is [M,K] row-major (lda);  transA == 1: A is stored [K,M] (lda)
 //   transB == 0: B is [K,N] row-major (ldb);  transB == 1: B is stored [N,K] (ldb)
-INDM_API int indm_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int transA,
+INDM_API int indm_gemm_f32(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
                            int transB, long lda, long ldb, long ldc, int batch, long strideA,
                            long strideB, long strideC, float alpha, const float* bias,
                            const float* bias2, int rows_per_group, const float* R, long ldr,
                            long strideR, float beta, float* ws, long ws_floats, void* stream) {
   if (M < 0 || N < 0 || K < 0 || batch < 0) return INDM_E_SHAPE;
   IgemmParams p = {};
-  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.A = A; p.G = gateA; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
   p.alpha = alpha; p.beta = beta; p.bias = bias; p.bias2 = bias2;
   p.rpg = rows_per_group > 0 ? rows_per_group : 1;
   p.R = R; p.ldr = ldr; p.sR = strideR;
-  p.a_vec = al16(A) && (lda % 4 == 0) && (strideA % 4 == 0);
+  p.a_vec = al16(A) && al16(gateA) && (lda % 4 == 0) && (strideA % 4 == 0);
   p.b_vec = al16(B) && (ldb % 4 == 0) && (strideB % 4 == 0);
   return run(p, transA ? A_COL : A_ROW, transB ? B_COL : B_ROW, ws, ws_floats, (hipStream_t)stream);
 }
@@ -540,7 +599,7 @@ INDM_API int indm_gemm_f32(const float* A, const float* B, float* C, int M, int 
 INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int Nimg, int H, int W,
                                  int Cin, int Cout, int KH, int KW, int stride, int pad, int in_dil,
                                  int OH, int OW, float alpha, const float* bias, const float* bias2,
-                                 const float* R, float beta, void* stream) {
+                                 const float* R, float beta, float* ws, long ws_floats, void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return INDM_E_SHAPE;
   IgemmParams p = {};
   p.A = x; p.B = w; p.C = y;
@@ -553,7 +612,7 @@ INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int N
   p.a_vec = al16(x) && (Cin % 4 == 0);
   p.b_vec = al16(w) && (Cout % 4 == 0);
   p.a_tap_uniform = (Cin % BK == 0);
-  return run(p, A_CONV, B_ROW, nullptr, 0, (hipStream_t)stream);
+  return run(p, A_CONV, B_ROW, ws, ws_floats, (hipStream_t)stream);
 }
 
 // Data-grad of a stride-1 convolution (and, with in_dil = forward stride, of a strided one):
@@ -561,7 +620,8 @@ INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int N
 // dy: [Nimg,H,W,Cout] (H,W = dy spatial), dx: [Nimg,OH,OW,Cin].  pad' = K-1-pad_fwd.
 INDM_API int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, int H, int W,
                                    int Cin, int Cout, int KH, int KW, int pad_t, int in_dil, int OH,
-                                   int OW, float alpha, const float* R, float beta, void* stream) {
+                                   int OW, float alpha, const float* R, float beta, float* ws, long ws_floats,
+                                   void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return INDM_E_SHAPE;
   IgemmParams p = {};
   p.A = dy; p.B = w; p.C = dx;
@@ -573,7 +633,7 @@ INDM_API int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, i
   p.a_vec = al16(dy) && (Cout % 4 == 0);
   p.b_vec = al16(w) && (Cout % 4 == 0);
   p.a_tap_uniform = p.b_tap_uniform = (Cout % BK == 0);
-  return run(p, A_CONV, B_DGRAD, nullptr, 0, (hipStream_t)stream);
+  return run(p, A_CONV, B_DGRAD, ws, ws_floats, (hipStream_t)stream);
 }
 
 // Weight-grad: dw[kh,kw,ci,co] = alpha * sum_{n,oh,ow} x[n, oh*s+kh-p, ow*s+kw-p, ci] * dy[n,oh,ow,co]

@@ -373,13 +373,22 @@ __global__ __launch_bounds__(256) void colreduce_part_kernel(const float* __rest
     if (c + 3 < C) o[3] = s.w;
   }
 }
-__global__ void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int P,
-                                       float alpha, float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 64 columns x 4 partial-lanes; fixed combination order -> deterministic
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C,
+                                                               int P, float alpha, float beta) {
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int l = threadIdx.x >> 6;
   float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(long)p * C + c];
-  out[c] = alpha * s + (beta != 0.f ? beta * out[c] : 0.f);
+  if (c < C)
+    for (int p = l; p < P; p += 4) s += part[(long)p * C + c];
+  sh[l][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (l == 0 && c < C) {
+    const int t = threadIdx.x & 63;
+    const float r = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+    out[c] = alpha * r + (beta != 0.f ? beta * out[c] : 0.f);
+  }
 }
 
 // ---- BatchNorm2d (training-mode batch statistics) + optional ELU, rows = N*H*W, NHWC ----------
@@ -544,7 +553,7 @@ INDM_API int indm_colreduce_f32(const float* x, const float* y, float* out, long
   const int C4 = (C + 3) / 4;
   hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C4, 64), (int)P), dim3(256), 0, st, x, y, ws, R, C, mode, rpb);
   INDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, ws, out, C, (int)P, alpha, beta);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, out, C, (int)P, alpha, beta);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

@@ -111,10 +111,8 @@ class IResBlock(nn.Module):
         W1, W2, W3 = W
         d0, d1, d2 = gates
         t = ops.conv2d_t(v, W3, hw)
-        t = ops.mul(t, d2)
-        t = ops.conv1x1_t(t, W2)
-        t = ops.mul(t, d1)
-        t = ops.conv2d_t(t, W1, hw)
+        t = ops.conv1x1_t(t, W2, gate=d2)       # (t .* d2) @ W2^T : the cos gate rides on the GEMM's A loader
+        t = ops.conv2d_t(t, W1, hw, gate=d1)    # (t .* d1) through the transposed 3x3
         if d0 is not None:
             t = ops.mul(t, d0)
         return t

@@ -26,12 +26,12 @@ ERRORS = {-1: "INDM_E_SHAPE", -2: "INDM_E_DTYPE", -3: "INDM_E_LAUNCH", -4: "INDM
 
 # name -> argtypes (restype is int unless listed in _LONG_RET)
 _SIGS = {
-    "indm_gemm_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_l, c_l, c_l, c_f, c_p, c_p,
+    "indm_gemm_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_l, c_l, c_l, c_f, c_p, c_p,
                       c_i, c_p, c_l, c_l, c_f, c_p, c_l, c_p],
     "indm_conv2d_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
-                            c_p, c_p, c_f, c_p],
+                            c_p, c_p, c_f, c_p, c_l, c_p],
     "indm_conv2d_dgrad_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
-                              c_p],
+                              c_p, c_l, c_p],
     "indm_conv2d_wgrad_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
                               c_p, c_l, c_p],
     "indm_groupnorm_ws_floats": [c_i, c_i, c_i, c_i],
@@ -195,8 +195,9 @@ class _timed:
 
 # --------------------------------------------------------------------------- GEMM / conv
 def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, rows_per_group=1, res=None,
-         beta=1.0, splitk=False):
-    """C[(batch),M,N] = alpha * (op(a) @ op(b) + bias[N] + bias2[M//rows_per_group, N]) + beta*res.
+         beta=1.0, splitk=False, gate=None):
+    """C[(batch),M,N] = alpha * (op(a * gate) @ op(b) + bias[N] + bias2[M//rows_per_group, N]) + beta*res.
+    gate (optional) has a's shape and multiplies it elementwise inside the operand loader.
 
     a: [..,M,K] (or stored [..,K,M] when trans_a); b: [..,K,N] (or stored [..,N,K] when trans_b).
     2-D operands broadcast over the batch of the other one.
@@ -215,7 +216,7 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     sB = b.shape[-1] * b.shape[-2] if b.dim() == 3 else 0
     ws = _ws(SPLITK_WS_FLOATS, a.device) if splitk else None
     with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch):
-        st = lib().indm_gemm_f32(_ptr(a), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
+        st = lib().indm_gemm_f32(_ptr(a), _ptr(gate), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
                                  b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
                                  _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
                                  _ptr(ws), SPLITK_WS_FLOATS if splitk else 0, _stream())
@@ -271,23 +272,28 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
     OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
     y = torch.empty((N, OH, OW, Co), dtype=torch.float32, device=x.device)
     with _timed("A_CONV", "B_ROW", N * OH * OW, Co, KH * KW * Ci):
+        ws = _ws(SPLITK_WS_FLOATS, x.device)
         st = lib().indm_conv2d_fwd_f32(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, KH, KW, stride, pad, 1, OH, OW,
-                                       alpha, _ptr(bias), _ptr(bias2), _ptr(res), beta, _stream())
+                                       alpha, _ptr(bias), _ptr(bias2), _ptr(res), beta, _ptr(ws), SPLITK_WS_FLOATS,
+                                       _stream())
     _chk(st, "indm_conv2d_fwd_f32")
     return y
 
 
-def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0):
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, gate=None):
     """Gradient of conv2d w.r.t. its input (= transposed convolution). dy [N,OH,OW,Co], w [KH,KW,Ci,Co]
-    -> dx [N,H,W,Ci] with (H,W) = in_hw."""
+    -> dx [N,H,W,Ci] with (H,W) = in_hw.  gate (optional, dy's shape): computes with dy*gate."""
     N, OH, OW, Co = dy.shape
+    if gate is not None and not (_skinny(w.shape[0], w.shape[1], stride, pad, w.shape[2], Co) and res is None):
+        dy, gate = mul(dy, gate), None
     KH, KW, Ci, Co2 = w.shape
     if Co != Co2:
         raise RuntimeError("conv2d_dgrad: channel mismatch")
     H, W = in_hw
     if _skinny(KH, KW, stride, pad, Ci, Co) and res is None:
         # transposed 3x3 conv with a skinny output: P = dy @ w[(tap,ci), co]^T, then gather with flipped shifts
-        P = gemm(dy.reshape(-1, Co), w.reshape(9 * Ci, Co), trans_b=True)
+        P = gemm(dy.reshape(-1, Co), w.reshape(9 * Ci, Co), trans_b=True,
+                 gate=None if gate is None else gate.reshape(-1, Co))
         return tap_gather(P.view(N, H, W, 9 * Ci), None, -1, alpha)
     if _skinny(KH, KW, stride, pad, Co, Ci):
         # transposed conv with a skinny INPUT dy: spread dy (+1), then [pixels, 9*Co] x [(tap,co), ci]
@@ -297,8 +303,9 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0):
         return gemm(dycol.reshape(-1, 9 * Co), wt, alpha=alpha, res=r, beta=beta).view(N, H, W, Ci)
     dx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=dy.device)
     with _timed("A_CONV", "B_DGRAD", N * H * W, Ci, KH * KW * Co):
+        ws = _ws(SPLITK_WS_FLOATS, dy.device)
         st = lib().indm_conv2d_dgrad_f32(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride,
-                                         H, W, alpha, _ptr(res), beta, _stream())
+                                         H, W, alpha, _ptr(res), beta, _ptr(ws), SPLITK_WS_FLOATS, _stream())
     _chk(st, "indm_conv2d_dgrad_f32")
     return dx
 

@@ -20,32 +20,39 @@ def _c(t):
 
 # ----------------------------------------------------------------------------- dense contractions
 class _Gemm(Function):
-    """C = alpha*(op(A) op(B) + bias + bias2[row // rpg]) + beta*res"""
+    """C = alpha*(op(A .* G) op(B) + bias + bias2[row // rpg]) + beta*res   (G optional)"""
 
     @staticmethod
-    def forward(ctx, a, b, bias, bias2, res, trans_a, trans_b, alpha, beta, rpg, wgrad_b_splitk):
-        a, b, res = _c(a), _c(b), _c(res)
-        ctx.save_for_backward(a, b)
+    def forward(ctx, a, b, bias, bias2, res, trans_a, trans_b, alpha, beta, rpg, wgrad_b_splitk, gate):
+        a, b, res, gate = _c(a), _c(b), _c(res), _c(gate)
+        ctx.save_for_backward(a, b, gate)
         ctx.cfg = (trans_a, trans_b, alpha, beta, rpg, wgrad_b_splitk, bias is not None, bias2 is not None,
                    res is not None)
-        return hip.gemm(a, b, trans_a, trans_b, alpha, _c(bias), _c(bias2), rpg, res, beta)
+        return hip.gemm(a, b, trans_a, trans_b, alpha, _c(bias), _c(bias2), rpg, res, beta, gate=gate)
 
     @staticmethod
     def backward(ctx, dc):
-        a, b = ctx.saved_tensors
+        a, b, gate = ctx.saved_tensors
         ta, tb, alpha, beta, rpg, sk, has_bias, has_bias2, has_res = ctx.cfg
         dc = _c(dc)
-        da = db = dbias = dbias2 = dres = None
-        if ctx.needs_input_grad[0]:
+        da = db = dbias = dbias2 = dres = dgate = None
+        if ctx.needs_input_grad[0] or (gate is not None and ctx.needs_input_grad[11]):
             if not ta:
-                da = hip.gemm(dc, b, False, not tb, alpha)            # dC op(B)^T
+                dag = hip.gemm(dc, b, False, not tb, alpha)            # dC op(B)^T
             else:
-                da = hip.gemm(b, dc, tb, True, alpha)                 # op(B) dC^T  (stored [K,M])
+                dag = hip.gemm(b, dc, tb, True, alpha)                 # op(B) dC^T  (stored [K,M])
+            if gate is None:
+                da = dag
+            else:
+                da = hip.mul(dag, gate) if ctx.needs_input_grad[0] else None
+                dgate = hip.mul(dag, a) if ctx.needs_input_grad[11] else None
         if ctx.needs_input_grad[1]:
             if not tb:
-                db = hip.gemm(a, dc, not ta, False, alpha, splitk=sk)  # op(A)^T dC
-            else:
-                db = hip.gemm(dc, a, True, ta, alpha, splitk=sk)       # dC^T op(A)  (stored [N,K])
+                db = hip.gemm(a, dc, not ta, False, alpha, splitk=sk, gate=gate)  # op(A.*G)^T dC
+            elif gate is None:
+                db = hip.gemm(dc, a, True, ta, alpha, splitk=sk)                   # dC^T op(A)  (stored [N,K])
+            else:  # the gate rides on the A-operand loader: form op(A.*G)^T dC = dB^T and transpose the small result
+                db = hip.gemm(a, dc, not ta, False, alpha, splitk=sk, gate=gate).transpose(-1, -2).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             dbias = hip.colreduce(dc, None, 0, alpha)
         if has_bias2 and ctx.needs_input_grad[3]:
@@ -55,13 +62,14 @@ class _Gemm(Function):
             dbias2 = hip.gemm(ones, g, False, False, alpha).reshape(-1, n)
         if has_res and ctx.needs_input_grad[4]:
             dres = hip.axpby(dc, None, beta, 0.0)
-        return da, db, dbias, dbias2, dres, None, None, None, None, None, None
+        return da, db, dbias, dbias2, dres, None, None, None, None, None, None, dgate
 
 
 def gemm(a, b, bias=None, bias2=None, res=None, trans_a=False, trans_b=False, alpha=1.0, beta=1.0, rows_per_group=1,
-         weight_b=False):
-    """weight_b=True marks b as a weight: its gradient reduces over all rows of a (split-K)."""
-    return _Gemm.apply(a, b, bias, bias2, res, trans_a, trans_b, alpha, beta, rows_per_group, weight_b)
+         weight_b=False, gate=None):
+    """weight_b=True marks b as a weight: its gradient reduces over all rows of a (split-K).
+    gate: optional tensor of a's shape multiplied into a inside the GEMM's operand loader."""
+    return _Gemm.apply(a, b, bias, bias2, res, trans_a, trans_b, alpha, beta, rows_per_group, weight_b, gate)
 
 
 def linear(x, w, bias=None):
@@ -79,10 +87,10 @@ def conv1x1(x, w, bias=None, bias2=None, res=None, alpha=1.0, beta=1.0):
     return y.reshape(N, H, W, w.shape[1])
 
 
-def conv1x1_t(v, w):
-    """Transpose of conv1x1 w.r.t. its input: v [N,H,W,Cout] -> [N,H,W,Cin]  (v @ w^T)."""
+def conv1x1_t(v, w, gate=None):
+    """Transpose of conv1x1 w.r.t. its input: (v .* gate) [N,H,W,Cout] -> [N,H,W,Cin]  ((v.*gate) @ w^T)."""
     N, H, W, C = v.shape
-    y = gemm(v.reshape(-1, C), w, trans_b=True, weight_b=True)
+    y = gemm(v.reshape(-1, C), w, trans_b=True, weight_b=True, gate=None if gate is None else gate.reshape(-1, C))
     return y.reshape(N, H, W, w.shape[0])
 
 
@@ -121,30 +129,36 @@ def conv2d(x, w, bias=None, bias2=None, res=None, stride=1, pad=1, alpha=1.0, be
 
 
 class _Conv2dT(Function):
-    """t = d<conv(x,w), v>/dx : the transposed convolution as a forward op."""
+    """t = d<conv(x,w), v .* gate>/dx : the transposed convolution as a forward op (gate optional)."""
 
     @staticmethod
-    def forward(ctx, v, w, in_hw, stride, pad):
-        v, w = _c(v), _c(w)
-        ctx.save_for_backward(v, w)
+    def forward(ctx, v, w, in_hw, stride, pad, gate):
+        v, w, gate = _c(v), _c(w), _c(gate)
+        ctx.save_for_backward(v, w, gate)
         ctx.cfg = (in_hw, stride, pad)
-        return hip.conv2d_dgrad(v, w, in_hw, stride, pad)
+        return hip.conv2d_dgrad(v, w, in_hw, stride, pad, gate=gate)
 
     @staticmethod
     def backward(ctx, dt):
-        v, w = ctx.saved_tensors
+        v, w, gate = ctx.saved_tensors
         in_hw, stride, pad = ctx.cfg
         dt = _c(dt)
-        dv = dw = None
-        if ctx.needs_input_grad[0]:
-            dv = hip.conv2d(dt, w, stride, pad)
+        dv = dw = dgate = None
+        if ctx.needs_input_grad[0] or (gate is not None and ctx.needs_input_grad[5]):
+            dvg = hip.conv2d(dt, w, stride, pad)
+            if gate is None:
+                dv = dvg
+            else:
+                dv = hip.mul(dvg, gate) if ctx.needs_input_grad[0] else None
+                dgate = hip.mul(dvg, v) if ctx.needs_input_grad[5] else None
         if ctx.needs_input_grad[1]:
-            dw = hip.conv2d_wgrad(dt, v, w.shape[0], w.shape[1], stride, pad)
-        return dv, dw, None, None, None
+            vg = v if gate is None else hip.mul(v, gate)
+            dw = hip.conv2d_wgrad(dt, vg, w.shape[0], w.shape[1], stride, pad)
+        return dv, dw, None, None, None, dgate
 
 
-def conv2d_t(v, w, in_hw, stride=1, pad=1):
-    return _Conv2dT.apply(v, w, in_hw, stride, pad)
+def conv2d_t(v, w, in_hw, stride=1, pad=1, gate=None):
+    return _Conv2dT.apply(v, w, in_hw, stride, pad, gate)
 
 
 # ----------------------------------------------------------------------------- normalisation / softmax

@@ -14,7 +14,9 @@ import torch.nn.functional as F
 
 
 def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, rows_per_group=1, res=None,
-         beta=1.0, splitk=False):
+         beta=1.0, splitk=False, gate=None):
+    if gate is not None:
+        a = a * gate
     A = a.transpose(-1, -2) if trans_a else a
     Bm = b.transpose(-1, -2) if trans_b else b
     out = torch.matmul(A, Bm)
@@ -74,7 +76,9 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
     return y.contiguous()
 
 
-def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0):
+def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, gate=None):
+    if gate is not None:
+        dy = dy * gate
     N, OH, OW, Co = dy.shape
     KH, KW, Ci, _ = w.shape
     H, W = in_hw

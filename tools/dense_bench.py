@@ -21,6 +21,9 @@ a, w = r(M, 512), r(512, 512)
 timeit(lambda: hip.gemm(a, w), 2*M*512*512, "gemm NN  [131072,512]x[512,512] (flow 1x1 fwd)")
 timeit(lambda: hip.gemm(a, w, trans_b=True), 2*M*512*512, "gemm NT  (flow 1x1 transposed / dgrad)")
 timeit(lambda: hip.gemm(a, a, trans_a=True, splitk=True), 2*M*512*512, "gemm TN  split-K (1x1 wgrad)")
+a4, w4 = r(4096, 4096), r(4096, 4096)
+timeit(lambda: hip.gemm(a4, w4), 2*4096**3, "gemm NN  4096^3 (reference point: guide's untuned kernel = 122 TF)")
+timeit(lambda: hip.gemm(a4, w4, trans_b=True), 2*4096**3, "gemm NT  4096^3")
 M1 = B * 256
 a1 = r(M1, 512)
 timeit(lambda: hip.gemm(a1, w), 2*M1*512*512, "gemm NN  [32768,512]x[512,512] (flow scale 1)")
