@@ -167,13 +167,19 @@ def profile_stop():
     return out
 
 
-def _tile(M, N):
-    return "128x32" if (N <= 32 and M > 32) else ("32x128" if M <= 32 else "128x128")
+def _tile(M, N, amode="", batch=1, splitk=False):
+    if N <= 32 and M > 32:
+        return "128x32"
+    if M <= 32:
+        return "32x128"
+    if amode in ("A_ROW", "A_CONV") and not splitk and N >= 128 and -(-M // 256) * -(-N // 128) * batch >= 256:
+        return "256x128"
+    return "128x128"
 
 
 class _timed:
-    def __init__(self, amode, bmode, M, N, K, batch=1):
-        self.key = f"igemm<{amode},{bmode},{_tile(M, N)}>"
+    def __init__(self, amode, bmode, M, N, K, batch=1, splitk=False):
+        self.key = f"igemm<{amode},{bmode},{_tile(M, N, amode, batch, splitk)}>"
         self.flops = 2.0 * M * N * K * batch
         self.on = _Profile.enabled and (_Profile.only is None or _Profile.only == self.key)
 
@@ -215,7 +221,7 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     sA = a.shape[-1] * a.shape[-2] if a.dim() == 3 else 0
     sB = b.shape[-1] * b.shape[-2] if b.dim() == 3 else 0
     ws = _ws(SPLITK_WS_FLOATS, a.device) if splitk else None
-    with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch):
+    with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch, splitk):
         st = lib().indm_gemm_f32(_ptr(a), _ptr(gate), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
                                  b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
                                  _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
