@@ -523,7 +523,8 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
   if (p.N <= 32 && p.M > 32) {
     dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 32), p.batch * p.splitk);
     hipLaunchKernelGGL((igemm_kernel<AM, BMODE, 128, 32, 4, 1>), grid, block, 0, st, p);
-  } else if (p.M <= 32) {
+  } else if (p.M <= 128 && cdiv(p.M, 32) * cdiv(p.N, 128) * p.batch * p.splitk <= 512) {
+    // short-M GEMMs (per-image vectors x weights): 32-row tiles so more than a handful of CUs get work
     dim3 grid(cdiv(p.M, 32) * cdiv(p.N, 128), p.batch * p.splitk);
     hipLaunchKernelGGL((igemm_kernel<AM, BMODE, 32, 128, 1, 4>), grid, block, 0, st, p);
   } else if (use_tall_tile<AM>(p)) {
@@ -548,7 +549,7 @@ inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 // Pick split-K so that tiles*splits fills the chip (>= ~2 waves of 256 CUs) when the
 // output is small and the reduction long (weight grads: K = B*H*W pixels).
 int choose_splitk(int M, int N, int K, int batch, long ws_floats) {
-  long tiles = (long)cdiv(M, (N <= 32 && M > 32) ? 128 : (M <= 32 ? 32 : 128)) *
+  long tiles = (long)cdiv(M, (N <= 32 && M > 32) ? 128 : (M <= 128 ? 32 : 128)) *
                cdiv(N, (N <= 32 && M > 32) ? 32 : 128) * batch;
   if (tiles >= 256 || K < 4 * BK * 8) return 1;
   long want = (1024 + tiles - 1) / tiles;

@@ -89,8 +89,9 @@ class IResBlock(nn.Module):
     def weights(self):
         return [c.normalized() for c in self.convs]
 
-    def g(self, x, h, W, want_gates):
-        """g(x,h) and (optionally) the cos gates d0,d1,d2 for the VJP chain."""
+    def g(self, x, cb, W, want_gates):
+        """g(x,h) and (optionally) the cos gates d0,d1,d2 for the VJP chain.  cb = Linear_h(h) @ W2 is the folded
+        conditioning bias [B, idim] (computed for all blocks at once by ResidualFlow.prepare)."""
         c1, c2, c3 = self.convs
         W1, W2, W3 = W
         d0 = None
@@ -99,8 +100,6 @@ class IResBlock(nn.Module):
             a0, d0 = ops.sincos(x)
         p1 = ops.conv2d(a0, W1, c1.bias)
         a1, d1 = ops.sincos(p1)
-        cb = ops.linear(h, c2.h_net.net.weight, c2.h_net.net.bias)        # [B, idim]
-        cb = ops.gemm(cb, W2)                                              # Linear(h) W2 (conditioning folded)
         p2 = ops.conv1x1(a1, W2, c2.bias, cb)
         a2, d2 = ops.sincos(p2)
         g = ops.conv2d(a2, W3, c3.bias)
@@ -117,7 +116,7 @@ class IResBlock(nn.Module):
             t = ops.mul(t, d0)
         return t
 
-    def forward_logdet(self, x, h, W, rng, stats):
+    def forward_logdet(self, x, cb, W, rng, stats):
         """_logdetgrad iresblock.py:90-174 (poisson, n_samples=1, neumann_grad in training)."""
         lamb = self.lamb_value
         n = rng.poisson(lamb)
@@ -130,7 +129,7 @@ class IResBlock(nn.Module):
 
         N, H, Wd, C = x.shape
         eps = rng.randn_image(N, C, H, Wd)
-        g, gates = self.g(x, h, W, True)
+        g, gates = self.g(x, cb, W, True)
         hw = (H, Wd)
         if training:  # neumann_logdet_estimator :264-273
             with torch.no_grad():
@@ -152,13 +151,13 @@ class IResBlock(nn.Module):
             stats.append((self, n, logdet.detach()))
         return ops.axpby(x, g), logdet
 
-    def inverse(self, y, h, W, atol=1e-5, rtol=1e-5, iters=None):
+    def inverse(self, y, cb, W, atol=1e-5, rtol=1e-5, iters=None):
         """_inverse_fixed_point iresblock.py:78-88"""
-        g, _ = self.g(y, h, W, False)
+        g, _ = self.g(y, cb, W, False)
         x, x_prev = ops.axpby(y, g, 1.0, -1.0), y
         i = 0
         while float(hip.fixed_point_check(x, x_prev, y, atol, rtol)) != 0.0:
-            g, _ = self.g(x, h, W, False)
+            g, _ = self.g(x, cb, W, False)
             x, x_prev = ops.axpby(y, g, 1.0, -1.0), x
             i += 1
             if i > 1000:
@@ -196,18 +195,37 @@ class ResidualFlow(nn.Module):
     def blocks(self):
         return [[b for b in t.chain if isinstance(b, IResBlock)] for t in self.transforms]
 
+    def prepare(self, h):
+        """Per-call constants of every block, computed up front in a few large launches:
+          * Lop-normalised weights (once per flow call, shared by g and every VJP),
+          * the folded conditioning bias  cb_b = Linear_b(h) @ W2_b  for ALL blocks: one [B,64]x[64, NB*idim]
+            GEMM + one batched [NB] x ([B,idim] x [idim,idim]) GEMM instead of 2*NB short-M launches.
+        Returns {block: (W, cb)}."""
+        blks = [b for sc in self.blocks() for b in sc]
+        Ws = [b.weights() for b in blks]
+        nb, B = len(blks), h.shape[0]
+        hw = torch.cat([b.convs[1].h_net.net.weight for b in blks], dim=0)      # [NB*idim, 64]
+        hb = torch.cat([b.convs[1].h_net.net.bias for b in blks], dim=0)
+        idim = blks[0].convs[1].in_ch
+        c = ops.linear(h, hw, hb).reshape(B, nb, idim).permute(1, 0, 2).contiguous()  # [NB, B, idim]
+        w2 = torch.stack([W[1] for W in Ws], dim=0)                                    # [NB, idim, idim]
+        cb = ops.gemm(c, w2)                                                           # [NB, B, idim]
+        cbs = cb.unbind(0)  # backward = one stack
+        return {b: (W, cbs[i]) for i, (b, W) in enumerate(zip(blks, Ws))}
+
     def fwdpass(self, x, h, eval_logdet, rng, stats=None):
         """:310-324 -- returns (z, logpx) with logpx = -sum logdet (as the reference)."""
         scales = self.blocks()
+        prep = self.prepare(h)
         logpx = None
         for si, blocks in enumerate(scales):
             for b in blocks:
-                W = b.weights()
+                W, cb = prep[b]
                 if eval_logdet:
-                    x, ld = b.forward_logdet(x, h, W, rng, stats)
+                    x, ld = b.forward_logdet(x, cb, W, rng, stats)
                     logpx = -ld if logpx is None else logpx - ld
                 else:
-                    g, _ = b.g(x, h, W, False)
+                    g, _ = b.g(x, cb, W, False)
                     x = ops.axpby(x, g)
             if si < len(scales) - 1:
                 x = ops.squeeze2x(x)
@@ -218,13 +236,15 @@ class ResidualFlow(nn.Module):
     def bwdpass(self, z, h, iters=None):
         """:326-335 + inverse :237-267"""
         scales = self.blocks()
+        prep = self.prepare(h)
         for _ in range(len(scales) - 1):
             z = ops.squeeze2x(z)
         for si in range(len(scales) - 1, -1, -1):
             if si < len(scales) - 1:
                 z = ops.unsqueeze2x(z)
             for b in reversed(scales[si]):
-                z = b.inverse(z, h, b.weights(), iters=iters)
+                W, cb = prep[b]
+                z = b.inverse(z, cb, W, iters=iters)
         return z
 
 

@@ -170,7 +170,7 @@ def profile_stop():
 def _tile(M, N, amode="", batch=1, splitk=False):
     if N <= 32 and M > 32:
         return "128x32"
-    if M <= 32:
+    if M <= 128 and -(-M // 32) * -(-N // 128) * batch <= 512:
         return "32x128"
     if amode in ("A_ROW", "A_CONV") and not splitk and N >= 128 and -(-M // 256) * -(-N // 128) * batch >= 256:
         return "256x128"
@@ -220,12 +220,12 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     out = torch.empty(shape, dtype=torch.float32, device=a.device)
     sA = a.shape[-1] * a.shape[-2] if a.dim() == 3 else 0
     sB = b.shape[-1] * b.shape[-2] if b.dim() == 3 else 0
-    ws = _ws(SPLITK_WS_FLOATS, a.device) if splitk else None
+    ws = _ws(SPLITK_WS_FLOATS, a.device)  # split-K is decided inside (only when the tile count cannot fill the chip)
     with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch, splitk):
         st = lib().indm_gemm_f32(_ptr(a), _ptr(gate), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
                                  b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
                                  _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
-                                 _ptr(ws), SPLITK_WS_FLOATS if splitk else 0, _stream())
+                                 _ptr(ws), SPLITK_WS_FLOATS, _stream())
     _chk(st, "indm_gemm_f32")
     return out
 
