@@ -253,10 +253,13 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 template <int AM, int BMODE, int TM, int TN, int WAVES_M, int WAVES_N>
+#ifndef INDM_EXP
+#define INDM_EXP 0
+#endif
 #ifndef INDM_WPE
 #define INDM_WPE 1
 #endif
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, INDM_WPE) void igemm_kernel(IgemmParams p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3 : 4)) void igemm_kernel(IgemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int RM = TM / WAVES_M / 32, RN = TN / WAVES_N / 32;
 #if 1
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, INDM_WPE) void igemm_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[NGA], rb[NGB];
+  float4 ra0[NGA], rb0[NGB], ra1[NGA], rb1[NGB];  // two register sets: slab kt+1 (to be stored) and kt+2 (in flight)
 
   // loop-invariant per-thread coordinates of the A row groups
   PixDec rowdec[NGA];
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, INDM_WPE) void igemm_kernel
     }
   }
 
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, float4 (&ra)[NGA], float4 (&rb)[NGB]) {
     const int k0 = kbeg + kt * BK;
     int3 tapdec = make_int3(0, 0, 0);
     int2 btap = make_int2(0, 0);
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, INDM_WPE) void igemm_kernel
       }
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float4 (&ra)[NGA], const float4 (&rb)[NGB]) {
     float* as = As + buf * BK * LDA_S;
     float* bs = Bs + buf * BK * LDB_S;
 #pragma unroll
@@ -417,17 +420,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, INDM_WPE) void igemm_kernel
   const int mw = wm * (TM / WAVES_M), nw = wn * (TN / WAVES_N);
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  if (nk > 0) {
-    gload(0);
-    sstore(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+  // One K-slab of MFMAs out of LDS buffer `buf`.  `mid` runs after half of the k-pairs: it stores the NEXT slab
+  // (already in registers) into the other LDS buffer, so the LDS-write issue and the vmcnt wait sit inside this
+  // wave's own MFMA stream instead of in front of the barrier.
+  auto compute = [&](int buf, auto&& mid) {
     const float* as = As + buf * BK * LDA_S + mw + l31;
     const float* bs = Bs + buf * BK * LDB_S + nw + l31;
-    // software-pipelined fragment reads: the ds_reads of k-pair kk+1 are in flight while the MFMAs of kk issue
     float a[2][RM], b[2][RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i) a[0][i] = as[lhi * LDA_S + i * 32];
@@ -452,9 +450,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, INDM_WPE) void igemm_kernel
       // sinks the reads to just before their use and exposes the LDS latency every 4 MFMAs)
       if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, RM + RN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, RM * RN, 0);
+      if (kk == BK / 4 - 1) mid();
     }
-    if (kt + 1 < nk) sstore(buf ^ 1);
+  };
+
+  // prologue: slab 0 -> LDS buffer 0, slab 1 -> register set 1
+  if (nk > 0) {
+    gload(0, ra0, rb0);
+    sstore(0, ra0, rb0);
+  }
+  if (nk > 1) gload(1, ra1, rb1);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even slab: MFMAs on buffer 0; set 1 holds slab kt+1 (stored mid-way); set 0 receives slab kt+2
+    if (kt + 2 < nk) gload(kt + 2, ra0, rb0);
+    compute(0, [&] { if (kt + 1 < nk) sstore(1, ra1, rb1); });
     __syncthreads();
+    if (kt + 1 < nk) {
+      if (kt + 3 < nk) gload(kt + 3, ra1, rb1);
+      compute(1, [&] { if (kt + 2 < nk) sstore(0, ra0, rb0); });
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----
