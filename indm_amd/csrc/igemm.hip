@@ -253,9 +253,6 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 template <int AM, int BMODE, int TM, int TN, int WAVES_M, int WAVES_N>
-#ifndef INDM_EXP
-#define INDM_EXP 0
-#endif
 #ifndef INDM_WPE
 #define INDM_WPE 1
 #endif

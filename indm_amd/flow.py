@@ -618,6 +618,9 @@ class WolfCore(nn.Module):
             return v.t().contiguous()[:, :, None, None]
         return v
 
+    def from_reference_layout(self, k, v):
+        return self._to_native(k, torch.as_tensor(v))
+
     def reference_state_dict(self, prefix="module."):
         return {prefix + k: self.to_reference_layout(k, v) for k, v in self.state_dict().items()}
 

@@ -400,6 +400,15 @@ class NCSNpp(nn.Module):
         """Convert a tensor shaped like parameter `key` (e.g. its gradient / EMA shadow) to the reference layout."""
         return self._layout(key, t.detach(), True)
 
+    def from_reference_layout(self, key, t):
+        """Inverse of to_reference_layout (OIHW -> RSCK, [O,I,1,1] -> [I,O])."""
+        t = torch.as_tensor(t)
+        if t.dim() == 4 and key.endswith("Conv_2.weight"):
+            return t[:, :, 0, 0].t().contiguous()
+        if t.dim() == 4:
+            return t.permute(2, 3, 1, 0).contiguous()
+        return t
+
     def reference_state_dict(self, prefix="module."):
         """State dict in the reference's key/layout convention (models/utils.py:93 wraps in DataParallel)."""
         return {prefix + k: self._layout(k, v.detach(), True) for k, v in self.state_dict().items()}

@@ -107,14 +107,48 @@ class FusedAdamW:
                       g["eps"], g["weight_decay"], self.t, float(grad_clip), gn, float(grad_scale), float(omd))
         self.last_grad_sqnorm = gn
 
+    def _views(self, flat):
+        out, o = {}, 0
+        for n, p in self.flat.named:
+            out[n] = flat[o:o + p.numel()].view(p.shape)
+            o += _pad4(p.numel())
+        return out
+
     def state_dict(self):
-        return dict(step=self.t, exp_avg=self.m, exp_avg_sq=self.v, param_groups=self.param_groups)
+        """torch.optim.AdamW.state_dict() layout (what the reference's save_checkpoint stores, utils.py:36-48):
+        `state[i]` for the i-th entry of model.parameters() (only parameters that have been stepped), moments in
+        the REFERENCE tensor layout."""
+        model = self.flat.module
+        m, v = self._views(self.m), self._views(self.v)
+        names = [n for n, _ in model.named_parameters()]
+        state = {}
+        if self.t > 0:
+            for i, n in enumerate(names):
+                if n in m:
+                    state[i] = dict(step=torch.tensor(float(self.t)),
+                                    exp_avg=model.to_reference_layout(n, m[n]).clone(),
+                                    exp_avg_sq=model.to_reference_layout(n, v[n]).clone())
+        g = self.param_groups[0]
+        group = dict(lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], amsgrad=False,
+                     foreach=None, maximize=False, capturable=False, differentiable=False, fused=None,
+                     decoupled_weight_decay=True, params=list(range(len(names))))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.t = sd["step"]
-        self.m.copy_(sd["exp_avg"])
-        self.v.copy_(sd["exp_avg_sq"])
-        self.param_groups = sd["param_groups"]
+        model = self.flat.module
+        m, v = self._views(self.m), self._views(self.v)
+        names = [n for n, _ in model.named_parameters()]
+        steps = set()
+        for i, st in sd["state"].items():
+            n = names[int(i)]
+            if n not in m:
+                continue
+            m[n].copy_(model.from_reference_layout(n, st["exp_avg"]).to(m[n].device))
+            v[n].copy_(model.from_reference_layout(n, st["exp_avg_sq"]).to(v[n].device))
+            steps.add(int(float(st["step"])))
+        self.t = max(steps) if steps else 0
+        g = sd["param_groups"][0]
+        self.param_groups = [dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])]
 
 
 class ExponentialMovingAverage:
@@ -171,10 +205,16 @@ class ExponentialMovingAverage:
         return [v[n] for n, p in self.flat.module.named_parameters() if p.requires_grad]
 
     def state_dict(self):
-        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params())
+        """models/ema.py:91-92: shadow_params in module.parameters() order, REFERENCE tensor layout."""
+        model = self.flat.module
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        return dict(decay=self.decay, num_updates=self.num_updates,
+                    shadow_params=[model.to_reference_layout(n, s).clone() for n, s in zip(names, self.shadow_params())])
 
     def load_state_dict(self, sd):
+        model = self.flat.module
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
         self.decay = sd["decay"]
         self.num_updates = sd["num_updates"]
-        for dst, src in zip(self.shadow_params(), sd["shadow_params"]):
-            dst.copy_(src)
+        for n, dst, src in zip(names, self.shadow_params(), sd["shadow_params"]):
+            dst.copy_(model.from_reference_layout(n, src).to(dst.device))

@@ -48,6 +48,34 @@ def build_states(config, score_model=None, flow_model=None, device=None):
     return state, flow_state, flat_g
 
 
+def save_checkpoint(config, ckpt_path, state):
+    """utils.save_checkpoint (utils.py:36-48): the file is readable by the REFERENCE's restore_checkpoint --
+    'model' carries the `module.`-prefixed OIHW state dict, 'ema' the shadow_params list in parameters() order,
+    'optimizer' a torch.optim.AdamW state dict."""
+    model = state["model"]
+    saved = {"optimizer": state["optimizer"].state_dict(),
+             "model": {k: v.cpu() for k, v in model.reference_state_dict(prefix="module.").items()},
+             "ema": {k: ([t.cpu() for t in v] if isinstance(v, list) else v) for k, v in state["ema"].state_dict().items()},
+             "step": state["step"]}
+    for st in saved["optimizer"]["state"].values():
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].cpu(), st["exp_avg_sq"].cpu()
+    torch.save(saved, ckpt_path)
+
+
+def restore_checkpoint(config, ckpt_path, state, device=None):
+    """utils.restore_checkpoint (utils.py:14-33) for checkpoints written by this repo OR by the reference."""
+    import os
+    if not os.path.exists(ckpt_path):
+        return state
+    loaded = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    if config.training.sde != "vesde":   # utils.py:23-24: VE runs do not restore the optimiser
+        state["optimizer"].load_state_dict(loaded["optimizer"])
+    state["model"].load_reference_state_dict(loaded["model"])
+    state["ema"].load_state_dict(loaded["ema"])
+    state["step"] = loaded["step"]
+    return state
+
+
 def get_loss_fns(config, sde, inverse_scaler, train=True, scaler=None, world_size=1, allreduce=None):
     """utils.py:147-154"""
     optimize_fn = losses.optimization_manager(config)

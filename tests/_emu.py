@@ -61,11 +61,15 @@ def conv_out_size(h, k, stride, pad):
 
 
 def _w_oihw(w):
-    return w.permute(3, 2, 0, 1)
+    return w.permute(3, 2, 0, 1).contiguous()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
 
 
 def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
-    y = F.conv2d(x.permute(0, 3, 1, 2), _w_oihw(w), None, stride, pad).permute(0, 2, 3, 1)
+    y = F.conv2d(_nchw(x), _w_oihw(w), None, stride, pad).permute(0, 2, 3, 1)
     if bias is not None:
         y = y + bias
     if bias2 is not None:
@@ -82,7 +86,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
     N, OH, OW, Co = dy.shape
     KH, KW, Ci, _ = w.shape
     H, W = in_hw
-    dx = torch.nn.grad.conv2d_input((N, Ci, H, W), _w_oihw(w), dy.permute(0, 3, 1, 2), stride, pad)
+    dx = torch.nn.grad.conv2d_input((N, Ci, H, W), _w_oihw(w), _nchw(dy), stride, pad)
     dx = alpha * dx.permute(0, 2, 3, 1)
     if res is not None:
         dx = dx + beta * res
@@ -92,7 +96,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
 def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
     N, H, W, Ci = x.shape
     Co = dy.shape[-1]
-    dw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (Co, Ci, kh, kw), dy.permute(0, 3, 1, 2), stride, pad)
+    dw = torch.nn.grad.conv2d_weight(_nchw(x), (Co, Ci, kh, kw), _nchw(dy), stride, pad)
     return (alpha * dw.permute(2, 3, 1, 0)).contiguous()
 
 

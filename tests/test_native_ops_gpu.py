@@ -1,0 +1,48 @@
+"""The reference's two native ops through their drop-in mirrors (indm_amd/op.py) against the golden vectors the
+reference's own CPU fallbacks produced (tests/golden/native_ops.npz): forward, gradient and double gradient."""
+import pytest
+import torch
+
+import golden_utils as gu
+from indm_amd import op
+
+pytestmark = pytest.mark.gpu
+
+
+def test_upfirdn2d_golden_fwd_grad():
+    d = gu.load("native_ops")
+    for i, (c, h, w, up, down, p0, p1) in enumerate(d["cases"]):
+        for kn in ("fir", "rand"):
+            g = gu.sub(d, f"ufd{i}_{kn}")
+            x = g["x"].cuda().requires_grad_(True)
+            y = op.upfirdn2d(x, g["k"].cuda(), up=int(up), down=int(down), pad=(int(p0), int(p1)))
+            gu.assert_close(y, g["y"], 1e-5, 1e-6, f"ufd{i} {kn}")
+            (gx,) = torch.autograd.grad(y, x, g["gy"].cuda(), create_graph=True)
+            gu.assert_close(gx, g["gx"], 1e-5, 1e-6, f"ufd{i} {kn} grad")
+            # double backward: d/d(gy) <gx, v> = upfirdn2d(v) with the forward parameters (op/upfirdn2d.py:64-85)
+            gy = g["gy"].cuda().requires_grad_(True)
+            (gx2,) = torch.autograd.grad(y, x, gy, create_graph=True)
+            v = torch.linspace(-1, 1, gx2.numel(), device="cuda").reshape(gx2.shape)
+            (ggy,) = torch.autograd.grad(gx2, gy, v)
+            ref = op.upfirdn2d(v, g["k"].cuda(), up=int(up), down=int(down), pad=(int(p0), int(p1)))
+            gu.assert_close(ggy, ref, 1e-5, 1e-6, f"ufd{i} {kn} double-backward")
+
+
+def test_fused_leaky_relu_golden_and_grads():
+    d = gu.load("native_ops")
+    g = gu.sub(d, "flr")
+    x = g["x"].cuda().requires_grad_(True)
+    b = g["b"].cuda().requires_grad_(True)
+    y = op.fused_leaky_relu(x, b)
+    gu.assert_close(y, g["y"], 1e-6, 1e-6, "fused_leaky_relu")
+    gy = torch.linspace(-1, 1, y.numel(), device="cuda").reshape(y.shape)
+    gx, gb = torch.autograd.grad(y, [x, b], gy)
+    xr, br = g["x"].double().requires_grad_(True), g["b"].double().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(xr + br.view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+    gxr, gbr = torch.autograd.grad(yr, [xr, br], gy.cpu().double())
+    gu.assert_close(gx, gxr, 1e-5, 1e-6, "flr gx")
+    gu.assert_close(gb, gbr, 1e-5, 1e-5, "flr gb")
+    m = op.FusedLeakyReLU(8, negative_slope=0.1).cuda()
+    out = m(g["x"].cuda())
+    ref = torch.nn.functional.leaky_relu(g["x"], 0.1) * 2 ** 0.5
+    gu.assert_close(out, ref, 1e-6, 1e-6, "FusedLeakyReLU slope 0.1 (CUDA-kernel semantics)")
