@@ -1,0 +1,83 @@
+"""Full-size parity: ONE training step of the real configs/vp/CIFAR10/indm_nll architecture (61.8 M + 13.2 M
+parameters, 32 iResBlocks of width 512, 55-module NCSN++) at batch 2 on the HIP path vs the CPU oracle with the
+same random-init weights and the same noise.  Exercises every production tile shape / channel count that the
+mini golden configs cannot (tall 256x128 tiles, 512-wide gates, skinny 3/12 <-> 512 edges, 384/512-ch GroupNorm)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_utils as gu  # noqa: F401  (puts oracle/ on sys.path)
+import indm_oracle as O
+from indm_amd import configs, losses, sde_lib, utils
+from indm_amd.flow import create_flow_model
+from indm_amd.rng import ReplayRng
+
+pytestmark = pytest.mark.gpu
+
+
+class RecordingRng(O.Rng):
+    def __init__(self):
+        self.events = []
+
+    def _rec(self, kind, v):
+        self.events.append((kind, np.asarray(v.numpy() if torch.is_tensor(v) else v).copy()))
+        return v
+
+    def randn(self, *shape):
+        return self._rec("randn", torch.randn(*shape))
+
+    def randn_like(self, x):
+        return self._rec("randn", torch.randn_like(x))
+
+    def rand(self, *shape):
+        return self._rec("rand", torch.rand(*shape))
+
+    def rademacher_like(self, x):
+        return self._rec("rademacher", super().rademacher_like(x))
+
+    def poisson(self, lam):
+        n = super().poisson(lam)
+        self.events.append(("poisson", np.asarray(n)))
+        return n
+
+
+@pytest.mark.timeout(1500)
+def test_full_size_training_step_matches_oracle():
+    torch.manual_seed(7)
+    np.random.seed(7)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.model.dropout = 0.0
+    cfg.training.batch_size = 2
+    dev = torch.device("cuda")
+    cfg.device = dev
+    score = utils.create_model(cfg, dev)
+    fl = create_flow_model(cfg).to(dev)
+    with torch.no_grad():  # init_scale=0 leaves the output convs at 1e-10: make the untrained net non-degenerate
+        for n, p in score.named_parameters():
+            if p.dim() > 1 and p.abs().max() < 1e-6:
+                p.copy_(torch.randn_like(p) * 0.02)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
+    x = (torch.rand(2, 3, 32, 32) * 2 - 1)
+
+    ost = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, cfg)
+    ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    rec = RecordingRng()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    want = O.flow_step_fn_nll(cfg, O.get_sde(cfg), ost, ofst, x, rec)
+
+    state, fstate, _ = utils.build_states(cfg, score, fl, dev)
+    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+    score.train(); fl.train()
+    rng = ReplayRng(rec.events, dev)
+    got = step_fn(state, fstate, x.to(dev), rng=rng)
+    assert rng.done()
+    for name, a, b in zip(("loss", "score", "flow", "logp"), got, want):
+        gu.assert_close(a, b, 1e-3, 1e-5, "full-size " + name)
+    ss, sf = score.reference_state_dict(prefix=""), fl.reference_state_dict(prefix="")
+    for sd, o, lr in ((ss, ost, cfg.optim.lr), (sf, ofst, cfg.flow.lr)):
+        for k in list(o.trainable)[:: max(1, len(o.trainable) // 12)]:
+            diff = (sd[k].cpu().double() - o.P[k].detach().double()).abs()
+            assert diff.max().item() <= 2.2 * lr, (k, diff.max().item())
+            frac = (diff > 1e-6 + 1e-4 * o.P[k].detach().abs().double()).double().mean().item()
+            assert frac < 5e-3, (k, frac)
