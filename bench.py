@@ -84,6 +84,22 @@ def cpu_baseline(cfg, score, flow, batch=16, timeout=420):
                       f"(oracle/indm_oracle.py, torch CPU fp32, {res['threads']} threads): {res['dt']:.1f} s"}
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of `kernel_key` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate runs of this same command, gfx950 FETCH_SIZE correction applied; profiles/*traffic*.json).  PMC
+    counters cannot be read from inside the timed process, so this is the newest committed measurement of the same
+    kernel instantiation, or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("bench_key") == kernel_key:
+            return d["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,10 +191,13 @@ def main():
         if dominant and dominant in prof and prof[dominant]["ms"] > 0:
             p = prof[dominant]
             ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+            traffic, src = pmc_traffic(dominant)
             out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_source": src,
                                "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
-                               "algorithmic_gflop_per_launch": p["flops"] / p["launches"] / 1e9}
+                               "algorithmic_gflop_per_launch": p["flops"] / p["launches"] / 1e9,
+                               "algorithmic_bytes_per_launch": p["bytes"] / p["launches"]}
         else:
             out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:

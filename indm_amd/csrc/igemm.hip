@@ -253,19 +253,12 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 template <int AM, int BMODE, int TM, int TN, int WAVES_M, int WAVES_N>
-#ifndef INDM_WPE
-#define INDM_WPE 1
-#endif
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3 : 4)) void igemm_kernel(IgemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int RM = TM / WAVES_M / 32, RN = TN / WAVES_N / 32;
-#if 1
   // row-contiguous operands: +4 padding keeps every [k][row] slab row 16-byte aligned -> one ds_write_b128 per
   // float4; k-contiguous operands keep +2 (conflict-free transposing ds_write_b32)
   constexpr int LDA_S = TM + (a_kcontig<AM>() ? 2 : 4), LDB_S = TN + (b_kcontig<BMODE>() ? 2 : 4);
-#else
-  constexpr int LDA_S = TM + 2, LDB_S = TN + 2;
-#endif
   constexpr int KG = BK / 4;  // float4 groups along K per row
   constexpr int GA = TM * KG, GB = TN * KG;  // float4 groups per operand slab
   constexpr int NGA = (GA + NT - 1) / NT, NGB = (GB + NT - 1) / NT;
@@ -378,13 +371,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
         } else {
           constexpr int Q = TM / 4;
           const int k = g / Q, row = (g % Q) * 4;
-#if 1
           *(float4*)(as + k * LDA_S + row) = ra[j];
-#else
-          float2* d = (float2*)(as + k * LDA_S + row);
-          d[0] = make_float2(ra[j].x, ra[j].y);
-          d[1] = make_float2(ra[j].z, ra[j].w);
-#endif
         }
       }
     }
@@ -401,13 +388,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
         } else {
           constexpr int Q = TN / 4;
           const int k = g / Q, row = (g % Q) * 4;
-#if 1
           *(float4*)(bs + k * LDB_S + row) = rb[j];
-#else
-          float2* d = (float2*)(bs + k * LDB_S + row);
-          d[0] = make_float2(rb[j].x, rb[j].y);
-          d[1] = make_float2(rb[j].z, rb[j].w);
-#endif
         }
       }
     }

@@ -161,8 +161,8 @@ def profile_stop():
     _Profile.enabled = False
     torch.cuda.synchronize()
     out = {}
-    for k, (flops, evs) in _Profile.rec.items():
-        out[k] = dict(launches=len(evs), flops=flops, ms=sum(a.elapsed_time(b) for a, b in evs))
+    for k, (flops, evs) in _Profile.rec.items():  # flops = [flops, algorithmic bytes]
+        out[k] = dict(launches=len(evs), flops=flops[0], bytes=flops[1], ms=sum(a.elapsed_time(b) for a, b in evs))
     _Profile.rec = {}
     return out
 
@@ -178,9 +178,11 @@ def _tile(M, N, amode="", batch=1, splitk=False):
 
 
 class _timed:
-    def __init__(self, amode, bmode, M, N, K, batch=1, splitk=False):
+    def __init__(self, amode, bmode, M, N, K, batch=1, splitk=False, nbytes=None):
         self.key = f"igemm<{amode},{bmode},{_tile(M, N, amode, batch, splitk)}>"
         self.flops = 2.0 * M * N * K * batch
+        # algorithmic bytes: every operand read once, the result written once (conv callers pass the image size)
+        self.bytes = float(nbytes) if nbytes is not None else 4.0 * batch * (M * K + K * N + M * N)
         self.on = _Profile.enabled and (_Profile.only is None or _Profile.only == self.key)
 
     def __enter__(self):
@@ -193,8 +195,9 @@ class _timed:
     def __exit__(self, *a):
         if self.on:
             self.e1.record()
-            r = _Profile.rec.setdefault(self.key, [0.0, []])
-            r[0] += self.flops
+            r = _Profile.rec.setdefault(self.key, [[0.0, 0.0], []])
+            r[0][0] += self.flops
+            r[0][1] += self.bytes
             r[1].append((self.e0, self.e1))
         return False
 
@@ -221,7 +224,9 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     sA = a.shape[-1] * a.shape[-2] if a.dim() == 3 else 0
     sB = b.shape[-1] * b.shape[-2] if b.dim() == 3 else 0
     ws = _ws(SPLITK_WS_FLOATS, a.device)  # split-K is decided inside (only when the tile count cannot fill the chip)
-    with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch, splitk):
+    nbytes = 4 * (a.numel() * (2 if gate is not None else 1) + b.numel() + out.numel()
+                  + (res.numel() if res is not None else 0))
+    with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch, splitk, nbytes):
         st = lib().indm_gemm_f32(_ptr(a), _ptr(gate), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
                                  b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
                                  _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
@@ -277,7 +282,7 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
         return y2.view(N, H, W, Co)
     OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
     y = torch.empty((N, OH, OW, Co), dtype=torch.float32, device=x.device)
-    with _timed("A_CONV", "B_ROW", N * OH * OW, Co, KH * KW * Ci):
+    with _timed("A_CONV", "B_ROW", N * OH * OW, Co, KH * KW * Ci, nbytes=4 * (x.numel() + w.numel() + y.numel())):
         ws = _ws(SPLITK_WS_FLOATS, x.device)
         st = lib().indm_conv2d_fwd_f32(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, KH, KW, stride, pad, 1, OH, OW,
                                        alpha, _ptr(bias), _ptr(bias2), _ptr(res), beta, _ptr(ws), SPLITK_WS_FLOATS,
@@ -308,7 +313,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
         r = res.reshape(-1, Ci) if res is not None else None
         return gemm(dycol.reshape(-1, 9 * Co), wt, alpha=alpha, res=r, beta=beta).view(N, H, W, Ci)
     dx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=dy.device)
-    with _timed("A_CONV", "B_DGRAD", N * H * W, Ci, KH * KW * Co):
+    with _timed("A_CONV", "B_DGRAD", N * H * W, Ci, KH * KW * Co, nbytes=4 * (dy.numel() + w.numel() + dx.numel())):
         ws = _ws(SPLITK_WS_FLOATS, dy.device)
         st = lib().indm_conv2d_dgrad_f32(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride,
                                          H, W, alpha, _ptr(res), beta, _ptr(ws), SPLITK_WS_FLOATS, _stream())
@@ -332,7 +337,7 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
                     splitk=True).view(3, 3, Ci, Co)
     dw = torch.empty((kh, kw, Ci, Co), dtype=torch.float32, device=x.device)
     ws = _ws(SPLITK_WS_FLOATS, x.device)
-    with _timed("A_WGRAD", "B_ROW", kh * kw * Ci, Co, N * OH * OW):
+    with _timed("A_WGRAD", "B_ROW", kh * kw * Ci, Co, N * OH * OW, nbytes=4 * (x.numel() + dy.numel() + dw.numel())):
         st = lib().indm_conv2d_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), N, H, W, Ci, Co, kh, kw, stride, pad, OH, OW,
                                          alpha, None, 0.0, _ptr(ws), SPLITK_WS_FLOATS, _stream())
     _chk(st, "indm_conv2d_wgrad_f32")
