@@ -16,6 +16,7 @@
 //   * XCD-aware tile order: the N-tiles that share an A row-panel land on one XCD's L2
 //   * optional split-K into a caller-provided workspace (deterministic reduce kernel)
 #include "indm_common.h"
+#include <cstdlib>
 #include <stdlib.h>
 
 namespace {
@@ -546,10 +547,12 @@ int choose_splitk(int M, int N, int K, int batch, long ws_floats) {
   long tiles = (long)cdiv(M, (N <= 32 && M > 32) ? 128 : (M <= 128 ? 32 : 128)) *
                cdiv(N, (N <= 32 && M > 32) ? 32 : 128) * batch;
   if (tiles >= 256 || K < 4 * BK * 8) return 1;
-  long want = (1024 + tiles - 1) / tiles;
+  static const long target = getenv("INDM_SPLITK_TARGET") ? atol(getenv("INDM_SPLITK_TARGET")) : 1024;
+  long want = (target + tiles - 1) / tiles;
   long maxs = K / (BK * 8);
   if (want > maxs) want = maxs;
-  if (want > 256) want = 256;
+  static const long cap = getenv("INDM_SPLITK_MAX") ? atol(getenv("INDM_SPLITK_MAX")) : 256;
+  if (want > cap) want = cap;
   while (want > 1 && (long)want * batch * M * N > ws_floats) --want;
   return want < 1 ? 1 : (int)want;
 }

@@ -1079,3 +1079,125 @@ def ode_sampler(Ps, Pf, cfg, sde, shape, rng, eps, rtol=1e-5, atol=1e-5, tempera
             _, x = rd_predictor(sde, score_fn, x, vec_eps, rng, next_t=torch.zeros_like(vec_eps), probability_flow=False)
         after, _ = flow_forward(Pf, cfg, x * temperature, log_det=None, reverse=True, rng=rng, iters=iters)
         return inverse_scaler(cfg, x), inverse_scaler(cfg, after), sol.nfev
+
+
+def _pc_updates(cfg, sde, score_fn, rng):
+    """shared_{corrector,predictor}_update_fn sampling.py:343-362 for the registries the configs select."""
+    pred, corr = cfg.sampling.predictor.lower(), cfg.sampling.corrector.lower()
+
+    def corrector(x, vec_t, snr):
+        if corr == "langevin":
+            return langevin_corrector(sde, score_fn, x, vec_t, rng, snr, cfg.sampling.n_steps_each)
+        return x, x
+
+    def predictor(x, vec_t, vec_next_t):
+        if pred == "euler_maruyama":
+            return em_predictor(sde, score_fn, x, vec_t, rng)
+        if pred == "reverse_diffusion":
+            return rd_predictor(sde, score_fn, x, vec_t, rng, vec_next_t, cfg.sampling.probability_flow)
+        return x, x
+
+    return corrector, predictor
+
+
+def denoise_update_fn(sde, score_fn, x, rng, eps, final_time):  # sampling.py:402-408
+    vec_eps = torch.ones(x.shape[0]) * eps
+    return rd_predictor(sde, score_fn, x, vec_eps, rng, torch.ones_like(vec_eps) * final_time,
+                        probability_flow=True)[1]
+
+
+def _finish_sampler(Pf, cfg, before, temperature, rng, iters):
+    after, _ = flow_forward(Pf, cfg, before * temperature, log_det=None, reverse=True, rng=rng, iters=iters)
+    return inverse_scaler(cfg, before), inverse_scaler(cfg, after)
+
+
+def pc_sampler_search(Ps, Pf, cfg, sde, shape, rng, eps, temperature=1.0, data_mean=None, final_time=0.0,
+                      before_data=None, iters=None):
+    """get_pc_sampler.pc_sampler_search sampling.py:458-495 (selected by sampling.pc_denoise)"""
+    with torch.no_grad():
+        score_fn = get_score_fn(Ps, cfg, sde, train=False)
+        corrector, predictor = _pc_updates(cfg, sde, score_fn, rng)
+        if before_data is None:
+            x = sde.prior_sampling(shape, rng, data_mean)
+            timesteps = torch.linspace(sde.T, eps, sde.N)
+            x_mean = x
+            for i in range(sde.N - 1):
+                vec_t = torch.ones(shape[0]) * timesteps[i]
+                vec_next_t = torch.ones(shape[0]) * timesteps[i + 1]
+                x, x_mean = corrector(x, vec_t, cfg.sampling.snr)
+                x, x_mean = predictor(x, vec_t, vec_next_t)
+        else:
+            x_mean = x = before_data
+        denoise = cfg.sampling.noise_removal
+        if not cfg.sampling.need_sample:
+            x_mean = x = denoise_update_fn(sde, score_fn, x_mean if denoise else x, rng, eps, final_time)
+        before, after = _finish_sampler(Pf, cfg, x_mean if denoise else x, temperature, rng, iters)
+        return before, after, sde.N * (cfg.sampling.n_steps_each + 1)
+
+
+def pc_sampler_more_step(Ps, Pf, cfg, sde, shape, rng, eps, temperature=1.0, data_mean=None, final_time=0.0,
+                         before_data=None, iters=None):
+    """get_pc_sampler.pc_sampler_more_step sampling.py:497-535 (selected by sampling.more_step)"""
+    with torch.no_grad():
+        score_fn = get_score_fn(Ps, cfg, sde, train=False)
+        corrector, predictor = _pc_updates(cfg, sde, score_fn, rng)
+        if before_data is None:
+            # the reference calls corrector_update_fn without `snr` here (sampling.py:512) -> TypeError on step 0
+            raise TypeError("shared_corrector_update_fn() missing 1 required positional argument: 'snr'")
+        x_mean = x = before_data
+        if not cfg.sampling.need_sample:
+            timesteps = torch.exp(torch.linspace(np.log(1e-3), np.log(1e-5), 100))
+            for i in range(100):
+                vec_t = torch.ones(shape[0]) * timesteps[i]
+                x, x_mean = corrector(x, vec_t, cfg.sampling.snr)
+                x, x_mean = predictor(x, vec_t, None)
+        before, after = _finish_sampler(Pf, cfg, x_mean if cfg.sampling.noise_removal else x, temperature, rng, iters)
+        return before, after, sde.N * (cfg.sampling.n_steps_each + 1)
+
+
+def get_bpd(Ps, Pf, cfg, sde, eval_batches, rng, eval=False, rtol=1e-5, atol=1e-5):
+    """evaluation.get_bpd evaluation.py:388-494: `num_nelbo` NELBO passes, then NLL "wrong" (residual=False) and
+    "correct" (residual=True) at eps_bpd, then at the training truncation time if that differs from 1e-5.
+    eval_batches: list of [B,C,H,W] tensors in [0,1].  Returns the means the reference logs and every call's output."""
+    num_data = cfg.eval.num_test_data if eval else 10000
+    scale = (lambda x: x * 2.0 - 1.0) if cfg.data.centered else (lambda x: x)
+    res, calls = {}, []
+
+    def batches(n):
+        it = iter(eval_batches)
+        for _ in range((n - 1) // cfg.eval.batch_size + 1):
+            try:
+                b = next(it)
+            except StopIteration:  # datasets.get_batch restarts the iterator (datasets.py:106-113)
+                it = iter(eval_batches)
+                b = next(it)
+            yield scale((255.0 * b + rng.rand(*b.shape)) / 256.0)
+
+    full, full_r = [], []
+    for _ in range(cfg.eval.num_nelbo):
+        a, r = [], []
+        for b in batches(num_data):
+            n1, n2 = nelbo_fn(Ps, Pf, cfg, sde, b, rng)
+            calls.append(("nelbo", n1, n2))
+            a.extend(n1.numpy().reshape(-1)); r.extend(n2.numpy().reshape(-1))
+        full.append(np.mean(a)); full_r.append(np.mean(r))
+    res["nelbo_bpd_per_eval"], res["nelbo_residual_bpd_per_eval"] = full, full_r
+    res["nelbo_bpd"], res["nelbo_residual_bpd"] = np.mean(full), np.mean(full_r)
+    if not eval:
+        num_data = num_data // 10
+    eps_bpd = 1e-5 if cfg.eval.truncation_time == -1.0 else cfg.eval.truncation_time
+
+    def nll_pass(residual, e):
+        v = []
+        for b in batches(num_data):
+            bpd, _, nfe = likelihood_fn(Ps, Pf, cfg, sde, b, rng, residual=residual, eps_bpd=e, rtol=rtol, atol=atol)
+            calls.append(("nll", bpd, (residual, e, nfe)))
+            v.extend(bpd.numpy().reshape(-1))
+        return np.mean(v)
+
+    if not cfg.eval.skip_nll_wrong:
+        res["nll_wrong_bpd"] = nll_pass(False, eps_bpd)
+    res["nll_correct_bpd"] = nll_pass(True, eps_bpd)
+    if cfg.training.truncation_time != 1e-5:
+        res["nll_correct_train_eps_bpd"] = nll_pass(True, cfg.training.truncation_time)
+    return res, calls

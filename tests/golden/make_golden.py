@@ -64,6 +64,9 @@ class Recorder:
         def rand(*a, **k):
             r = o["rand"](*a, **k); ev.append(("rand", r.detach().cpu().numpy().copy())); return r
 
+        def rand_like(x, **k):
+            r = o["rand_like"](x, **k); ev.append(("rand", r.detach().cpu().numpy().copy())); return r
+
         def randint_like(x, **k):
             r = o["randint_like"](x, **k)
             ev.append(("rademacher", (r.float() * 2 - 1).cpu().numpy().copy())); return r
@@ -71,12 +74,13 @@ class Recorder:
         def poisson(lam, n):
             r = o["poisson"](lam, n); ev.append(("poisson", np.asarray(r[0], dtype=np.int64))); return r
 
-        torch.randn, torch.randn_like, torch.rand = randn, randn_like, rand
+        torch.randn, torch.randn_like, torch.rand, torch.rand_like = randn, randn_like, rand, rand_like
         torch.randint_like, np.random.poisson = randint_like, poisson
         try:
             yield
         finally:
             torch.randn, torch.randn_like, torch.rand = o["randn"], o["randn_like"], o["rand"]
+            torch.rand_like = o["rand_like"]
             torch.randint_like, np.random.poisson = o["randint_like"], o["poisson"]
 
 
@@ -375,6 +379,147 @@ def golden_model(out_dir, name, cfg_name, patch):
     print(name, "done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
 
 
+# ----------------------------------------------------------------------------- section-8(f) rows: sampler variants,
+# the get_bpd evaluation protocol, a deeper score net, the CelebA (squeeze) flow
+def _load_fixture_weights(fixture, score, flow):
+    d = dict(np.load(os.path.join(HERE, fixture + ".npz")))
+    skip = {"t", "out", "gy", "gx", "raw_out"}
+    for pre, mod in (("score", score), ("flow", flow)):
+        sd = {}
+        for k, v in d.items():
+            if k.startswith(pre + "/") and k[len(pre) + 1:] not in skip and not k.startswith(pre + "/grad/"):
+                sd["module." + k[len(pre) + 1:]] = torch.from_numpy(v)
+        mod.load_state_dict(sd)
+    return d
+
+
+class _TfBatch:
+    """what `datasets.get_batch_` (datasets.py:115-128) expects from a TFDS iterator: batch['image']._numpy()"""
+    def __init__(self, a):
+        self.a = a
+
+    def _numpy(self):
+        return self.a
+
+
+def golden_extra(out_dir):
+    import logging
+    out = {}
+    # ---- (f3) pc_sampler_search / denoise_update_fn / pc_sampler_more_step, VE mini, sde.N = 4 ----
+    cfg = mini(ref_import.get_config("configs.ve.CIFAR10.indm"))
+    score, flow = build(cfg, seed=1234)
+    _load_fixture_weights("mini_ve", score, flow)
+    cfg.model.num_scales = 4            # sde.N (the score net's `sigmas` buffer is only read by discrete-time models)
+    score.eval(); flow.eval()
+    sde = sde_lib.get_sde(cfg)
+    inverse_scaler = ref_datasets.get_data_inverse_scaler(cfg)
+    B = 2
+    shape = (B, 3, 32, 32)
+    cfg.sampling.method = "pc"
+    cfg.sampling.pc_denoise = True
+    cfg.sampling.need_sample = False
+    sampler = sampling.get_sampling_fn(cfg, sde, shape, inverse_scaler, cfg.sampling.truncation_time)
+    rec = Recorder()
+    with rec.on():
+        before, after, nfe = sampler(score, flow, final_time=0.0)
+    out["search/before"], out["search/after"], out["search/nfe"] = before.numpy(), after.numpy(), np.asarray(nfe)
+    pack_events("search", rec.events, out)
+    g = torch.Generator().manual_seed(11)
+    bd = torch.randn(shape, generator=g) * 0.5
+    out["search_bd/before_data"] = bd.numpy()
+    rec = Recorder()
+    with rec.on():
+        before, after, nfe = sampler(score, flow, final_time=5e-6, before_data=bd.clone(), temperature=0.9)
+    out["search_bd/before"], out["search_bd/after"] = before.numpy(), after.numpy()
+    pack_events("search_bd", rec.events, out)
+    cfg.sampling.need_sample = True     # no denoising step: before_data passes straight to the flow inverse
+    rec = Recorder()
+    with rec.on():
+        before, after, nfe = sampling.get_sampling_fn(cfg, sde, shape, inverse_scaler, cfg.sampling.truncation_time)(
+            score, flow, before_data=bd.clone())
+    out["search_ns/before"], out["search_ns/after"] = before.numpy(), after.numpy()
+    pack_events("search_ns", rec.events, out)
+    cfg.sampling.pc_denoise = False
+    cfg.sampling.more_step = True
+    cfg.sampling.need_sample = False
+    shape1 = (1, 3, 32, 32)
+    sampler = sampling.get_sampling_fn(cfg, sde, shape1, inverse_scaler, cfg.sampling.truncation_time)
+    rec = Recorder()
+    with rec.on():
+        before, after, nfe = sampler(score, flow, before_data=bd[:1].clone())
+    out["more_step/before"], out["more_step/after"] = before.numpy(), after.numpy()
+    pack_events("more_step", rec.events, out)
+    try:  # before_data=None: the reference's own loop is broken (sampling.py:512 omits snr; :510 indexes past the end)
+        sampler(score, flow)
+        out["more_step/none_raises"] = np.asarray("")
+    except Exception as e:  # noqa: BLE001
+        out["more_step/none_raises"] = np.asarray(type(e).__name__)
+
+    # ---- (f2) evaluation.get_bpd protocol, VP-NLL mini ----
+    ref_import._stub("cleanfid"); ref_import._stub("cleanfid.fid")
+    sys.modules["cleanfid"].fid = sys.modules["cleanfid.fid"]
+    tf = sys.modules["tensorflow"]
+    tf.float32, tf.function = "float32", (lambda f: f)
+    import evaluation
+    cfg = mini(ref_import.get_config("configs.vp.CIFAR10.indm_nll"))
+    score, flow = build(cfg, seed=1234)
+    _load_fixture_weights("mini_vp_nll", score, flow)
+    sde = sde_lib.get_sde(cfg)
+    inverse_scaler = ref_datasets.get_data_inverse_scaler(cfg)
+    scaler = ref_datasets.get_data_scaler(cfg)
+    cfg.eval.num_test_data = 4
+    cfg.eval.num_nelbo = 2
+    cfg.eval.batch_size = 2
+    cfg.eval.truncation_time = 1e-4
+    g = torch.Generator().manual_seed(21)
+    imgs = torch.randint(0, 256, (4, 32, 32, 3), generator=g).float() / 255.0   # NHWC in [0,1] as TFDS yields
+    out["bpd/images_nhwc"] = imgs.numpy()
+    eval_ds = [{"image": _TfBatch(imgs[i:i + 2].numpy())} for i in (0, 2)]
+    nelbo_fn = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=inverse_scaler)
+    nll_fn = likelihood.get_likelihood_fn(cfg, sde, inverse_scaler, rtol=1e-3, atol=1e-3)
+    calls = []
+
+    def nelbo_rec(*a, **k):
+        r = nelbo_fn(*a, **k); calls.append(("nelbo", r[0].detach().numpy().copy(), r[1].detach().numpy().copy())); return r
+
+    def nll_rec(*a, **k):
+        r = nll_fn(*a, **k)
+        calls.append(("nll", r[0].detach().numpy().copy(), np.asarray([float(k["residual"]), k["eps_bpd"], r[2]])))
+        return r
+
+    msgs = []
+
+    class H(logging.Handler):
+        def emit(self, record):
+            msgs.append(record.getMessage())
+
+    h = H(); logging.getLogger().addHandler(h); logging.getLogger().setLevel(logging.INFO)
+    rec = Recorder()
+    with rec.on():
+        evaluation.get_bpd(cfg, eval_ds, scaler, nelbo_rec, nll_rec, score, flow, step=7, eval=True)
+    logging.getLogger().removeHandler(h)
+    pack_events("bpd", rec.events, out)
+    for i, c in enumerate(calls):
+        out[f"bpd/call{i:02d}_{c[0]}_a"], out[f"bpd/call{i:02d}_{c[0]}_b"] = c[1], c[2]
+    out["bpd/n_calls"] = np.asarray(len(calls))
+    out["bpd/log"] = np.asarray([m for m in msgs if m.startswith("step:")])
+    out["bpd/flow_training_after"] = np.asarray(int(flow.training))
+
+    # ---- config #5 flavour: more than one residual block per resolution (num_res_for_upsampling = nrb+1) ----
+    cfg = mini(ref_import.get_config("configs.vp.CIFAR10.indm_nll"))
+    cfg.model.num_res_blocks = 2
+    score, _ = build(cfg, seed=77)
+    pack_sd("nrb2", score, out)
+    score.eval()
+    x = data_batch(cfg, 2, seed=9)
+    t = torch.tensor([0.2, 0.8])
+    out["nrb2_io/x"], out["nrb2_io/t"] = x.numpy(), t.numpy()
+    out["nrb2_io/raw_out"] = score(x, t * 999).detach().numpy()
+
+    np.savez_compressed(os.path.join(out_dir, "mini_extra.npz"), **out)
+    print("mini_extra done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
+
+
 def patch_vp_nll(cfg):
     pass
 
@@ -400,3 +545,5 @@ if __name__ == "__main__":
         golden_model(HERE, "mini_vp_fid", "configs.vp.CIFAR10.indm_fid", patch_vp_fid)
     if "ve" in which:
         golden_model(HERE, "mini_ve", "configs.ve.CIFAR10.indm", patch_ve)
+    if "extra" in which:
+        golden_extra(HERE)

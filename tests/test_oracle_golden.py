@@ -184,3 +184,107 @@ def test_two_training_steps(fx):
     for k, v in gu.sub(d, "after2/flow/buffers").items():
         gu.assert_close(fstate.P[k].float(), v.float(), 1e-5, 1e-6, k)
     assert [state.step, fstate.step, state.num_updates] == list(d["after2/steps"])
+
+
+# ----------------------------------------------------------------------------- SURVEY section 8(f) rows (mini_extra.npz)
+def _extra_ve():
+    d, w = gu.load("mini_extra"), gu.load("mini_ve")
+    cfg = gu.mini_config("mini_ve")
+    cfg.model.num_scales = 4
+    cfg.sampling.method = "pc"
+    return d, cfg, gu.state_dict(w, "score"), gu.state_dict(w, "flow")
+
+
+def test_pc_sampler_search_and_denoise():
+    d, cfg, Ps, Pf = _extra_ve()
+    cfg.sampling.pc_denoise, cfg.sampling.need_sample = True, False
+    sde = O.get_sde(cfg)
+    shape = (2, 3, 32, 32)
+    rng = O.ReplayRng(gu.events(d, "search"))
+    before, after, nfe = O.pc_sampler_search(Ps, Pf, cfg, sde, shape, rng, cfg.sampling.truncation_time)
+    assert rng.done() and nfe == int(d["search/nfe"])
+    gu.assert_close(before, d["search/before"], 1e-4, 1e-4, "search before")
+    gu.assert_close(after, d["search/after"], 1e-3, 1e-3, "search after")
+    rng = O.ReplayRng(gu.events(d, "search_bd"))
+    bd = torch.from_numpy(d["search_bd/before_data"])
+    before, after, _ = O.pc_sampler_search(Ps, Pf, cfg, sde, shape, rng, cfg.sampling.truncation_time,
+                                           temperature=0.9, final_time=5e-6, before_data=bd)
+    assert rng.done()
+    gu.assert_close(before, d["search_bd/before"], 1e-4, 1e-4, "search(before_data) before")
+    gu.assert_close(after, d["search_bd/after"], 1e-3, 1e-3, "search(before_data) after")
+    cfg.sampling.need_sample = True
+    rng = O.ReplayRng(gu.events(d, "search_ns"))
+    before, after, _ = O.pc_sampler_search(Ps, Pf, cfg, sde, shape, rng, cfg.sampling.truncation_time, before_data=bd)
+    assert rng.done()
+    gu.assert_close(before, d["search_ns/before"], 1e-5, 1e-5, "search(need_sample) before")
+    gu.assert_close(after, d["search_ns/after"], 1e-3, 1e-3, "search(need_sample) after")
+
+
+def test_pc_sampler_more_step():
+    d, cfg, Ps, Pf = _extra_ve()
+    cfg.sampling.more_step, cfg.sampling.need_sample = True, False
+    sde = O.get_sde(cfg)
+    rng = O.ReplayRng(gu.events(d, "more_step"))
+    bd = torch.from_numpy(d["search_bd/before_data"])[:1]
+    before, after, _ = O.pc_sampler_more_step(Ps, Pf, cfg, sde, (1, 3, 32, 32), rng, cfg.sampling.truncation_time,
+                                              before_data=bd)
+    assert rng.done()
+    gu.assert_close(before, d["more_step/before"], 1e-4, 1e-4, "more_step before")
+    gu.assert_close(after, d["more_step/after"], 1e-3, 1e-3, "more_step after")
+    assert str(d["more_step/none_raises"]) == "TypeError"
+    with pytest.raises(TypeError):
+        O.pc_sampler_more_step(Ps, Pf, cfg, sde, (1, 3, 32, 32), O.Rng(), cfg.sampling.truncation_time)
+
+
+def bpd_config():
+    cfg = gu.mini_config("mini_vp_nll")
+    cfg.eval.num_test_data, cfg.eval.num_nelbo, cfg.eval.batch_size, cfg.eval.truncation_time = 4, 2, 2, 1e-4
+    return cfg
+
+
+def parse_bpd_log(d):
+    """the means evaluation.get_bpd logged (evaluation.py:423-471), in order"""
+    import re
+    vals = {}
+    for line in [str(s) for s in d["bpd/log"]]:
+        m = re.search(r"mean (nelbo|nelbo_residual|nll) bpd: ([0-9.e+-]+)", line)
+        a = re.search(r"average nelbo bpd out of \d+ evaluations: ([0-9.e+-]+)", line)
+        if a:
+            vals.setdefault("avg", []).append(float(a.group(1)))
+        elif m:
+            tag = m.group(1) if m.group(1) != "nll" else ("nll_wrong" if "WRONG" in line else "nll_correct")
+            if "num samples: 4" in line:
+                vals.setdefault(tag, []).append(float(m.group(2)))
+    return vals
+
+
+def test_get_bpd_protocol():
+    d, w = gu.load("mini_extra"), gu.load("mini_vp_nll")
+    cfg = bpd_config()
+    Ps, Pf = gu.state_dict(w, "score"), gu.state_dict(w, "flow")
+    imgs = torch.from_numpy(d["bpd/images_nhwc"]).permute(0, 3, 1, 2).contiguous()
+    rng = O.ReplayRng(gu.events(d, "bpd"))
+    res, calls = O.get_bpd(Ps, Pf, cfg, O.get_sde(cfg), [imgs[:2], imgs[2:]], rng, eval=True, rtol=1e-3, atol=1e-3)
+    assert rng.done() and len(calls) == int(d["bpd/n_calls"])
+    for i, c in enumerate(calls):
+        gu.assert_close(c[1], d[f"bpd/call{i:02d}_{c[0]}_a"], 2e-4, 2e-4, f"get_bpd call {i} ({c[0]})")
+        if c[0] == "nelbo":
+            gu.assert_close(c[2], d[f"bpd/call{i:02d}_nelbo_b"], 2e-4, 2e-4, f"get_bpd call {i} residual")
+        else:
+            ref = d[f"bpd/call{i:02d}_nll_b"]
+            assert (float(c[2][0]), c[2][1], c[2][2]) == (ref[0], ref[1], int(ref[2]))
+    logged = parse_bpd_log(d)
+    assert np.allclose(res["nelbo_bpd_per_eval"], logged["nelbo"], rtol=2e-4)
+    assert np.allclose([res["nelbo_bpd"], res["nelbo_residual_bpd"]], logged["avg"], rtol=2e-4)
+    assert np.isclose(res["nll_wrong_bpd"], logged["nll_wrong"][-1], rtol=2e-4)
+    assert np.isclose(res["nll_correct_bpd"], logged["nll_correct"][-1], rtol=2e-4)
+    assert "nll_correct_train_eps_bpd" not in res      # training.truncation_time == 1e-5
+
+
+def test_deeper_score_net():
+    d = gu.load("mini_extra")
+    cfg = gu.mini_config("mini_vp_nll")
+    cfg.model.num_res_blocks = 2
+    P = gu.sub(d, "nrb2")
+    out = O.ncsnpp_forward(P, cfg, torch.from_numpy(d["nrb2_io/x"]), torch.from_numpy(d["nrb2_io/t"]) * 999)
+    gu.assert_close(out, d["nrb2_io/raw_out"], 1e-4, 1e-5, "nrb=2 score net")
