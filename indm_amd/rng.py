@@ -26,6 +26,10 @@ class DeviceRng:
     def randn(self, *shape):
         return torch.randn(*shape, device=self.device, generator=self.gen)
 
+    def rand(self, *shape):
+        """device uniforms (the dequantisation noise of evaluation.py:410)"""
+        return torch.rand(*shape, device=self.device, generator=self.gen)
+
     def rand_host(self, *shape):
         """[B] uniforms for the diffusion time (sde_lib.py:202); drawn on the host so the fp32 scalar
         schedule can be evaluated there without a device round trip."""
@@ -66,6 +70,9 @@ class ReplayRng:
 
     def randn(self, *shape):
         return self._next("randn", shape).to(self.device)
+
+    def rand(self, *shape):
+        return self._next("rand", shape).to(self.device)
 
     def rand_host(self, *shape):
         return self._next("rand", shape)

@@ -2,6 +2,7 @@
 
     get_sampling_fn(config, sde, shape, inverse_scaler, eps) -> sampler(model, flow_model, temperature=1.,
         data_mean=None, final_time=0., before_data=None, sample_dir=None, r=None) -> (before, after, nfe)
+(pc_sampler, pc_sampler_search [sampling.pc_denoise], pc_sampler_more_step [sampling.more_step], ode_sampler)
 
 Every predictor / corrector update is ONE fused kernel  x' = a[b]*x + b[b]*net_out + c[b]*z  whose per-image
 coefficients come from the host-side SDE schedule (sde_lib.py); the Langevin step size (two batch-mean norms)
@@ -100,20 +101,51 @@ def _d(v, x):
 
 def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1,
                    probability_flow=False, continuous=False, denoise=True, eps=1e-3, device="cuda"):
-    """sampling.py:365-456.  predictor in {'euler_maruyama','reverse_diffusion','none'}, corrector in
-    {'langevin','none'} (the registries of sampling.py:36-83 reduced to what the configs select)."""
+    """sampling.py:365-545.  predictor in {'euler_maruyama','reverse_diffusion','none'}, corrector in
+    {'langevin','none'} (the registries of sampling.py:36-83 reduced to what the configs select).  Returns
+    pc_sampler_search when sampling.pc_denoise, pc_sampler_more_step when sampling.more_step, else pc_sampler
+    (sampling.py:538-545)."""
+    B, C, H, W = shape
+
+    def prior(rng, data_mean):
+        x = rng.randn_image(B, C, H, W)                       # sde.prior_sampling (sde_lib.py:159-163/289-293)
+        if isinstance(sde, VESDE):
+            x = hip.axpby(x, None, float(sde.sigma_max), 0.0, float(data_mean or 0.0))
+        elif data_mean:
+            x = hip.axpby(x, None, 1.0, 0.0, float(data_mean))
+        return x
+
+    def corrector_update(st, x, vec_t, snr_):
+        if corrector == "langevin":
+            return st.langevin(x, vec_t, snr_, n_steps)
+        return x, x
+
+    def predictor_update(st, x, vec_t, vec_next_t):
+        if predictor == "euler_maruyama":
+            return st.em(x, vec_t)
+        if predictor == "reverse_diffusion":
+            return st.rd(x, vec_t, vec_next_t, probability_flow)
+        return x, x
+
+    def finish(before_nhwc, flow_model, temperature, rng, iters):
+        before = ops.to_nchw(before_nhwc)
+        if config.flow.model != "identity":
+            after, _ = flow_forward(config, flow_model, hip.axpby(before, None, float(temperature), 0.0),
+                                    log_det=None, reverse=True, rng=rng, iters=iters)
+        else:
+            after = before
+        return inverse_scaler(before), inverse_scaler(after), sde.N * (n_steps + 1)
+
+    def given(before_data):
+        return ops.to_nhwc(before_data.to(device).float())
 
     def pc_sampler(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
                    sample_dir=None, r=None, rng=None, iters=None):
+        """sampling.py:410-456 (the search-npz side write at :436-445 is file I/O of the caller's cache)"""
         rng = rng or DeviceRng(device)
         with torch.no_grad():
             num_scales = config.sampling.num_scales if config.sampling.num_scales != sde.N else sde.N
-            B, C, H, W = shape
-            x = rng.randn_image(B, C, H, W)                       # sde.prior_sampling (sde_lib.py:159-163/289-293)
-            if isinstance(sde, VESDE):
-                x = hip.axpby(x, None, float(sde.sigma_max), 0.0, float(data_mean or 0.0))
-            elif data_mean:
-                x = hip.axpby(x, None, 1.0, 0.0, float(data_mean))
+            x = prior(rng, data_mean)
             timesteps = torch.linspace(sde.T, eps, num_scales)
             st = _Stepper(config, sde, model, rng)
             x_mean = x
@@ -123,21 +155,59 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
                     snr_temp = config.sampling.snr
                 else:
                     snr_temp = config.sampling.begin_snr + (config.sampling.end_snr - config.sampling.begin_snr) * i / num_scales
-                if corrector == "langevin":
-                    x, x_mean = st.langevin(x, vec_t, snr_temp, n_steps)
-                if predictor == "euler_maruyama":
-                    x, x_mean = st.em(x, vec_t)
-                elif predictor == "reverse_diffusion":
-                    x, x_mean = st.rd(x, vec_t, None, probability_flow)
-            before = x_mean if denoise else x
-            before = ops.to_nchw(before)
-            if config.flow.model != "identity":
-                after, _ = flow_forward(config, flow_model, hip.axpby(before, None, float(temperature), 0.0),
-                                        log_det=None, reverse=True, rng=rng, iters=iters)
-            else:
-                after = before
-            return inverse_scaler(before), inverse_scaler(after), sde.N * (n_steps + 1)
+                x, x_mean = corrector_update(st, x, vec_t, snr_temp)
+                x, x_mean = predictor_update(st, x, vec_t, None)
+            return finish(x_mean if denoise else x, flow_model, temperature, rng, iters)
 
+    def denoise_update_fn(st, x, final_time):
+        """sampling.py:402-408: one reverse-diffusion probability-flow step from eps to final_time"""
+        vec_eps = torch.ones(B) * eps
+        return st.rd(x, vec_eps, torch.ones_like(vec_eps) * final_time, probability_flow=True)[1]
+
+    def pc_sampler_search(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
+                          sample_dir=None, r=None, rng=None, iters=None):
+        """sampling.py:458-495"""
+        rng = rng or DeviceRng(device)
+        with torch.no_grad():
+            st = _Stepper(config, sde, model, rng)
+            if before_data is None:
+                x = prior(rng, data_mean)
+                timesteps = torch.linspace(sde.T, eps, sde.N)
+                x_mean = x
+                for i in range(sde.N - 1):
+                    vec_t = torch.ones(B) * timesteps[i]
+                    vec_next_t = torch.ones(B) * timesteps[i + 1]
+                    x, x_mean = corrector_update(st, x, vec_t, config.sampling.snr)
+                    x, x_mean = predictor_update(st, x, vec_t, vec_next_t)
+            else:
+                x_mean = x = given(before_data)
+            if not config.sampling.need_sample:
+                x_mean = x = denoise_update_fn(st, x_mean if denoise else x, final_time)
+            return finish(x_mean if denoise else x, flow_model, temperature, rng, iters)
+
+    def pc_sampler_more_step(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
+                             sample_dir=None, r=None, rng=None, iters=None):
+        """sampling.py:497-535"""
+        rng = rng or DeviceRng(device)
+        with torch.no_grad():
+            st = _Stepper(config, sde, model, rng)
+            if before_data is None:
+                # the reference calls corrector_update_fn without its required `snr` here (sampling.py:512) and
+                # would index timesteps[sde.N] two lines above: same error, raised before any work is queued
+                raise TypeError("shared_corrector_update_fn() missing 1 required positional argument: 'snr'")
+            x_mean = x = given(before_data)
+            if not config.sampling.need_sample:
+                timesteps = torch.exp(torch.linspace(np.log(1e-3), np.log(1e-5), 100))
+                for i in range(100):
+                    vec_t = torch.ones(B) * timesteps[i]
+                    x, x_mean = corrector_update(st, x, vec_t, config.sampling.snr)
+                    x, x_mean = predictor_update(st, x, vec_t, None)
+            return finish(x_mean if denoise else x, flow_model, temperature, rng, iters)
+
+    if config.sampling.pc_denoise:
+        return pc_sampler_search
+    if config.sampling.more_step:
+        return pc_sampler_more_step
     return pc_sampler
 
 

@@ -520,6 +520,67 @@ def golden_extra(out_dir):
     print("mini_extra done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
 
 
+def golden_celeba(out_dir):
+    """BASELINE config #4 flavour: vp/CELEBA/indm_fid -- 64x64 images, flow.squeeze=True (the flow and its encoder
+    see the space-to-depth image [12,32,32]), imagenet/64x64 wolf JSON, two-phase flow_step_fn_fid."""
+    cfg = mini(ref_import.get_config("configs.vp.CELEBA.indm_fid"))
+    cfg.model.ch_mult = (1, 2, 2)       # 64 -> 32 -> 16: keeps one attention block (attn_resolutions = (16,))
+    out = {}
+    score, flow = build(cfg, seed=4321)
+    pack_sd("score", score, out)
+    pack_sd("flow", flow, out)
+    sde = sde_lib.get_sde(cfg)
+    B = 2
+    x = data_batch(cfg, B, seed=6)
+    out["x"] = x.numpy()
+    inverse_scaler = ref_datasets.get_data_inverse_scaler(cfg)
+    scaler = ref_datasets.get_data_scaler(cfg)
+    score.eval()
+    t = torch.tensor([0.25, 0.75])
+    out["score/t"] = t.numpy()
+    out["score/raw_out"] = score(x, t * 999).detach().numpy()
+    for mode in ("train", "eval"):
+        flow.train() if mode == "train" else flow.eval()
+        saved = {k: v.clone() for k, v in flow.state_dict().items()}
+        rec = Recorder()
+        with rec.on():
+            z, ld = flow_forward(cfg, flow, x.clone(), reverse=False)
+        out[f"flow_{mode}/z"], out[f"flow_{mode}/logdet_kl"] = z.detach().numpy(), ld.detach().numpy()
+        pack_events(f"flow_{mode}", rec.events, out)
+        flow.load_state_dict(saved)
+    flow.eval()
+    rec = Recorder()
+    with rec.on(), torch.no_grad():
+        xr, _ = flow_forward(cfg, flow, torch.tensor(out["flow_eval/z"]), log_det=None, reverse=True)
+    out["flow_reverse/x"] = xr.numpy()
+    pack_events("flow_reverse", rec.events, out)
+    nelbo_fn = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=inverse_scaler)
+    rec = Recorder()
+    with rec.on():
+        n1, n2 = nelbo_fn(score, flow, x.clone())
+    out["nelbo/bpd"], out["nelbo/bpd_residual"] = n1.detach().numpy(), n2.detach().numpy()
+    pack_events("nelbo", rec.events, out)
+    optimize_fn = losses.optimization_manager(cfg)
+    step_fn = losses.get_step_fn(cfg, sde, train=True, optimize_fn=optimize_fn, scaler=scaler)
+    state, fstate = make_states(cfg, score, flow)
+    score.train(); flow.train()
+    xb = data_batch(cfg, B, seed=100)
+    out["step0/x"] = xb.numpy()
+    rec = Recorder()
+    with rec.on():
+        l, ls, lf, lp = step_fn(state, fstate, xb)
+    for nm, v in (("loss", l), ("loss_score", ls), ("loss_flow", lf), ("loss_logp", lp)):
+        out[f"step0/{nm}"] = v.numpy()
+    pack_events("step0", rec.events, out)
+    for pre, mod, st in (("score", score, state), ("flow", flow, fstate)):
+        named = [(n[len("module."):], p.detach()) for n, p in mod.named_parameters()]
+        for k, v in tensor_stats(named).items():
+            out[f"after1/{pre}/stat/{k}"] = v
+    out["after1/steps"] = np.asarray([state["step"], fstate["step"], state["ema"].num_updates])
+    np.savez_compressed(os.path.join(out_dir, "mini_celeba.npz"), **out)
+    print("mini_celeba done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
+
+
 def patch_vp_nll(cfg):
     pass
 
@@ -547,3 +608,5 @@ if __name__ == "__main__":
         golden_model(HERE, "mini_ve", "configs.ve.CIFAR10.indm", patch_ve)
     if "extra" in which:
         golden_extra(HERE)
+    if "celeba" in which:
+        golden_celeba(HERE)

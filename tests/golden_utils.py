@@ -40,11 +40,15 @@ def events(d, prefix):
     return [(k[len(prefix) + 7:], d[k]) for k in keys]  # "prefix/evNNN_kind"
 
 
-CFG = {"mini_vp_nll": "vp/CIFAR10/indm_nll", "mini_vp_fid": "vp/CIFAR10/indm_fid", "mini_ve": "ve/CIFAR10/indm"}
+CFG = {"mini_vp_nll": "vp/CIFAR10/indm_nll", "mini_vp_fid": "vp/CIFAR10/indm_fid", "mini_ve": "ve/CIFAR10/indm",
+       "mini_celeba": "vp/CELEBA/indm_fid"}
 
 
 def mini_config(fixture):
-    return configs.mini(configs.get_config(CFG[fixture]))
+    cfg = configs.mini(configs.get_config(CFG[fixture]))
+    if fixture == "mini_celeba":
+        cfg.model.ch_mult = (1, 2, 2)   # as in make_golden.golden_celeba: 64 -> 32 -> 16, one attention block
+    return cfg
 
 
 def assert_close(a, b, rtol=1e-4, atol=1e-5, name=""):

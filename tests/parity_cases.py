@@ -186,3 +186,152 @@ def case_two_training_steps(fx, device, tol=1.0):
 
 ALL_CASES = [case_state_dict_roundtrip, case_score_network, case_flow_forward_modes, case_nelbo, case_pc_sampler,
              case_two_training_steps]
+
+
+# ----------------------------------------------------------------------------- SURVEY section 8(f) rows (mini_extra.npz)
+def _extra_ve(device):
+    d = gu.load("mini_extra")
+    _, cfg, score, fl = build("mini_ve", device)
+    cfg.model.num_scales = 4
+    cfg.sampling.method = "pc"
+    score.eval(); fl.eval()
+    return d, cfg, score, fl
+
+
+def case_pc_sampler_search(device, tol=1.0):
+    d, cfg, score, fl = _extra_ve(device)
+    cfg.sampling.pc_denoise, cfg.sampling.need_sample = True, False
+    sde = sde_lib.get_sde(cfg)
+    inv = utils.get_data_inverse_scaler(cfg)
+    shape = (2, 3, 32, 32)
+    fn = sampling.get_sampling_fn(cfg, sde, shape, inv, cfg.sampling.truncation_time, device=device)
+    assert fn.__name__ == "pc_sampler_search"
+    rng = ReplayRng(gu.events(d, "search"), device)
+    before, after, nfe = fn(score, fl, final_time=0.0, rng=rng)
+    assert rng.done() and nfe == int(d["search/nfe"])
+    gu.assert_close(before, d["search/before"], 2e-4 * tol, 2e-4 * tol, "search before")
+    gu.assert_close(after, d["search/after"], 2e-3 * tol, 2e-3 * tol, "search after")
+    bd = torch.from_numpy(d["search_bd/before_data"])
+    rng = ReplayRng(gu.events(d, "search_bd"), device)
+    before, after, _ = fn(score, fl, temperature=0.9, final_time=5e-6, before_data=bd, rng=rng)
+    assert rng.done()
+    gu.assert_close(before, d["search_bd/before"], 2e-4 * tol, 2e-4 * tol, "search(before_data) before")
+    gu.assert_close(after, d["search_bd/after"], 2e-3 * tol, 2e-3 * tol, "search(before_data) after")
+    cfg.sampling.need_sample = True
+    fn = sampling.get_sampling_fn(cfg, sde, shape, inv, cfg.sampling.truncation_time, device=device)
+    rng = ReplayRng(gu.events(d, "search_ns"), device)
+    before, after, _ = fn(score, fl, before_data=bd, rng=rng)
+    assert rng.done()
+    gu.assert_close(before, d["search_ns/before"], 1e-5, 1e-5, "search(need_sample) before")
+    gu.assert_close(after, d["search_ns/after"], 2e-3 * tol, 2e-3 * tol, "search(need_sample) after")
+
+
+def case_pc_sampler_more_step(device, tol=1.0):
+    import pytest
+    d, cfg, score, fl = _extra_ve(device)
+    cfg.sampling.more_step, cfg.sampling.need_sample = True, False
+    sde = sde_lib.get_sde(cfg)
+    fn = sampling.get_sampling_fn(cfg, sde, (1, 3, 32, 32), utils.get_data_inverse_scaler(cfg),
+                                  cfg.sampling.truncation_time, device=device)
+    assert fn.__name__ == "pc_sampler_more_step"
+    rng = ReplayRng(gu.events(d, "more_step"), device)
+    before, after, _ = fn(score, fl, before_data=torch.from_numpy(d["search_bd/before_data"])[:1], rng=rng)
+    assert rng.done()
+    gu.assert_close(before, d["more_step/before"], 5e-4 * tol, 5e-4 * tol, "more_step before")   # 100 chained steps
+    gu.assert_close(after, d["more_step/after"], 3e-3 * tol, 3e-3 * tol, "more_step after")
+    with pytest.raises(TypeError):          # what the reference itself raises for before_data=None
+        fn(score, fl)
+
+
+def case_get_bpd(device, tol=1.0):
+    import logging
+    import test_oracle_golden as tog
+    from indm_amd import evaluation
+    d = gu.load("mini_extra")
+    _, cfg, score, fl = build("mini_vp_nll", device)
+    ref = tog.bpd_config()
+    for k in ("num_test_data", "num_nelbo", "batch_size", "truncation_time"):
+        cfg.eval[k] = ref.eval[k]
+    sde = sde_lib.get_sde(cfg)
+    inv, scaler = utils.get_data_inverse_scaler(cfg), utils.get_data_scaler(cfg)
+    nelbo_fn = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=inv)
+    nll_fn = likelihood.get_likelihood_fn(cfg, sde, inv, rtol=1e-3, atol=1e-3)
+    imgs = d["bpd/images_nhwc"]
+    eval_ds = [{"image": imgs[i:i + 2]} for i in (0, 2)]       # TFDS-style NHWC batches
+    score.eval(); fl.train()
+    rng = ReplayRng(gu.events(d, "bpd"), device)
+    res = evaluation.get_bpd(cfg, eval_ds, scaler, nelbo_fn, nll_fn, score, fl, step=7, eval=True, rng=rng)
+    assert rng.done() and fl.training == bool(int(d["bpd/flow_training_after"]))
+    logged = tog.parse_bpd_log(d)
+    assert np.allclose(res["nelbo_bpd_per_eval"], logged["nelbo"], rtol=3e-4 * tol), (res, logged)
+    assert np.allclose(res["nelbo_residual_bpd_per_eval"], logged["nelbo_residual"], rtol=3e-4 * tol)
+    assert np.allclose([res["nelbo_bpd"], res["nelbo_residual_bpd"]], logged["avg"], rtol=3e-4 * tol)
+    assert np.isclose(res["nll_wrong_bpd"], logged["nll_wrong"][-1], rtol=1e-3 * tol), (res, logged)
+    assert np.isclose(res["nll_correct_bpd"], logged["nll_correct"][-1], rtol=1e-3 * tol), (res, logged)
+    assert "nll_correct_train_eps_bpd" not in res
+
+
+def case_deeper_score_net(device, tol=1.0):
+    d = gu.load("mini_extra")
+    cfg = gu.mini_config("mini_vp_nll")
+    cfg.model.num_res_blocks = 2
+    cfg.device = torch.device(device)
+    score = ncsnpp.NCSNpp(cfg)
+    score.load_reference_state_dict(gu.sub(d, "nrb2"))
+    score = score.to(device).eval()
+    out = score(torch.from_numpy(d["nrb2_io/x"]).to(device), (torch.from_numpy(d["nrb2_io/t"]) * 999).to(device))
+    gu.assert_close(out, d["nrb2_io/raw_out"], 2e-4 * tol, 2e-5 * tol, "nrb=2 score net")
+
+
+def case_celeba_squeeze(device, tol=1.0):
+    """BASELINE config #4 flavour: vp/CELEBA/indm_fid (64x64, flow.squeeze=True, two-phase fid step)."""
+    fx = "mini_celeba"
+    d, cfg, score, fl = build(fx, device)
+    sde = sde_lib.get_sde(cfg)
+    x = torch.from_numpy(d["x"]).to(device)
+    score.eval()
+    out = score(x, (torch.from_numpy(d["score/t"]) * 999).to(device))
+    gu.assert_close(out, d["score/raw_out"], 2e-4 * tol, 2e-5 * tol, "celeba score net")
+    for mode in ("train", "eval"):
+        fl.load_reference_state_dict(gu.state_dict(d, "flow"))
+        fl.train() if mode == "train" else fl.eval()
+        rng = ReplayRng(gu.events(d, f"flow_{mode}"), device)
+        with torch.no_grad():
+            z, ld = iflow.flow_forward(cfg, fl, x.clone(), reverse=False, rng=rng)
+        assert rng.done()
+        gu.assert_close(z, d[f"flow_{mode}/z"], 2e-5 * tol, 2e-5 * tol, f"celeba flow {mode} z")
+        gu.assert_close(ld, d[f"flow_{mode}/logdet_kl"], 5e-5 * tol, 2e-4 * tol, f"celeba flow {mode} logdet")
+    fl.load_reference_state_dict(gu.state_dict(d, "flow"))
+    fl.eval()
+    rng = ReplayRng(gu.events(d, "flow_reverse"), device)
+    with torch.no_grad():
+        xr, _ = iflow.flow_forward(cfg, fl, torch.from_numpy(d["flow_eval/z"]).to(device), log_det=None,
+                                   reverse=True, rng=rng)
+    assert rng.done()
+    gu.assert_close(xr, d["flow_reverse/x"], 2e-4 * tol, 2e-4 * tol, "celeba flow reverse")
+    fn = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=utils.get_data_inverse_scaler(cfg))
+    rng = ReplayRng(gu.events(d, "nelbo"), device)
+    b1, b2 = fn(score, fl, x, rng=rng)
+    assert rng.done()
+    gu.assert_close(b1, d["nelbo/bpd"], 2e-4 * tol, 2e-4 * tol, "celeba nelbo")
+    gu.assert_close(b2, d["nelbo/bpd_residual"], 2e-4 * tol, 2e-4 * tol, "celeba nelbo residual")
+    state, flow_state, _ = utils.build_states(cfg, score, fl, device)
+    step_fn = losses.get_step_fn(cfg, sde, train=True)
+    score.train(); fl.train()
+    rng = ReplayRng(gu.events(d, "step0"), device)
+    outs = step_fn(state, flow_state, torch.from_numpy(d["step0/x"]).to(device), rng=rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), outs):
+        gu.assert_close(v, d[f"step0/{nm}"], 5e-4 * tol, 2e-5 * tol, f"celeba step0 {nm}")
+    for pre, model in (("score", score), ("flow", fl)):
+        for n, p in model.named_parameters():
+            ref = torch.from_numpy(d[f"after1/{pre}/stat/{n}"]).double()
+            got = gu.stat(p)
+            scale = (ref[1].item() * p.numel()) ** 0.5 + 1e-12
+            assert abs(got[0] - ref[0]).item() <= 1e-4 * tol * scale + 2e-6, ("param sum " + n, got, ref)
+            assert abs(got[1] - ref[1]).item() <= 1e-4 * tol * ref[1].item() + 1e-9, ("param sumsq " + n, got, ref)
+    assert [state["step"], flow_state["step"], state["ema"].num_updates] == list(d["after1/steps"])
+
+
+EXTRA_CASES = [case_pc_sampler_search, case_pc_sampler_more_step, case_get_bpd, case_deeper_score_net,
+               case_celeba_squeeze]

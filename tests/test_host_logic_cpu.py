@@ -15,3 +15,8 @@ def test_case(case, fx, emulate_hip):
 
 def test_pf_ode(emulate_hip):
     pc.case_pf_ode("mini_vp_nll", "cpu")
+
+
+@pytest.mark.parametrize("case", pc.EXTRA_CASES, ids=lambda f: f.__name__)
+def test_extra_case(case, emulate_hip):
+    case("cpu")

@@ -288,3 +288,44 @@ def test_deeper_score_net():
     P = gu.sub(d, "nrb2")
     out = O.ncsnpp_forward(P, cfg, torch.from_numpy(d["nrb2_io/x"]), torch.from_numpy(d["nrb2_io/t"]) * 999)
     gu.assert_close(out, d["nrb2_io/raw_out"], 1e-4, 1e-5, "nrb=2 score net")
+
+
+def test_celeba_squeeze_config():
+    """BASELINE config #4 flavour (vp/CELEBA/indm_fid: 64x64, flow.squeeze, two-phase fid step) -- mini_celeba.npz"""
+    d, cfg = gu.load("mini_celeba"), gu.mini_config("mini_celeba")
+    assert cfg.flow.squeeze and cfg.data.image_size == 64
+    sde = O.get_sde(cfg)
+    x = torch.from_numpy(d["x"])
+    Ps = gu.state_dict(d, "score")
+    out = O.ncsnpp_forward(Ps, cfg, x, torch.from_numpy(d["score/t"]) * 999)
+    gu.assert_close(out, d["score/raw_out"], 1e-4, 1e-5, "celeba score net")
+    for mode in ("train", "eval"):
+        rng = O.ReplayRng(gu.events(d, f"flow_{mode}"))
+        with torch.no_grad():
+            z, ld = O.flow_forward(gu.state_dict(d, "flow"), cfg, x.clone(), training=(mode == "train"), rng=rng,
+                                   bn_updates={})
+        assert rng.done()
+        gu.assert_close(z, d[f"flow_{mode}/z"], 1e-5, 1e-5, f"celeba flow {mode} z")
+        gu.assert_close(ld, d[f"flow_{mode}/logdet_kl"], 2e-5, 1e-4, f"celeba flow {mode} logdet")
+    rng = O.ReplayRng(gu.events(d, "flow_reverse"))
+    with torch.no_grad():
+        xr, _ = O.flow_forward(gu.state_dict(d, "flow"), cfg, torch.from_numpy(d["flow_eval/z"]), log_det=None,
+                               reverse=True, rng=rng)
+    assert rng.done()
+    gu.assert_close(xr, d["flow_reverse/x"], 1e-4, 1e-4, "celeba flow reverse")
+    rng = O.ReplayRng(gu.events(d, "nelbo"))
+    b1, b2 = O.nelbo_fn(Ps, gu.state_dict(d, "flow"), cfg, sde, x, rng)
+    assert rng.done()
+    gu.assert_close(b1, d["nelbo/bpd"], 1e-4, 1e-4, "celeba nelbo")
+    gu.assert_close(b2, d["nelbo/bpd_residual"], 1e-4, 1e-4, "celeba nelbo residual")
+    state = O.OracleState(gu.state_dict(d, "score"), cfg.optim.lr, cfg.model.ema_rate, cfg)
+    fstate = O.OracleState(gu.state_dict(d, "flow"), cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    rng = O.ReplayRng(gu.events(d, "step0"))
+    outs = O.flow_step_fn_fid(cfg, sde, state, fstate, torch.from_numpy(d["step0/x"]), rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), outs):
+        gu.assert_close(v, d[f"step0/{nm}"], 2e-4, 1e-5, f"celeba step0 {nm}")
+    for pre, st in (("score", state), ("flow", fstate)):
+        for k in st.trainable:
+            gu.assert_close(gu.stat(st.P[k]), d[f"after1/{pre}/stat/{k}"], 1e-5, 1e-6, "param " + k)
+    assert [state.step, fstate.step, state.num_updates] == list(d["after1/steps"])

@@ -21,6 +21,12 @@ def test_pf_ode():
     pc.case_pf_ode("mini_vp_nll", "cuda")
 
 
+@pytest.mark.parametrize("case", pc.EXTRA_CASES, ids=lambda f: f.__name__)
+def test_extra_case(case):
+    """sampler variants, the get_bpd protocol, a deeper score net -- on the real kernels."""
+    case("cuda")
+
+
 def test_no_cpu_fallback():
     """The product path must refuse CPU tensors instead of silently falling back."""
     from indm_amd import hip
