@@ -16,8 +16,7 @@
 //   * XCD-aware tile order: the N-tiles that share an A row-panel land on one XCD's L2
 //   * optional split-K into a caller-provided workspace (deterministic reduce kernel)
 #include "indm_common.h"
-#include <cstdlib>
-#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -482,6 +481,359 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
   }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---- loaders of the big-tile kernel ---------------------------------------------------------------------------
+// Preconditions (checked on the host, big_tile_n): a_vec && b_vec, K % 16 == 0, conv reduction slabs never straddle
+// a tap.  Rows / columns beyond M / N are CLAMPED, not zeroed: they only feed accumulators whose results the
+// epilogue never stores, so the GEMM modes load unconditionally (no select that would drag the vmcnt wait up to
+// the load).  Only the zero padding of a convolution needs a predicate; it is an exec-masked load.
+template <int AM>
+__device__ __forceinline__ long a_off(const IgemmParams& p, int row, int k, const PixDec& rd, const int3& tapdec,
+                                      int kbase, bool& ok) {
+  ok = true;
+  if constexpr (AM == A_ROW) {
+    return (long)min(row, p.M - 1) * p.lda + k;
+  } else if constexpr (AM == A_COL) {
+    return (long)k * p.lda + min(row, p.M - 4);
+  } else if constexpr (AM == A_CONV) {
+    int ih = rd.oh * p.stride + tapdec.x - p.pad, iw = rd.ow * p.stride + tapdec.y - p.pad;
+    ok = ih >= 0 && iw >= 0;
+    if (p.dil > 1) {
+      ok = ok && ((ih % p.dil) | (iw % p.dil)) == 0;
+      ih /= p.dil;
+      iw /= p.dil;
+    }
+    ok = ok && ih < p.H && iw < p.W;
+    return (((long)rd.img * p.H + ih) * p.W + iw) * p.Cin + tapdec.z + (k - kbase);
+  } else {
+    const PixDec d = decode_pix(k, p.OH, p.OW);
+    const int ih = d.oh * p.stride + rd.img - p.pad, iw = d.ow * p.stride + rd.oh - p.pad;
+    ok = ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
+    return (((long)d.img * p.H + ih) * p.W + iw) * p.Cin + rd.ow;
+  }
+}
+
+template <int BMODE>
+__device__ __forceinline__ float4 b_fast(const IgemmParams& p, const float* B, int row, int k, const int2& btap,
+                                         int kbase) {
+  long off;
+  if constexpr (BMODE == B_ROW) {
+    off = (long)k * p.ldb + min(row, p.N - 4);
+  } else if constexpr (BMODE == B_COL) {
+    off = (long)min(row, p.N - 1) * p.ldb + k;
+  } else {
+    off = ((long)(p.KH * p.KW - 1 - btap.x) * p.N + min(row, p.N - 1)) * p.Cout + btap.y + (k - kbase);
+  }
+  return *(const float4*)(B + off);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// "Big tile" kernel for the long contractions (M*N large, no split-K): ONE wavefront per SIMD owning a 128 x 128
+// (or 128 x 64) register tile -- 256 (128) accumulator registers out of the 512-entry unified VGPR/AGPR file --
+// so one pass over a 16-deep LDS slab feeds 128 (64) MFMAs per wave between barriers instead of 32.  Four waves
+// (2 x 2) make a 256 x 256 (256 x 128) block tile; operand traffic per FLOP drops 1.33x vs the 8-wave 256 x 128
+// kernel and the LDS-read / barrier / global-load instruction counts per MFMA drop 2-4x.
+//
+// LDS images (double-buffered, every store is one ds_write_b128, every layout conflict-free):
+//   * k-contiguous operand (A_ROW, A_CONV, B_COL, B_DGRAD): [row][16 k], the four 16-byte k-chunks of a row
+//     XOR-swizzled with (row>>2)&3.  Fragments are read with ds_read_b128: lane (r, h) takes k-chunk 2*sg+h of
+//     row r and feeds component t of it to the t-th MFMA of k-group sg.
+//   * row-contiguous operand (A_COL, A_WGRAD, B_ROW): [k][rows+4], fragments by ds_read_b32 of row
+//     8*sg + 4*h + t -- the SAME k as the k-contiguous operand supplies in that MFMA.
+// The MFMA only sums over k, so any bijection lane-half/step -> k is valid as long as A and B agree; that frees
+// the k-contiguous operands from transposing LDS writes.
+template <int AM, int BMODE, int TN, bool HAS_G>
+__global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(IgemmParams p) {
+  static_assert(BK == 16, "big-tile kernel is written for 16-deep slabs");
+  constexpr int TM = 256, NT = 256;
+  constexpr int WN = TN / 2;
+  constexpr int RM = 4, RN = WN / 32;
+  constexpr bool AK = a_kcontig<AM>(), BKC = b_kcontig<BMODE>();
+  constexpr int LDA_R = TM + 4, LDB_R = TN + 4;
+  constexpr int A_SZ = AK ? TM * BK : BK * LDA_R;
+  constexpr int B_SZ = BKC ? TN * BK : BK * LDB_R;
+  constexpr int NGA = TM * 4 / NT, NGB = TN * 4 / NT;  // float4 groups per thread per slab
+  constexpr int NMFMA = 4 * RM * RN;                   // MFMAs of one 8-deep k-group
+  constexpr int NITEMS = RM + RN + NGA + NGB;          // side-work items woven into one k-group
+  constexpr int STEP = NMFMA / NITEMS;
+  static_assert(STEP >= 1, "not enough MFMAs to hide the side work");
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+  float* As = smem;
+  float* Bs = smem + 2 * A_SZ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
+  const int lt = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int bz = blockIdx.y;
+  const float* A = p.A + (long)bz * p.sA;
+  const float* G = HAS_G ? p.G + (long)bz * p.sA : nullptr;
+  const float* B = p.B + (long)bz * p.sB;
+  const int nk = p.K / BK;
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2][NGA], rb[2][NGB], rg[2][HAS_G ? NGA : 1];  // two prefetch sets: slab s lives in set s&1
+  float4 fa[2][RM], fb[2][RN];                             // fragments of k-group 0 / 1
+  unsigned okmask[2] = {0u, 0u};                           // conv zero-padding predicates of the two prefetch sets
+
+  PixDec rowdec[NGA];
+#pragma unroll
+  for (int j = 0; j < NGA; ++j) {
+    const int g = tid + j * NT;
+    rowdec[j].img = rowdec[j].oh = rowdec[j].ow = 0;
+    if constexpr (AM == A_CONV) {
+      const int row = m0 + g / 4;
+      if (row < p.M) rowdec[j] = decode_pix(row, p.OH, p.OW);
+    } else if constexpr (AM == A_WGRAD) {
+      const int row = m0 + (g % (TM / 4)) * 4;
+      if (row < p.M) {
+        const int tap = row / p.Cin;
+        rowdec[j].ow = row - tap * p.Cin;
+        rowdec[j].img = tap / p.KW;
+        rowdec[j].oh = tap - rowdec[j].img * p.KW;
+      }
+    }
+  }
+
+  // ---- side-work items: each is one memory instruction plus its address arithmetic --------------------------
+  auto gl_a = [&](auto SET, int j, int kt) {  // global -> register set SET: A group j of slab kt
+    const int k0 = kt * BK;
+    int3 tapdec = make_int3(0, 0, 0);
+    if constexpr (AM == A_CONV) {
+      const int tap = k0 / p.Cin;
+      tapdec.z = k0 - tap * p.Cin;
+      tapdec.x = tap / p.KW;
+      tapdec.y = tap - tapdec.x * p.KW;
+    }
+    const int g = tid + j * NT;
+    bool ok;
+    long off;
+    if constexpr (AK) {
+      off = a_off<AM>(p, m0 + g / 4, k0 + (g % 4) * 4, rowdec[j], tapdec, k0, ok);
+    } else {
+      constexpr int Q = TM / 4;
+      off = a_off<AM>(p, m0 + (g % Q) * 4, k0 + g / Q, rowdec[j], tapdec, k0, ok);
+    }
+    if constexpr (AM == A_CONV || AM == A_WGRAD) {
+      // zero padding: fetch offset 0 instead and remember the predicate; the select happens at the LDS store, so no
+      // branch splits the MFMA stream and no wait is pulled up to the load
+      off = ok ? off : 0;
+      okmask[SET] = (okmask[SET] & ~(1u << j)) | ((ok ? 1u : 0u) << j);
+    }
+    ra[SET][j] = *(const float4*)(A + off);
+    if constexpr (HAS_G) rg[SET][j] = *(const float4*)(G + off);
+  };
+  auto gl_b = [&](auto SET, int j, int kt) {
+    const int k0 = kt * BK;
+    int2 btap = make_int2(0, 0);
+    if constexpr (BMODE == B_DGRAD) {
+      btap.x = k0 / p.Cout;
+      btap.y = k0 - btap.x * p.Cout;
+    }
+    const int g = tid + j * NT;
+    if constexpr (BKC) {
+      rb[SET][j] = b_fast<BMODE>(p, B, n0 + g / 4, k0 + (g % 4) * 4, btap, k0);
+    } else {
+      constexpr int Q = TN / 4;
+      rb[SET][j] = b_fast<BMODE>(p, B, n0 + (g % Q) * 4, k0 + g / Q, btap, k0);
+    }
+  };
+  auto st_a = [&](auto BUF, auto SET, int j) {  // register set SET -> LDS buffer BUF (gate multiplied in here)
+    float* as = As + BUF * A_SZ;
+    const int g = tid + j * NT;
+    float4 v = ra[SET][j];
+    if constexpr (AM == A_CONV || AM == A_WGRAD) {
+      if (!((okmask[SET] >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (HAS_G) {
+      const float4 q = rg[SET][j];
+      v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w;
+    }
+    if constexpr (AK) {
+      const int row = g / 4, q = g % 4;
+      *(float4*)(as + row * BK + ((q ^ ((row >> 2) & 3)) << 2)) = v;
+    } else {
+      constexpr int Q = TM / 4;
+      *(float4*)(as + (g / Q) * LDA_R + (g % Q) * 4) = v;
+    }
+  };
+  auto st_b = [&](auto BUF, auto SET, int j) {
+    float* bs = Bs + BUF * B_SZ;
+    const int g = tid + j * NT;
+    if constexpr (BKC) {
+      const int row = g / 4, q = g % 4;
+      *(float4*)(bs + row * BK + ((q ^ ((row >> 2) & 3)) << 2)) = rb[SET][j];
+    } else {
+      constexpr int Q = TN / 4;
+      *(float4*)(bs + (g / Q) * LDB_R + (g % Q) * 4) = rb[SET][j];
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mw = wm * 128, nw = wn * WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int swz = (l31 >> 2) & 3;  // (row>>2)&3 of every fragment row this lane reads (tile bases are multiples of 32)
+
+  // fragments of the 8-deep k-group SG of LDS buffer BUF: component t feeds the t-th MFMA of the group
+  auto fr_a = [&](auto BUF, auto SG, int i) {
+    const float* as = As + BUF * A_SZ;
+    if constexpr (AK) {
+      fa[SG][i] = *(const float4*)(as + (mw + i * 32 + l31) * BK + (((SG * 2 + lhi) ^ swz) << 2));
+    } else {
+      const float* q = as + (SG * 8 + lhi * 4) * LDA_R + mw + i * 32 + l31;
+      fa[SG][i] = make_float4(q[0], q[LDA_R], q[2 * LDA_R], q[3 * LDA_R]);
+    }
+  };
+  auto fr_b = [&](auto BUF, auto SG, int j) {
+    const float* bs = Bs + BUF * B_SZ;
+    if constexpr (BKC) {
+      fb[SG][j] = *(const float4*)(bs + (nw + j * 32 + l31) * BK + (((SG * 2 + lhi) ^ swz) << 2));
+    } else {
+      const float* q = bs + (SG * 8 + lhi * 4) * LDB_R + nw + j * 32 + l31;
+      fb[SG][j] = make_float4(q[0], q[LDB_R], q[2 * LDB_R], q[3 * LDB_R]);
+    }
+  };
+  auto comp = [](const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; };
+
+  // One k-group of MFMAs on fragment set SG with `side(n)`, n = 0..NITEMS-1, woven in every STEP MFMAs.  With one
+  // wave per SIMD nobody else fills issue slots, so memory instructions must sit BETWEEN MFMAs (15 free issue
+  // slots under each 64-cycle MFMA), never in a burst after them; sched_barrier(0) pins the source order.
+  auto kgroup = [&](auto SG, auto&& side) {
+    static_for<0, NMFMA>([&](auto Q) {
+      constexpr int q = decltype(Q)::value;
+      constexpr int t = q / (RM * RN), i = (q / RN) % RM, j = q % RN;
+      const float a = comp(fa[SG][i], t), b = comp(fb[SG][j], t);
+      if constexpr (TN == 256) {
+        // 256 accumulators only fit the AGPR half of the register file: pin them there (hipcc would otherwise pick
+        // the VGPR-destination MFMA form and shuttle every accumulator through v_accvgpr_* each slab)
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(a), "v"(b));
+      } else {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+      }
+      if constexpr ((q + 1) % STEP == 0 && (q + 1) / STEP <= NITEMS) {
+        side(std::integral_constant<int, (q + 1) / STEP - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // Slab s (LDS buffer PAR = s&1):
+  //   k-group A: MFMAs on k-group 1 of slab s-1 | reads k-group 0 of slab s, fetches slab s+2 into set PAR
+  //   k-group B: MFMAs on k-group 0 of slab s   | reads k-group 1 of slab s, stores slab s+1 (set 1-PAR) to LDS
+  //   barrier
+  // Past the end of K the fetches are clamped to the last slab (valid memory, the copy is stored to the LDS buffer
+  // nobody reads any more), so the loop body has no tail variants.
+  auto slab = [&](auto PAR, int s) {
+    using OTH = std::integral_constant<int, 1 - decltype(PAR)::value>;
+    const int kt = min(s + 2, nk - 1);
+    kgroup(I1{}, [&](auto NC) {
+      constexpr int n = decltype(NC)::value;
+      if constexpr (n < RM) fr_a(PAR, I0{}, n);
+      else if constexpr (n < RM + RN) fr_b(PAR, I0{}, n - RM);
+      else if constexpr (n < RM + RN + NGA) gl_a(PAR, n - RM - RN, kt);
+      else gl_b(PAR, n - RM - RN - NGA, kt);
+    });
+    kgroup(I0{}, [&](auto NC) {
+      constexpr int n = decltype(NC)::value;
+      if constexpr (n < RM) fr_a(PAR, I1{}, n);
+      else if constexpr (n < RM + RN) fr_b(PAR, I1{}, n - RM);
+      else if constexpr (n < RM + RN + NGA) st_a(OTH{}, OTH{}, n - RM - RN);
+      else st_b(OTH{}, OTH{}, n - RM - RN - NGA);
+    });
+    __syncthreads();
+  };
+
+  // prologue: slab 0 -> LDS buffer 0, slab 1 -> set 1, slab 2 -> set 0; then "k-group B" of slab 0
+#pragma unroll
+  for (int j = 0; j < NGA; ++j) gl_a(I0{}, j, 0);
+#pragma unroll
+  for (int j = 0; j < NGB; ++j) gl_b(I0{}, j, 0);
+#pragma unroll
+  for (int j = 0; j < NGA; ++j) st_a(I0{}, I0{}, j);
+#pragma unroll
+  for (int j = 0; j < NGB; ++j) st_b(I0{}, I0{}, j);
+  {
+    const int k1 = min(1, nk - 1);
+#pragma unroll
+    for (int j = 0; j < NGA; ++j) gl_a(I1{}, j, k1);
+#pragma unroll
+    for (int j = 0; j < NGB; ++j) gl_b(I1{}, j, k1);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RM; ++i) fr_a(I0{}, I0{}, i);
+#pragma unroll
+  for (int j = 0; j < RN; ++j) fr_b(I0{}, I0{}, j);
+  {
+    const int k2 = min(2, nk - 1);
+#pragma unroll
+    for (int j = 0; j < NGA; ++j) gl_a(I0{}, j, k2);
+#pragma unroll
+    for (int j = 0; j < NGB; ++j) gl_b(I0{}, j, k2);
+  }
+  kgroup(I0{}, [&](auto NC) {
+    constexpr int n = decltype(NC)::value;
+    if constexpr (n < RM) fr_a(I0{}, I1{}, n);
+    else if constexpr (n < RM + RN) fr_b(I0{}, I1{}, n - RM);
+    else if constexpr (n < RM + RN + NGA) st_a(I1{}, I1{}, n - RM - RN);
+    else st_b(I1{}, I1{}, n - RM - RN - NGA);
+  });
+  __syncthreads();
+
+  for (int s = 1; s < nk; s += 2) {
+    slab(I1{}, s);
+    if (s + 1 < nk) slab(I0{}, s + 1);
+  }
+  kgroup(I1{}, [&](auto) {});  // k-group 1 of the last slab
+  if constexpr (TN == 256) {
+    // the accumulators were written by MFMAs the compiler cannot see: cover the XDL-write -> VALU-read hazard
+    // (18 wait states for a 16-pass MFMA) by hand before the epilogue reads them
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
+  }
+
+  float* C = p.C + (long)bz * p.sC;
+  const float* R = p.R ? p.R + (long)bz * p.sR : nullptr;
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int n = n0 + nw + j * 32 + l31;
+      if (n >= p.N) continue;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bn;
+        if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
+        v *= p.alpha;
+        if (R) v += p.beta * R[(long)m * p.ldr + n];
+        C[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
 // Deterministic split-K combine + epilogue.
 __global__ void igemm_splitk_reduce(IgemmParams p) {
   const long total = (long)p.batch * p.M * p.N;
@@ -510,11 +862,40 @@ inline bool use_tall_tile(const IgemmParams& p) {
   }
 }
 
+// Big-tile kernel eligibility: no split-K and enough 256-row tiles to give every CU work.  Returns the block tile
+// width (256 / 128) or 0.
+inline int big_tile_n(const IgemmParams& p) {
+  if (p.splitk != 1 || p.N < 64 || p.M < 1024 || !p.a_vec || !p.b_vec || (p.K & 15)) return 0;
+  int tn = (cdiv(p.N, 256) * 256 <= cdiv(p.N, 128) * 128) ? 256 : 128;
+  // 256-wide tiles leave one block per CU, so nothing overlaps a tile's prologue / epilogue: only worth it when the
+  // K loop is long (measured: K = 512 -> 106 TF at 256x256 vs 119 TF at 256x128; K = 4096 -> 142 vs 138)
+  if (tn == 256 && p.K < 1024) tn = 128;
+  if ((long)cdiv(p.M, 256) * cdiv(p.N, tn) * p.batch >= 224) return tn;
+  if (tn == 256 && (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224) return 128;
+  return 0;
+}
+
 template <int AM, int BMODE>
 int launch_tiles(const IgemmParams& p, hipStream_t st) {
   // tile choice: skinny N (flow 3/12-channel edges, last score conv) -> 128x32;
   // skinny M (27-/108-row weight grads) -> 32x128; everything else 128x128.
   dim3 block(256);
+  if constexpr (AM == A_ROW || (AM == A_CONV && BMODE == B_DGRAD)) {  // the long forward / data-grad contractions
+    // measured on MI355X (tools/dense_bench.py): the big tile wins on ungated plain GEMMs (+7-8 %) and on data-grad
+    // convolutions that fill 256x256 tiles (+7-14 %); gated GEMMs (two operand streams in flight do not fit the
+    // register budget) and B_ROW-weight convolutions stay on the 8-wave kernel.
+    const bool eligible = !p.G && (AM == A_ROW || (BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform)) &&
+                          (BMODE != B_ROW || (p.N & 3) == 0);
+    int btn = eligible ? big_tile_n(p) : 0;
+    if (AM == A_CONV && btn != 256) btn = 0;
+    if (btn) {
+      // one wave per SIMD with a 128x128 / 128x64 register tile (see igemm_big_kernel)
+      dim3 grid(cdiv(p.M, 256) * cdiv(p.N, btn), p.batch);
+      if (btn == 256) hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 256, false>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 128, false>), grid, block, 0, st, p);
+      return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+    }
+  }
   if (p.N <= 32 && p.M > 32) {
     dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 32), p.batch * p.splitk);
     hipLaunchKernelGGL((igemm_kernel<AM, BMODE, 128, 32, 4, 1>), grid, block, 0, st, p);
@@ -547,12 +928,10 @@ int choose_splitk(int M, int N, int K, int batch, long ws_floats) {
   long tiles = (long)cdiv(M, (N <= 32 && M > 32) ? 128 : (M <= 128 ? 32 : 128)) *
                cdiv(N, (N <= 32 && M > 32) ? 32 : 128) * batch;
   if (tiles >= 256 || K < 4 * BK * 8) return 1;
-  static const long target = getenv("INDM_SPLITK_TARGET") ? atol(getenv("INDM_SPLITK_TARGET")) : 1024;
-  long want = (target + tiles - 1) / tiles;
+  long want = (1024 + tiles - 1) / tiles;  // 512...1536 measured within noise of each other
   long maxs = K / (BK * 8);
   if (want > maxs) want = maxs;
-  static const long cap = getenv("INDM_SPLITK_MAX") ? atol(getenv("INDM_SPLITK_MAX")) : 256;
-  if (want > cap) want = cap;
+  if (want > 256) want = 256;
   while (want > 1 && (long)want * batch * M * N > ws_floats) --want;
   return want < 1 ? 1 : (int)want;
 }

@@ -167,7 +167,26 @@ def profile_stop():
     return out
 
 
-def _tile(M, N, amode="", batch=1, splitk=False):
+def _big_tile_n(M, N, K, batch):
+    """mirror of big_tile_n() in csrc/igemm.hip (only used to LABEL launches for the live profile)"""
+    if N < 64 or M < 1024 or K % 16:
+        return 0
+    tn = 256 if -(-N // 256) * 256 <= -(-N // 128) * 128 else 128
+    if tn == 256 and K < 1024:
+        tn = 128
+    if -(-M // 256) * -(-N // tn) * batch >= 224:
+        return tn
+    if tn == 256 and -(-M // 256) * -(-N // 128) * batch >= 224:
+        return 128
+    return 0
+
+
+def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
+    if not gated and not splitk and (amode == "A_ROW" or (amode == "A_CONV" and bmode == "B_DGRAD")) and \
+            (bmode != "B_ROW" or N % 4 == 0):
+        tn = _big_tile_n(M, N, K, batch)
+        if tn and (amode == "A_ROW" or tn == 256):
+            return f"big256x{tn}"
     if N <= 32 and M > 32:
         return "128x32"
     if M <= 128 and -(-M // 32) * -(-N // 128) * batch <= 512:
@@ -178,8 +197,8 @@ def _tile(M, N, amode="", batch=1, splitk=False):
 
 
 class _timed:
-    def __init__(self, amode, bmode, M, N, K, batch=1, splitk=False, nbytes=None):
-        self.key = f"igemm<{amode},{bmode},{_tile(M, N, amode, batch, splitk)}>"
+    def __init__(self, amode, bmode, M, N, K, batch=1, splitk=False, nbytes=None, gated=False):
+        self.key = f"igemm<{amode},{bmode},{_tile(M, N, K, amode, bmode, batch, splitk, gated)}>"
         self.flops = 2.0 * M * N * K * batch
         # algorithmic bytes: every operand read once, the result written once (conv callers pass the image size)
         self.bytes = float(nbytes) if nbytes is not None else 4.0 * batch * (M * K + K * N + M * N)
@@ -226,7 +245,8 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     ws = _ws(SPLITK_WS_FLOATS, a.device)  # split-K is decided inside (only when the tile count cannot fill the chip)
     nbytes = 4 * (a.numel() * (2 if gate is not None else 1) + b.numel() + out.numel()
                   + (res.numel() if res is not None else 0))
-    with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch, splitk, nbytes):
+    with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch, splitk, nbytes,
+                gated=gate is not None):
         st = lib().indm_gemm_f32(_ptr(a), _ptr(gate), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
                                  b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
                                  _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,

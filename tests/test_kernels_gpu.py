@@ -84,6 +84,39 @@ def test_gemm_epilogue_batched_splitk():
     close(out, ref, name="qk^t")
 
 
+# ---- big-tile kernel (igemm_big_kernel: 256x256 / 256x128 block tiles, one wave per SIMD) ----------------------
+@pytest.mark.parametrize("M,N,K,tb", [(28672 + 37, 512, 80, False), (28672 + 37, 512, 80, True),
+                                      (57344 + 5, 128, 48, False), (57344, 192, 16, True),
+                                      (30000, 500, 100, True), (29000, 260, 36, False)])
+def test_gemm_big_tile(M, N, K, tb):
+    a, g = rnd(M, K), rnd(M, K, seed=5)
+    b = rnd(N, K, seed=1) if tb else rnd(K, N, seed=1)
+    out, ref = run_both("gemm", a, b, trans_b=tb)
+    close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), name="big gemm")
+    rpg = M // 7 if M % 7 == 0 else M
+    bias, bias2, res = rnd(N, seed=2), rnd(M // rpg, N, seed=3), rnd(M, N, seed=4)
+    out, ref = run_both("gemm", a, b, trans_b=tb, gate=g, alpha=0.5, bias=bias, bias2=bias2, rows_per_group=rpg,
+                        res=res, beta=-1.5)
+    close(out, ref, rtol=1e-5, atol=1e-4, name="big gemm gated + epilogue")
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", [(64, 32, 32, 16, 128, 3, 1, 1), (32, 32, 32, 32, 512, 3, 1, 1),
+                                               (57, 32, 32, 16, 256, 1, 1, 0), (64, 32, 32, 32, 128, 3, 2, 1)])
+def test_conv_big_tile(N, H, W, Ci, Co, k, s, p):
+    x, w = rnd(N, H, W, Ci), rnd(k, k, Ci, Co, seed=1, scale=0.2)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    bias, bias2 = rnd(Co, seed=2), rnd(N, Co, seed=3)
+    out, ref = run_both("conv2d", x, w, stride=s, pad=p, bias=bias, bias2=bias2, alpha=0.7,
+                        res=rnd(N, OH, OW, Co, seed=9), beta=0.3)
+    close(out, ref, rtol=1e-5, atol=1e-4, name="big conv fwd")
+    # data gradient of a conv whose INPUT is the wide tensor: dy has Ci channels here, dx has Co
+    w2 = rnd(k, k, Co, Ci, seed=6, scale=0.2)
+    dy = rnd(N, OH, OW, Ci, seed=4)
+    out, r2 = run_both("conv2d_dgrad", dy, w2, (H, W), stride=s, pad=p, alpha=2.0, res=rnd(N, H, W, Co, seed=5),
+                       beta=0.5)
+    close(out, r2, rtol=1e-5, atol=1e-4, name="big conv dgrad")
+
+
 CONV_CASES = [
     # N, H, W, Ci, Co, k, stride, pad
     (2, 16, 16, 32, 64, 3, 1, 1),

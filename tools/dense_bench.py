@@ -20,6 +20,9 @@ M = B * 1024
 a, w = r(M, 512), r(512, 512)
 timeit(lambda: hip.gemm(a, w), 2*M*512*512, "gemm NN  [131072,512]x[512,512] (flow 1x1 fwd)")
 timeit(lambda: hip.gemm(a, w, trans_b=True), 2*M*512*512, "gemm NT  (flow 1x1 transposed / dgrad)")
+ga = r(M, 512)
+timeit(lambda: hip.gemm(a, w, trans_b=True, gate=ga), 2*M*512*512, "gemm NT gated (VJP chain)")
+timeit(lambda: hip.gemm(a, w, gate=ga), 2*M*512*512, "gemm NN gated")
 timeit(lambda: hip.gemm(a, a, trans_a=True, splitk=True), 2*M*512*512, "gemm TN  split-K (1x1 wgrad)")
 a4, w4 = r(4096, 4096), r(4096, 4096)
 timeit(lambda: hip.gemm(a4, w4), 2*4096**3, "gemm NN  4096^3 (reference point: guide's untuned kernel = 122 TF)")

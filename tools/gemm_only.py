@@ -1,17 +1,23 @@
-"""Run a few launches of one igemm shape (for rocprofv3 --pmc)."""
+"""Run a few launches of one contraction shape (for rocprofv3 --pmc).  usage: gemm_only.py MODE [M N K]
+MODE: nn | nt (igemm), vnn | vnt (vendor torch.matmul, reference point only), conv"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from indm_amd import hip
 mode = sys.argv[1] if len(sys.argv) > 1 else "nn"
-M = 128 * 1024
-a, w = torch.randn(M, 512, device="cuda"), torch.randn(512, 512, device="cuda")
-x, wt = torch.randn(128, 32, 32, 128, device="cuda"), torch.randn(3, 3, 128, 128, device="cuda")
+M, N, K = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (128 * 1024, 512, 512)
+a, w = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda")
+wt = w.t().contiguous()
+x, cw = torch.randn(128, 32, 32, 128, device="cuda"), torch.randn(3, 3, 128, 128, device="cuda")
 for _ in range(5):
     if mode == "nn":
         hip.gemm(a, w)
     elif mode == "nt":
-        hip.gemm(a, w, trans_b=True)
+        hip.gemm(a, wt, trans_b=True)
+    elif mode == "vnn":
+        torch.matmul(a, w)
+    elif mode == "vnt":
+        torch.matmul(a, wt.t())
     elif mode == "conv":
-        hip.conv2d(x, wt)
+        hip.conv2d(x, cw)
 torch.cuda.synchronize()
