@@ -43,14 +43,48 @@ def _usable_cores():
     return max(1, min(n, 32))
 
 
+class _RecordingRng:
+    """Oracle noise source that records every draw so the GPU path can be replayed on the same noise."""
+
+    def __init__(self, base):
+        self.base, self.events = base, []
+
+    def _rec(self, kind, v):
+        import numpy as np
+        self.events.append((kind, np.asarray(v.numpy() if torch.is_tensor(v) else v).copy()))
+        return v
+
+    def randn(self, *shape):
+        return self._rec("randn", self.base.randn(*shape))
+
+    def randn_like(self, x):
+        return self._rec("randn", self.base.randn_like(x))
+
+    def rand(self, *shape):
+        return self._rec("rand", self.base.rand(*shape))
+
+    def rademacher_like(self, x):
+        return self._rec("rademacher", self.base.rademacher_like(x))
+
+    def poisson(self, lam):
+        return int(self._rec("poisson", self.base.poisson(lam)))
+
+
 def cpu_baseline_child(path, batch):
-    """Child process: one full-size oracle training step on the host cores (bounded sample)."""
+    """Child process: one full-size oracle training step on the host cores (bounded sample), plus the oracle's NELBO
+    bits/dim of two synthetic images with the noise it drew (the parent replays that noise on the GPU)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import indm_oracle as O
     from indm_amd import configs
     torch.set_num_threads(_usable_cores())
     blob = torch.load(path)
     cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    torch.manual_seed(4242)
+    rec = _RecordingRng(O.Rng())
+    xe = synthetic_batch(2, cfg.data.image_size, 4242, "cpu")
+    t0 = time.time()
+    nb, nbr = O.nelbo_fn(blob["score"], blob["flow"], cfg, O.get_sde(cfg), xe, rec)
+    torch.save({"events": rec.events, "bpd": nb, "bpd_residual": nbr, "seconds": time.time() - t0}, path + ".nelbo")
     st = O.OracleState(blob["score"], cfg.optim.lr, cfg.model.ema_rate, cfg)
     fst = O.OracleState(blob["flow"], cfg.flow.lr, cfg.flow.ema_rate, cfg)
     x = synthetic_batch(batch, cfg.data.image_size, 999, "cpu")
@@ -78,10 +112,41 @@ def cpu_baseline(cfg, score, flow, batch=16, timeout=420):
             res = json.loads(line)
         except Exception as e:  # noqa: BLE001
             return {"value": None, "unit": "images/s", "cores": _usable_cores(), "kind": "port",
-                    "sample": f"oracle step at batch {batch} did not finish within {timeout}s ({type(e).__name__})"}
+                    "sample": f"oracle step at batch {batch} did not finish within {timeout}s ({type(e).__name__})"}, None
+        nelbo = torch.load(path + ".nelbo", weights_only=False) if os.path.exists(path + ".nelbo") else None
     return {"value": batch / res["dt"], "unit": "images/s", "cores": res["threads"], "kind": "port",
             "sample": f"1 full-size vp/CIFAR10/indm_nll train step at batch {batch} on the CPU oracle "
-                      f"(oracle/indm_oracle.py, torch CPU fp32, {res['threads']} threads): {res['dt']:.1f} s"}
+                      f"(oracle/indm_oracle.py, torch CPU fp32, {res['threads']} threads): {res['dt']:.1f} s"}, nelbo
+
+
+def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
+    """The metric's second half: NELBO bits/dim of the same weights on the HIP path -- replayed on the
+    noise the CPU oracle drew for two synthetic images (|difference| must stay inside the +-0.01 bits/dim north-star
+    band) -- and nelbo_fn's own throughput on a batch of 32."""
+    from indm_amd import likelihood, utils
+    from indm_amd.rng import DeviceRng, ReplayRng
+    fn = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=utils.get_data_inverse_scaler(cfg))
+    score.eval(); flow.eval()
+    out = {}
+    if oracle_nelbo is not None:
+        xe = synthetic_batch(2, cfg.data.image_size, 4242, dev)
+        got, got_r = fn(score, flow, xe, rng=ReplayRng(oracle_nelbo["events"], dev))
+        out.update(bpd=[float(v) for v in got], bpd_cpu_oracle=[float(v) for v in oracle_nelbo["bpd"]],
+                   max_abs_diff_bpd=float((got.cpu() - oracle_nelbo["bpd"]).abs().max()),
+                   max_abs_diff_residual_bpd=float((got_r.cpu() - oracle_nelbo["bpd_residual"]).abs().max()),
+                   cpu_oracle_images_per_s=2.0 / oracle_nelbo["seconds"])
+    xb = synthetic_batch(32, cfg.data.image_size, 777, dev)
+    rng = DeviceRng(dev, seed=5)
+    fn(score, flow, xb, rng=rng)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        fn(score, flow, xb, rng=rng)
+    torch.cuda.synchronize()
+    out["images_per_s"] = 3 * 32 / (time.time() - t0)
+    out["note"] = "random-init weights after the timed steps; eval-mode flow log-det (n+20 power-series terms)"
+    score.train(); flow.train()
+    return out
 
 
 def pmc_traffic(kernel_key):
@@ -201,7 +266,8 @@ def main():
         else:
             out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, score, flow)
+            out["cpu_baseline"], oracle_nelbo = cpu_baseline(cfg, score, flow)
+            out["nelbo"] = nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
