@@ -195,7 +195,8 @@ def main():
     score = utils.create_model(cfg, dev)
     flow = create_flow_model(cfg).to(dev)
     state, flow_state, flat_g = utils.build_states(cfg, score, flow, dev)
-    if world > 1:
+    dist_on = torch.distributed.is_initialized()
+    if dist_on:
         parallel.broadcast_parameters(state["optimizer"].flat.p)
         parallel.broadcast_parameters(flow_state["optimizer"].flat.p)
     sde = sde_lib.get_sde(cfg)
@@ -207,7 +208,7 @@ def main():
     rng = DeviceRng(dev, seed=1234 + rank)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -235,7 +236,7 @@ def main():
     barrier()
     elapsed = time.time() - t0
     prof = hip.profile_stop() if dominant else {}
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
@@ -271,7 +272,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

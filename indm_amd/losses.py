@@ -141,7 +141,7 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         state["optimizer"].zero_grad()
 
     def _reduce_and_step(states):
-        if allreduce is not None and world_size > 1:
+        if allreduce is not None:
             allreduce()
         for s in states:
             optimize_fn(s["optimizer"], None, step=s["step"],

@@ -18,7 +18,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("INDM_FORCE_DIST") == "1"  # exercise the RCCL path with a single rank (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -35,7 +36,7 @@ def init_distributed(backend=None):
 
 def make_allreduce(flat_grad, world_size):
     """Closure performing the step's single collective on the joint gradient buffer."""
-    if world_size <= 1:
+    if world_size <= 1 and not (dist.is_initialized() and os.environ.get("INDM_FORCE_DIST") == "1"):
         return None
 
     def allreduce():
@@ -51,5 +52,5 @@ def shard_batch(batch, rank, world_size):
 
 
 def broadcast_parameters(flat_params, src=0):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("INDM_FORCE_DIST") == "1"):
         dist.broadcast(flat_params, src=src)

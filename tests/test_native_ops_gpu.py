@@ -46,3 +46,22 @@ def test_fused_leaky_relu_golden_and_grads():
     out = m(g["x"].cuda())
     ref = torch.nn.functional.leaky_relu(g["x"], 0.1) * 2 ** 0.5
     gu.assert_close(out, ref, 1e-6, 1e-6, "FusedLeakyReLU slope 0.1 (CUDA-kernel semantics)")
+
+
+def test_bench_rccl_path_single_rank():
+    """bench.py under the driver's launcher with ONE rank and the RCCL path forced on: init_process_group(nccl,
+    device_id), parameter broadcast, the flat-gradient all_reduce, barrier + MAX-reduce of the timing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, INDM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                        "--gpus", "1", "--steps", "1", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
