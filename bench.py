@@ -182,6 +182,9 @@ def main():
     from indm_amd.rng import DeviceRng
 
     rank, world, local = parallel.init_distributed()
+    # host-side work per step is a few [B]-vector ops: keep every rank's intra-op pool small so N ranks on one host do
+    # not oversubscribe its cores
+    torch.set_num_threads(max(1, min(8, _usable_cores() // max(world, 1))))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X; there is no CPU fallback for the product path")
     dev = torch.device("cuda", local)

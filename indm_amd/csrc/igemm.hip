@@ -52,6 +52,7 @@ struct IgemmParams {
   float* ws;
   int a_vec, b_vec;
   int a_tap_uniform, b_tap_uniform;  // reduction slab of BK never straddles a tap (Cin % BK == 0)
+  int wg_inc;                        // A_WGRAD: pixel decode advanced incrementally (needs OH*OW >= BK)
 };
 
 struct PixDec {
@@ -186,7 +187,13 @@ __device__ __forceinline__ float4 a_group(const IgemmParams& p, const float* A, 
   } else {  // A_WGRAD, row-contiguous over ci; rowdec = (kh, kw, ci) of this row group (hoisted)
     if (p.a_vec) {
       if (row >= p.M || k >= kend) return v;
-      const PixDec d = decode_pix(k, p.OH, p.OW);
+      // the caller tracks (img, oh, ow) of this thread's reduction pixel incrementally (tapdec); see gload
+      PixDec d;
+      if (p.wg_inc) {
+        d.img = tapdec.x; d.oh = tapdec.y; d.ow = tapdec.z;
+      } else {
+        d = decode_pix(k, p.OH, p.OW);
+      }
       const int ih = d.oh * p.stride + rowdec.img - p.pad, iw = d.ow * p.stride + rowdec.oh - p.pad;
       if (ih < 0 || iw < 0 || ih >= p.H || iw >= p.W) return v;
       return *(const float4*)(A + (((long)d.img * p.H + ih) * p.W + iw) * p.Cin + rowdec.ow);
@@ -312,6 +319,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
     }
   }
 
+  // A_WGRAD: the reduction index is an output pixel; its (img, oh, ow) decode costs two integer divisions per
+  // load.  gload() is called for consecutive slabs, so each thread keeps the decode of its pixel and steps it by
+  // BK pixels per call (BK = sa*OW + sb; at most one carry each because OH*OW >= BK).
+  PixDec kdec[NGA];
+  const int wg_sa = (AM == A_WGRAD) ? BK / p.OW : 0, wg_sb = (AM == A_WGRAD) ? BK % p.OW : 0;
+  if constexpr (AM == A_WGRAD) {
+#pragma unroll
+    for (int j = 0; j < NGA; ++j) kdec[j] = decode_pix(kbeg + (tid + j * NT) / (TM / 4), p.OH, p.OW);
+  }
+
   auto gload = [&](int kt, float4 (&ra)[NGA], float4 (&rb)[NGB]) {
     const int k0 = kbeg + kt * BK;
     int3 tapdec = make_int3(0, 0, 0);
@@ -338,6 +355,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
           ra[j] = a_group<AM>(p, A, G, m0 + g / KG, k0 + (g % KG) * 4, kend, rowdec[j], tapdec, k0);
         } else {
           constexpr int Q = TM / 4;
+          if constexpr (AM == A_WGRAD) {
+            tapdec = make_int3(kdec[j].img, kdec[j].oh, kdec[j].ow);
+            kdec[j].ow += wg_sb;
+            kdec[j].oh += wg_sa;
+            if (kdec[j].ow >= p.OW) { kdec[j].ow -= p.OW; ++kdec[j].oh; }
+            if (kdec[j].oh >= p.OH) { kdec[j].oh -= p.OH; ++kdec[j].img; }
+          }
           ra[j] = a_group<AM>(p, A, G, m0 + (g % Q) * 4, k0 + g / Q, kend, rowdec[j], tapdec, k0);
         }
       }
@@ -1044,5 +1068,6 @@ INDM_API int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, i
   p.alpha = alpha; p.beta = beta; p.rpg = 1; p.R = R; p.ldr = Cout;
   p.a_vec = al16(x) && (Cin % 4 == 0);
   p.b_vec = al16(dy) && (Cout % 4 == 0);
+  p.wg_inc = (OH * OW >= BK);
   return run(p, A_WGRAD, B_ROW, ws, ws_floats, (hipStream_t)stream);
 }
