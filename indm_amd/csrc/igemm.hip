@@ -597,11 +597,13 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
   const int lt = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
-  const int bz = blockIdx.y;
+  const int z = blockIdx.y;
+  const int bz = z / p.splitk, kz = z - bz * p.splitk;
   const float* A = p.A + (long)bz * p.sA;
   const float* G = HAS_G ? p.G + (long)bz * p.sA : nullptr;
   const float* B = p.B + (long)bz * p.sB;
-  const int nk = p.K / BK;
+  const int kbeg = kz * p.kps;                         // split-K: this block reduces over [kbeg, kbeg + kps)
+  const int nk = (min(p.K, kbeg + p.kps) - kbeg) / BK;
 
   f32x16 acc[RM][RN];
 #pragma unroll
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
 
   // ---- side-work items: each is one memory instruction plus its address arithmetic --------------------------
   auto gl_a = [&](auto SET, int j, int kt) {  // global -> register set SET: A group j of slab kt
-    const int k0 = kt * BK;
+    const int k0 = kbeg + kt * BK;
     int3 tapdec = make_int3(0, 0, 0);
     if constexpr (AM == A_CONV) {
       const int tap = k0 / p.Cin;
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
     if constexpr (HAS_G) rg[SET][j] = *(const float4*)(G + off);
   };
   auto gl_b = [&](auto SET, int j, int kt) {
-    const int k0 = kt * BK;
+    const int k0 = kbeg + kt * BK;
     int2 btap = make_int2(0, 0);
     if constexpr (BMODE == B_DGRAD) {
       btap.x = k0 / p.Cout;
@@ -835,6 +837,23 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
       for (int j = 0; j < RN; ++j) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[i][j]));
   }
 
+  if (p.splitk > 1) {  // partial sums -> workspace slab z; igemm_splitk_reduce applies the epilogue
+    float* W = p.ws + ((long)z * p.M) * p.N;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        const int n = n0 + nw + j * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (m < p.M) W[(long)m * p.N + n] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   float* C = p.C + (long)bz * p.sC;
   const float* R = p.R ? p.R + (long)bz * p.sR : nullptr;
 #pragma unroll
@@ -963,8 +982,29 @@ int choose_splitk(int M, int N, int K, int batch, long ws_floats) {
 int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return INDM_OK;
   if (p.K < 0) return INDM_E_SHAPE;
-  p.splitk = ws ? choose_splitk(p.M, p.N, p.K, p.batch, ws_floats) : 1;
   p.ws = ws;
+  if (am == A_COL && bm == B_ROW && ws) {
+    // weight-grad GEMMs (tiny output, K = pixels): 256x256 big tiles, one block per CU, split-K sized to 256 blocks
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
+    if (p.M >= 256 && p.N >= 256 && !(p.M & 3) && !(p.N & 3) && !(p.K & 15) && p.a_vec && p.b_vec && tiles <= 64 &&
+        p.K >= 8192) {
+      long want = 256 / tiles;
+      while (want > 1 && (p.K / want < 512 || want * p.batch * p.M * p.N > ws_floats)) --want;
+      if (want > 1) {
+        int kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
+        p.kps = kps;
+        p.splitk = cdiv(p.K, kps);
+        dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, 256)), (unsigned)(p.batch * p.splitk));
+        if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
+        if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+        const long total = (long)p.batch * p.M * p.N;
+        hipLaunchKernelGGL(igemm_splitk_reduce, dim3(ew_grid(total, 256)), dim3(256), 0, st, p);
+        return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+      }
+    }
+  }
+  p.splitk = ws ? choose_splitk(p.M, p.N, p.K, p.batch, ws_floats) : 1;
   int kps = cdiv(p.K > 0 ? p.K : 1, p.splitk);
   kps = cdiv(kps, BK) * BK;
   p.kps = kps;

@@ -182,6 +182,10 @@ def _big_tile_n(M, N, K, batch):
 
 
 def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
+    if amode == "A_COL" and bmode == "B_ROW" and M >= 256 and N >= 256 and M % 4 == 0 and N % 4 == 0 and \
+            K % 16 == 0 and K >= 8192 and -(-M // 256) * -(-N // 256) * batch <= 64 and \
+            K // max(1, 256 // (-(-M // 256) * -(-N // 256) * batch)) >= 512:
+        return "big256x256"  # weight-grad GEMM on the big-tile split-K path
     if not gated and not splitk and (amode == "A_ROW" or (amode == "A_CONV" and bmode == "B_DGRAD")) and \
             (bmode != "B_ROW" or N % 4 == 0):
         tn = _big_tile_n(M, N, K, batch)

@@ -117,6 +117,16 @@ def test_conv_big_tile(N, H, W, Ci, Co, k, s, p):
     close(out, r2, rtol=1e-5, atol=1e-4, name="big conv dgrad")
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 24576), (256, 768, 16384), (512, 260, 40000 // 16 * 16)])
+def test_wgrad_gemm_big_tile_splitk(M, N, K):
+    """weight-grad GEMM (A stored [K,M]) on the 256x256 big-tile split-K path, with and without the gate"""
+    a, b, g = rnd(K, M), rnd(K, N, seed=1), rnd(K, M, seed=2)
+    out, ref = run_both("gemm", a, b, trans_a=True, splitk=True, alpha=0.5)
+    close(out, ref, rtol=1e-5, atol=3e-3, name="big wgrad")
+    out, ref = run_both("gemm", a, b, trans_a=True, splitk=True, gate=g)
+    close(out, ref, rtol=1e-5, atol=3e-3, name="big wgrad gated")
+
+
 CONV_CASES = [
     # N, H, W, Ci, Co, k, stride, pad
     (2, 16, 16, 32, 64, 3, 1, 1),
