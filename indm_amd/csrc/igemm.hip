@@ -1004,6 +1004,25 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       }
     }
   }
+  if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
+      p.K >= 16384) {
+    // convolution weight grads: same recipe on the implicit-GEMM A operand (256 x 256|128 tiles)
+    const int tn = (p.N % 256 == 0) ? 256 : 128;
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, tn);
+    long want = (tn == 256 ? 256 : 512) / tiles;
+    while (want > 1 && (p.K / want < 512 || want * p.M * p.N > ws_floats)) --want;
+    if (tiles <= 128 && want > 1) {
+      int kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
+      p.kps = kps;
+      p.splitk = cdiv(p.K, kps);
+      dim3 grid((unsigned)tiles, (unsigned)p.splitk);
+      if (tn == 256) hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 128, false>), grid, dim3(256), 0, st, p);
+      if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+      hipLaunchKernelGGL(igemm_splitk_reduce, dim3(ew_grid((long)p.M * p.N, 256)), dim3(256), 0, st, p);
+      return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+    }
+  }
   p.splitk = ws ? choose_splitk(p.M, p.N, p.K, p.batch, ws_floats) : 1;
   int kps = cdiv(p.K > 0 ? p.K : 1, p.splitk);
   kps = cdiv(kps, BK) * BK;

@@ -180,6 +180,17 @@ def test_conv2d_big_wgrad_splitk():
     close(out, ref, rtol=1e-5, atol=2e-3, name="wgrad splitk")
 
 
+@pytest.mark.parametrize("N,H,Ci,Co,k,s,p", [(32, 32, 32, 128, 3, 1, 1), (32, 32, 32, 256, 3, 1, 1),
+                                             (64, 16, 64, 256, 3, 1, 1), (40, 32, 256, 128, 1, 1, 0),
+                                             (32, 34, 32, 128, 3, 2, 0)])
+def test_conv2d_wgrad_big_tile(N, H, Ci, Co, k, s, p):
+    """convolution weight grads on the big-tile split-K path (256x128 and 256x256 tiles, strided, 1x1)"""
+    OH = (H + 2 * p - k) // s + 1
+    x, dy = rnd(N, H, H, Ci), rnd(N, OH, OH, Co, seed=1)
+    out, ref = run_both("conv2d_wgrad", x, dy, k, k, stride=s, pad=p, alpha=0.25)
+    close(out, ref, rtol=1e-5, atol=3e-3, name="big conv wgrad")
+
+
 @pytest.mark.parametrize("N,HW,C", [(2, (32, 32), 128), (3, (16, 16), 256), (2, (16, 16), 384), (2, (4, 4), 512),
                                     (4, (8, 8), 16), (2, (16, 16), 64)])
 @pytest.mark.parametrize("act", [0, 1])
