@@ -345,10 +345,20 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
     return dx
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
-    """Gradient of conv2d w.r.t. its RSCK weight. x [N,H,W,Ci], dy [N,OH,OW,Co] -> [KH,KW,Ci,Co]."""
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None):
+    """Gradient of conv2d w.r.t. its RSCK weight. x [N,H,W,Ci], dy [N,OH,OW,Co] -> [KH,KW,Ci,Co].
+    dy_gate (optional, dy's shape): computes with dy .* dy_gate; on the skinny-x form the gate rides on the GEMM's
+    operand loader (the wide tensor is read once, no gated copy is written)."""
     N, H, W, Ci = x.shape
     _, OH, OW, Co = dy.shape
+    if dy_gate is not None:
+        if _skinny(kh, kw, stride, pad, Ci, Co):
+            # (dy .* g)^T [Co x pixels] x xcol [pixels x 9*Ci]  ->  [Co, 9*Ci], transposed back to RSCK (tiny)
+            xcol = tap_spread(x, -1)
+            q = gemm(dy.reshape(-1, Co), xcol.reshape(-1, 9 * Ci), trans_a=True, alpha=alpha, splitk=True,
+                     gate=dy_gate.reshape(-1, Co))
+            return q.t().contiguous().view(3, 3, Ci, Co)
+        dy = mul(dy, dy_gate)
     if _skinny(kh, kw, stride, pad, Co, Ci):
         # weight grad with a skinny dy: spread dy over the 9 taps, then one [Ci x pixels] x [pixels x 9*Co] GEMM
         dycol = tap_spread(dy, 1, alpha)

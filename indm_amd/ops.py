@@ -152,8 +152,7 @@ class _Conv2dT(Function):
                 dv = hip.mul(dvg, gate) if ctx.needs_input_grad[0] else None
                 dgate = hip.mul(dvg, v) if ctx.needs_input_grad[5] else None
         if ctx.needs_input_grad[1]:
-            vg = v if gate is None else hip.mul(v, gate)
-            dw = hip.conv2d_wgrad(dt, vg, w.shape[0], w.shape[1], stride, pad)
+            dw = hip.conv2d_wgrad(dt, v, w.shape[0], w.shape[1], stride, pad, dy_gate=gate)
         return dv, dw, None, None, None, dgate
 
 

@@ -93,7 +93,9 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
     return dx.contiguous()
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0):
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None):
+    if dy_gate is not None:
+        dy = dy * dy_gate
     N, H, W, Ci = x.shape
     Co = dy.shape[-1]
     dw = torch.nn.grad.conv2d_weight(_nchw(x), (Co, Ci, kh, kw), _nchw(dy), stride, pad)

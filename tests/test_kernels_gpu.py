@@ -159,6 +159,13 @@ def test_conv2d_fwd_dgrad_wgrad(N, H, W, Ci, Co, k, s, p):
     close(out, r3, rtol=1e-5, atol=2e-4, name="conv wgrad")
 
 
+@pytest.mark.parametrize("Ci,Co", [(3, 64), (12, 64), (32, 48)])
+def test_conv2d_wgrad_gated(Ci, Co):
+    x, dy, g = rnd(2, 16, 16, Ci), rnd(2, 16, 16, Co, seed=1), rnd(2, 16, 16, Co, seed=2)
+    out, ref = run_both("conv2d_wgrad", x, dy, 3, 3, alpha=0.5, dy_gate=g)
+    close(out, ref, rtol=1e-5, atol=2e-4, name="wgrad gated")
+
+
 def test_tap_gather_spread():
     P = rnd(2, 6, 5, 27)
     bias = rnd(3, seed=1)
