@@ -186,6 +186,11 @@ def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
             K % 16 == 0 and K >= 8192 and -(-M // 256) * -(-N // 256) * batch <= 64 and \
             K // max(1, 256 // (-(-M // 256) * -(-N // 256) * batch)) >= 512:
         return "big256x256"  # weight-grad GEMM on the big-tile split-K path
+    if amode == "A_WGRAD" and M >= 256 and N >= 128 and N % 4 == 0 and K % 16 == 0 and K >= 16384:
+        tn = 256 if N % 256 == 0 else 128
+        tiles = -(-M // 256) * -(-N // tn)
+        if tiles <= 128 and K // max(1, (256 if tn == 256 else 512) // tiles) >= 512:
+            return f"big256x{tn}"  # convolution weight grad on the big-tile split-K path
     if not gated and not splitk and (amode == "A_ROW" or (amode == "A_CONV" and bmode == "B_DGRAD")) and \
             (bmode != "B_ROW" or N % 4 == 0):
         tn = _big_tile_n(M, N, K, batch)
