@@ -42,10 +42,12 @@ class RecordingRng(O.Rng):
 
 
 @pytest.mark.timeout(1500)
-def test_full_size_training_step_matches_oracle():
+@pytest.mark.parametrize("name", ["vp/CIFAR10/indm_nll", "ve/CIFAR10/indm"])
+def test_full_size_training_step_matches_oracle(name):
+    """vp: flow_step_fn_nll; ve: the two-phase flow_step_fn_fid with the FIR / Fourier-embedding NCSN++ (upfirdn2d)"""
     torch.manual_seed(7)
     np.random.seed(7)
-    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg = configs.get_config(name)
     cfg.model.dropout = 0.0
     cfg.training.batch_size = 2
     dev = torch.device("cuda")
@@ -64,7 +66,8 @@ def test_full_size_training_step_matches_oracle():
     ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
     rec = RecordingRng()
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    want = O.flow_step_fn_nll(cfg, O.get_sde(cfg), ost, ofst, x, rec)
+    ostep = O.flow_step_fn_nll if cfg.training.likelihood_weighting else O.flow_step_fn_fid
+    want = ostep(cfg, O.get_sde(cfg), ost, ofst, x, rec)
 
     state, fstate, _ = utils.build_states(cfg, score, fl, dev)
     step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
