@@ -8,6 +8,8 @@ Every predictor / corrector update is ONE fused kernel  x' = a[b]*x + b[b]*net_o
 coefficients come from the host-side SDE schedule (sde_lib.py); the Langevin step size (two batch-mean norms)
 is computed on the device without a host round trip.  The state stays NHWC in HBM for the whole loop.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -141,7 +143,7 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
 
     def pc_sampler(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
                    sample_dir=None, r=None, rng=None, iters=None):
-        """sampling.py:410-456 (the search-npz side write at :436-445 is file I/O of the caller's cache)"""
+        """sampling.py:410-456"""
         rng = rng or DeviceRng(device)
         with torch.no_grad():
             num_scales = config.sampling.num_scales if config.sampling.num_scales != sde.N else sde.N
@@ -157,6 +159,13 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
                     snr_temp = config.sampling.begin_snr + (config.sampling.end_snr - config.sampling.begin_snr) * i / num_scales
                 x, x_mean = corrector_update(st, x, vec_t, snr_temp)
                 x, x_mean = predictor_update(st, x, vec_t, None)
+                if i == num_scales - 2 and sample_dir is not None:
+                    # the start point pc_sampler_search resumes from (sampling.py:436-445; read back by
+                    # sampling_lib.get_samples for VE pc_denoise)
+                    snap = inverse_scaler(ops.to_nchw(x_mean)).permute(0, 2, 3, 1).cpu().numpy() * 255.0
+                    os.makedirs(sample_dir, exist_ok=True)
+                    with open(os.path.join(sample_dir, f"samples_{r}_before_flow_for_search.npz"), "wb") as f:
+                        np.savez_compressed(f, samples=snap)
             return finish(x_mean if denoise else x, flow_model, temperature, rng, iters)
 
     def denoise_update_fn(st, x, final_time):

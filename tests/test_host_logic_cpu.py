@@ -20,3 +20,45 @@ def test_pf_ode(emulate_hip):
 @pytest.mark.parametrize("case", pc.EXTRA_CASES, ids=lambda f: f.__name__)
 def test_extra_case(case, emulate_hip):
     case("cpu")
+
+
+def test_sampling_lib_cache(emulate_hip, tmp_path):
+    """sampling_lib.get_samples: first call samples and writes the reference's npz files, second call resumes from
+    them (flow inverse in chunks of 16), pc_denoise resumes from the for-search snapshot."""
+    import numpy as np
+    import torch
+    import golden_utils as gu
+    from indm_amd import sampling, sampling_lib, sde_lib, utils
+    d, cfg, score, fl = pc.build("mini_ve", "cpu")
+    cfg.model.num_scales = 4
+    cfg.sampling.method, cfg.sampling.num_scales = "pc", 3
+    score.eval(); fl.eval()
+    sde = sde_lib.get_sde(cfg)
+    inv, scaler = utils.get_data_inverse_scaler(cfg), utils.get_data_scaler(cfg)
+    shape = (16, 3, 32, 32)
+    fn = sampling.get_sampling_fn(cfg, sde, shape, inv, cfg.sampling.truncation_time, device="cpu")
+    sd, tsd = str(tmp_path / "samples"), str(tmp_path / "samples" / "t1")
+    torch.manual_seed(0)
+    b1, a1 = sampling_lib.get_samples(cfg, score, fl, fn, 3, 0, sd, 1.0, inv, tsd, scaler)
+    f = np.load(sd + "/samples_0_before_flow.npz")["samples"]
+    g = np.load(tsd + "/samples_0.npz")["samples"]
+    s = np.load(sd + "/samples_0_before_flow_for_search.npz")["samples"]
+    assert f.shape == g.shape == s.shape == (16, 32, 32, 3) and g.dtype == np.uint8 and f.dtype != np.uint8
+    assert np.allclose(f, b1.permute(0, 2, 3, 1).numpy() * 255.0)
+    assert np.array_equal(g, np.clip(a1.permute(0, 2, 3, 1).numpy() * 255.0, 0, 255).astype(np.uint8))
+    # second call: cached latents -> flow inverse in chunks of 16 -> same images (up to the fixed-point tolerance)
+    os_remove = __import__("os").remove
+    os_remove(tsd + "/samples_0.npz")
+    b2, a2 = sampling_lib.get_samples(cfg, score, fl, fn, 3, 0, sd, 1.0, inv, tsd, scaler)
+    from indm_amd.flow import flow_forward
+    with torch.no_grad():
+        want = inv(flow_forward(cfg, fl, scaler(b2), log_det=None, reverse=True)[0])
+    assert torch.allclose(b2, b1, rtol=1e-6, atol=1e-6 * float(b1.abs().max())) and torch.equal(a2, want)
+    assert __import__("os").path.exists(tsd + "/samples_0.npz")
+    # pc_denoise: resumes from the for-search snapshot with the denoising sampler
+    cfg.sampling.pc_denoise, cfg.sampling.need_sample, cfg.sampling.pc_denoise_time = True, False, 0.0
+    fn2 = sampling.get_sampling_fn(cfg, sde, shape, inv, cfg.sampling.truncation_time, device="cpu")
+    b3, a3 = sampling_lib.get_samples(cfg, score, fl, fn2, 3, 0, sd, 1.0, inv, tsd, scaler)
+    assert __import__("os").path.exists(sd + "/samples_0_before_flow_denoise_0.0.npz")
+    assert np.load(tsd + "/samples_0_denoise_0.0.npz")["samples"].dtype == np.uint8
+    assert b3.shape == a3.shape == shape
