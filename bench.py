@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = the headline (exact fp32 MFMA); bf16 = MFMA inputs rounded to bf16, fp32 accumulate "
+                         "(the dtype of BASELINE configs #3-#5; NOT the headline configuration)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -194,6 +197,7 @@ def main():
     cfg = configs.get_config("vp/CIFAR10/indm_nll")
     cfg.training.batch_size = args.batch * world
     cfg.device = dev
+    cfg.compute_dtype = args.dtype
     torch.manual_seed(cfg.seed)                     # default_cifar10_configs.py:126
     score = utils.create_model(cfg, dev)
     flow = create_flow_model(cfg).to(dev)
@@ -251,9 +255,11 @@ def main():
             "metric": "training images/sec, CIFAR-10 INDM (VP, NLL)",
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs/vp/CIFAR10/indm_nll.py train step (flow 16-16 idim 512 + NCSN++ nf128), "
-                                   f"batch {args.batch}/GPU, 32x32x3, fp32, dropout 0.1, random-init weights",
+                                   f"batch {args.batch}/GPU, 32x32x3, "
+                                   + ("fp32" if args.dtype == "f32" else "bf16 MFMA inputs / fp32 accumulate (NOT the "
+                                      "fp32 parity configuration)") + ", dropout 0.1, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "last_loss_mean": float(last[0].mean()) if last is not None else None},
         }
@@ -261,8 +267,9 @@ def main():
             p = prof[dominant]
             ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
             traffic, src = pmc_traffic(dominant)
-            out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0   # dense bf16 MFMA peak (same guide)
+            out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "traffic_source": src,
                                "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
                                "algorithmic_gflop_per_launch": p["flops"] / p["launches"] / 1e9,

@@ -75,6 +75,22 @@ int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, 
                           int KH, int KW, int stride, int pad, int OH, int OW, float alpha, const float* R,
                           float beta, float* ws, long ws_floats, void* stream);
 
+/* "bf16 compute / fp32 accumulate" variants (BASELINE configs #3-#5): identical contracts and fp32 tensors, but the
+ * MFMA inputs are rounded to bf16 (round-to-nearest-even) and multiplied with v_mfma_f32_32x32x16_bf16. */
+int indm_gemm_bf16(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
+                   int transB, long lda, long ldb, long ldc, int batch, long strideA, long strideB, long strideC,
+                   float alpha, const float* bias, const float* bias2, int rows_per_group, const float* R, long ldr,
+                   long strideR, float beta, float* ws, long ws_floats, void* stream);
+int indm_conv2d_fwd_bf16(const float* x, const float* w, float* y, int Nimg, int H, int W, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int in_dil, int OH, int OW, float alpha, const float* bias,
+                         const float* bias2, const float* R, float beta, float* ws, long ws_floats, void* stream);
+int indm_conv2d_dgrad_bf16(const float* dy, const float* w, float* dx, int Nimg, int H, int W, int Cin, int Cout,
+                           int KH, int KW, int pad_t, int in_dil, int OH, int OW, float alpha, const float* R,
+                           float beta, float* ws, long ws_floats, void* stream);
+int indm_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout,
+                           int KH, int KW, int stride, int pad, int OH, int OW, float alpha, const float* R,
+                           float beta, float* ws, long ws_floats, void* stream);
+
 /* ---- normalisation / softmax / reductions --------------------------------------------------------------- */
 
 /* GroupNorm(G, C, eps) [+SiLU] [+Philox dropout], fused.  Replaces nn.GroupNorm + nn.SiLU + nn.Dropout at

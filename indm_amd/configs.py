@@ -60,6 +60,9 @@ def _defaults(dataset):
                         intermediate_dim=512, resblock_type="resflow", squeeze=dataset != "CIFAR10", actnorm=False,
                         grad_in_forward=False, act_fn="sin")
     c.seed = 42
+    # not a reference key: 'f32' (exact fp32 MFMA, the parity gate) or 'bf16' (MFMA inputs rounded to bf16, fp32
+    # accumulate: the "bf16 compute / fp32 accum" of BASELINE configs #3-#5); applied by losses.get_step_fn & friends
+    c.compute_dtype = "f32"
     return c
 
 

@@ -20,6 +20,8 @@
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 #ifndef INDM_BK
 #define INDM_BK 16
 #endif
@@ -53,6 +55,7 @@ struct IgemmParams {
   int a_vec, b_vec;
   int a_tap_uniform, b_tap_uniform;  // reduction slab of BK never straddles a tap (Cin % BK == 0)
   int wg_inc;                        // A_WGRAD: pixel decode advanced incrementally (needs OH*OW >= BK)
+  int bf16;                          // MFMA inputs rounded to bf16 (RNE), fp32 accumulate (BASELINE configs #3-#5)
 };
 
 struct PixDec {
@@ -259,7 +262,11 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
   return base + idx;
 }
 
-template <int AM, int BMODE, int TM, int TN, int WAVES_M, int WAVES_N>
+// BF16: the "bf16 compute / fp32 accumulate" mode of BASELINE configs #3-#5.  Tensors stay fp32 in HBM and in LDS;
+// a fragment is 8 k-values per lane (k = 8*(lane/32) + t), rounded to bf16 with v_cvt_pk_bf16_f32 after the LDS read,
+// and ONE v_mfma_f32_32x32x16_bf16 per 16-deep slab replaces eight fp32 MFMAs (16x the MFMA rate; the kernel is then
+// bound by its operand traffic, not by the matrix pipe).
+template <int AM, int BMODE, int TM, int TN, int WAVES_M, int WAVES_N, bool BF16 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3 : 4)) void igemm_kernel(IgemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int RM = TM / WAVES_M / 32, RN = TN / WAVES_N / 32;
@@ -428,6 +435,25 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
   auto compute = [&](int buf, auto&& mid) {
     const float* as = As + buf * BK * LDA_S + mw + l31;
     const float* bs = Bs + buf * BK * LDB_S + nw + l31;
+    if constexpr (BF16) {
+      static_assert(BK == 16, "one bf16 MFMA k-step per slab");
+      bf16x8 fa[RM], fb[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fa[i][t] = (__bf16)as[(8 * lhi + t) * LDA_S + i * 32];
+#pragma unroll
+      for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fb[j][t] = (__bf16)bs[(8 * lhi + t) * LDB_S + j * 32];
+      mid();
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      return;
+    }
     float a[2][RM], b[2][RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i) a[0][i] = as[lhi * LDA_S + i * 32];
@@ -927,7 +953,7 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     // measured on MI355X (tools/dense_bench.py): the big tile wins on ungated plain GEMMs (+7-8 %) and on data-grad
     // convolutions that fill 256x256 tiles (+7-14 %); gated GEMMs (two operand streams in flight do not fit the
     // register budget) and B_ROW-weight convolutions stay on the 8-wave kernel.
-    const bool eligible = !p.G && (AM == A_ROW || (BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform)) &&
+    const bool eligible = !p.bf16 && !p.G && (AM == A_ROW || (BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform)) &&
                           (BMODE != B_ROW || (p.N & 3) == 0);
     int btn = eligible ? big_tile_n(p) : 0;
     if (AM == A_CONV && btn != 256) btn = 0;
@@ -939,21 +965,27 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
     }
   }
+#define INDM_LAUNCH(TMV, TNV, WMV, WNV, GRID, BLOCK)                                                         \
+  do {                                                                                                       \
+    if (p.bf16) hipLaunchKernelGGL((igemm_kernel<AM, BMODE, TMV, TNV, WMV, WNV, true>), GRID, BLOCK, 0, st, p);  \
+    else hipLaunchKernelGGL((igemm_kernel<AM, BMODE, TMV, TNV, WMV, WNV, false>), GRID, BLOCK, 0, st, p);      \
+  } while (0)
   if (p.N <= 32 && p.M > 32) {
     dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 32), p.batch * p.splitk);
-    hipLaunchKernelGGL((igemm_kernel<AM, BMODE, 128, 32, 4, 1>), grid, block, 0, st, p);
+    INDM_LAUNCH(128, 32, 4, 1, grid, block);
   } else if (p.M <= 128 && cdiv(p.M, 32) * cdiv(p.N, 128) * p.batch * p.splitk <= 512) {
     // short-M GEMMs (per-image vectors x weights): 32-row tiles so more than a handful of CUs get work
     dim3 grid(cdiv(p.M, 32) * cdiv(p.N, 128), p.batch * p.splitk);
-    hipLaunchKernelGGL((igemm_kernel<AM, BMODE, 32, 128, 1, 4>), grid, block, 0, st, p);
+    INDM_LAUNCH(32, 128, 1, 4, grid, block);
   } else if (use_tall_tile<AM>(p)) {
     // 8-wave 256x128 tile: +8-10 % on the long-M forward / data-grad contractions (measured)
     dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch * p.splitk);
-    hipLaunchKernelGGL((igemm_kernel<AM, BMODE, 256, 128, 4, 2>), grid, dim3(512), 0, st, p);
+    INDM_LAUNCH(256, 128, 4, 2, grid, dim3(512));
   } else {
     dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128), p.batch * p.splitk);
-    hipLaunchKernelGGL((igemm_kernel<AM, BMODE, 128, 128, 2, 2>), grid, block, 0, st, p);
+    INDM_LAUNCH(128, 128, 2, 2, grid, block);
   }
+#undef INDM_LAUNCH
   if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
   if (p.splitk > 1) {
     const long total = (long)p.batch * p.M * p.N;
@@ -983,7 +1015,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return INDM_OK;
   if (p.K < 0) return INDM_E_SHAPE;
   p.ws = ws;
-  if (am == A_COL && bm == B_ROW && ws) {
+  if (am == A_COL && bm == B_ROW && ws && !p.bf16) {
     // weight-grad GEMMs (tiny output, K = pixels): 256x256 big tiles, one block per CU, split-K sized to 256 blocks
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
     if (p.M >= 256 && p.N >= 256 && !(p.M & 3) && !(p.N & 3) && !(p.K & 15) && p.a_vec && p.b_vec && tiles <= 64 &&
@@ -1004,7 +1036,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       }
     }
   }
-  if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
+  if (am == A_WGRAD && bm == B_ROW && ws && !p.bf16 && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
       p.K >= 16384) {
     // convolution weight grads: same recipe on the implicit-GEMM A operand (256 x 256|128 tiles)
     const int tn = (p.N % 256 == 0) ? 256 : 128;
@@ -1050,13 +1082,14 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
 // C[b] = alpha * (opA(A[b] .* gateA[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]   (gateA optional)
 //   transA == 0: A is [M,K] row-major (lda);  transA == 1: A is stored [K,M] (lda)
 //   transB == 0: B is [K,N] row-major (ldb);  transB == 1: B is stored [N,K] (ldb)
-INDM_API int indm_gemm_f32(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
+static int gemm_f32_impl(int bf16, const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
                            int transB, long lda, long ldb, long ldc, int batch, long strideA,
                            long strideB, long strideC, float alpha, const float* bias,
                            const float* bias2, int rows_per_group, const float* R, long ldr,
                            long strideR, float beta, float* ws, long ws_floats, void* stream) {
   if (M < 0 || N < 0 || K < 0 || batch < 0) return INDM_E_SHAPE;
   IgemmParams p = {};
+  p.bf16 = bf16;
   p.A = A; p.G = gateA; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.batch = batch; p.sA = strideA; p.sB = strideB; p.sC = strideC;
@@ -1067,16 +1100,32 @@ INDM_API int indm_gemm_f32(const float* A, const float* gateA, const float* B, f
   p.b_vec = al16(B) && (ldb % 4 == 0) && (strideB % 4 == 0);
   return run(p, transA ? A_COL : A_ROW, transB ? B_COL : B_ROW, ws, ws_floats, (hipStream_t)stream);
 }
+INDM_API int indm_gemm_f32(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
+                           int transB, long lda, long ldb, long ldc, int batch, long strideA,
+                           long strideB, long strideC, float alpha, const float* bias,
+                           const float* bias2, int rows_per_group, const float* R, long ldr,
+                           long strideR, float beta, float* ws, long ws_floats, void* stream) {
+  return gemm_f32_impl(0, A, gateA, B, C, M, N, K, transA, transB, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, bias, bias2, rows_per_group, R, ldr, strideR, beta, ws, ws_floats, stream);
+}
+// same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
+INDM_API int indm_gemm_bf16(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
+                           int transB, long lda, long ldb, long ldc, int batch, long strideA,
+                           long strideB, long strideC, float alpha, const float* bias,
+                           const float* bias2, int rows_per_group, const float* R, long ldr,
+                           long strideR, float beta, float* ws, long ws_floats, void* stream) {
+  return gemm_f32_impl(1, A, gateA, B, C, M, N, K, transA, transB, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, bias, bias2, rows_per_group, R, ldr, strideR, beta, ws, ws_floats, stream);
+}
 
 // NHWC convolution forward:  y[n,oh,ow,co] = sum x[n, oh*s+kh-p, ow*s+kw-p, ci] * w[kh,kw,ci,co]
 // (cross-correlation, same as torch conv2d). `in_dil` > 1 treats x as zero-inserted
 // (used for the data-grad of strided convolutions). Weight layout is RSCK = [KH,KW,Cin,Cout].
-INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int Nimg, int H, int W,
+static int conv2d_fwd_f32_impl(int bf16, const float* x, const float* w, float* y, int Nimg, int H, int W,
                                  int Cin, int Cout, int KH, int KW, int stride, int pad, int in_dil,
                                  int OH, int OW, float alpha, const float* bias, const float* bias2,
                                  const float* R, float beta, float* ws, long ws_floats, void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return INDM_E_SHAPE;
   IgemmParams p = {};
+  p.bf16 = bf16;
   p.A = x; p.B = w; p.C = y;
   p.M = Nimg * OH * OW; p.N = Cout; p.K = KH * KW * Cin;
   p.ldb = Cout; p.ldc = Cout; p.batch = 1;
@@ -1089,16 +1138,30 @@ INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int N
   p.a_tap_uniform = (Cin % BK == 0);
   return run(p, A_CONV, B_ROW, ws, ws_floats, (hipStream_t)stream);
 }
+INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int Nimg, int H, int W,
+                                 int Cin, int Cout, int KH, int KW, int stride, int pad, int in_dil,
+                                 int OH, int OW, float alpha, const float* bias, const float* bias2,
+                                 const float* R, float beta, float* ws, long ws_floats, void* stream) {
+  return conv2d_fwd_f32_impl(0, x, w, y, Nimg, H, W, Cin, Cout, KH, KW, stride, pad, in_dil, OH, OW, alpha, bias, bias2, R, beta, ws, ws_floats, stream);
+}
+// same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
+INDM_API int indm_conv2d_fwd_bf16(const float* x, const float* w, float* y, int Nimg, int H, int W,
+                                 int Cin, int Cout, int KH, int KW, int stride, int pad, int in_dil,
+                                 int OH, int OW, float alpha, const float* bias, const float* bias2,
+                                 const float* R, float beta, float* ws, long ws_floats, void* stream) {
+  return conv2d_fwd_f32_impl(1, x, w, y, Nimg, H, W, Cin, Cout, KH, KW, stride, pad, in_dil, OH, OW, alpha, bias, bias2, R, beta, ws, ws_floats, stream);
+}
 
 // Data-grad of a stride-1 convolution (and, with in_dil = forward stride, of a strided one):
 //   dx[n,ih,iw,ci] = sum_{kh,kw,co} dy[n, ih+pad'-..] * w[KH-1-kh, KW-1-kw, ci, co]
 // dy: [Nimg,H,W,Cout] (H,W = dy spatial), dx: [Nimg,OH,OW,Cin].  pad' = K-1-pad_fwd.
-INDM_API int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, int H, int W,
+static int conv2d_dgrad_f32_impl(int bf16, const float* dy, const float* w, float* dx, int Nimg, int H, int W,
                                    int Cin, int Cout, int KH, int KW, int pad_t, int in_dil, int OH,
                                    int OW, float alpha, const float* R, float beta, float* ws, long ws_floats,
                                    void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return INDM_E_SHAPE;
   IgemmParams p = {};
+  p.bf16 = bf16;
   p.A = dy; p.B = w; p.C = dx;
   p.M = Nimg * OH * OW; p.N = Cin; p.K = KH * KW * Cout;
   p.ldc = Cin; p.batch = 1;
@@ -1110,15 +1173,29 @@ INDM_API int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, i
   p.a_tap_uniform = p.b_tap_uniform = (Cout % BK == 0);
   return run(p, A_CONV, B_DGRAD, ws, ws_floats, (hipStream_t)stream);
 }
+INDM_API int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int pad_t, int in_dil, int OH,
+                                   int OW, float alpha, const float* R, float beta, float* ws, long ws_floats,
+                                   void* stream) {
+  return conv2d_dgrad_f32_impl(0, dy, w, dx, Nimg, H, W, Cin, Cout, KH, KW, pad_t, in_dil, OH, OW, alpha, R, beta, ws, ws_floats, stream);
+}
+// same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
+INDM_API int indm_conv2d_dgrad_bf16(const float* dy, const float* w, float* dx, int Nimg, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int pad_t, int in_dil, int OH,
+                                   int OW, float alpha, const float* R, float beta, float* ws, long ws_floats,
+                                   void* stream) {
+  return conv2d_dgrad_f32_impl(1, dy, w, dx, Nimg, H, W, Cin, Cout, KH, KW, pad_t, in_dil, OH, OW, alpha, R, beta, ws, ws_floats, stream);
+}
 
 // Weight-grad: dw[kh,kw,ci,co] = alpha * sum_{n,oh,ow} x[n, oh*s+kh-p, ow*s+kw-p, ci] * dy[n,oh,ow,co]
 //              (+ beta * R, same layout).  Reduction over pixels is split-K into `ws`.
-INDM_API int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, int H, int W,
+static int conv2d_wgrad_f32_impl(int bf16, const float* x, const float* dy, float* dw, int Nimg, int H, int W,
                                    int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
                                    int OW, float alpha, const float* R, float beta, float* ws,
                                    long ws_floats, void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0) return INDM_E_SHAPE;
   IgemmParams p = {};
+  p.bf16 = bf16;
   p.A = x; p.B = dy; p.C = dw;
   p.M = KH * KW * Cin; p.N = Cout; p.K = Nimg * OH * OW;
   p.ldb = Cout; p.ldc = Cout; p.batch = 1;
@@ -1129,4 +1206,17 @@ INDM_API int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, i
   p.b_vec = al16(dy) && (Cout % 4 == 0);
   p.wg_inc = (OH * OW >= BK);
   return run(p, A_WGRAD, B_ROW, ws, ws_floats, (hipStream_t)stream);
+}
+INDM_API int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
+                                   int OW, float alpha, const float* R, float beta, float* ws,
+                                   long ws_floats, void* stream) {
+  return conv2d_wgrad_f32_impl(0, x, dy, dw, Nimg, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, alpha, R, beta, ws, ws_floats, stream);
+}
+// same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
+INDM_API int indm_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int Nimg, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
+                                   int OW, float alpha, const float* R, float beta, float* ws,
+                                   long ws_floats, void* stream) {
+  return conv2d_wgrad_f32_impl(1, x, dy, dw, Nimg, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, alpha, R, beta, ws, ws_floats, stream);
 }

@@ -34,6 +34,14 @@ _SIGS = {
                               c_p, c_l, c_p],
     "indm_conv2d_wgrad_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
                               c_p, c_l, c_p],
+    "indm_gemm_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_i, c_l, c_l, c_l, c_f, c_p, c_p,
+                       c_i, c_p, c_l, c_l, c_f, c_p, c_l, c_p],
+    "indm_conv2d_fwd_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
+                             c_p, c_p, c_f, c_p, c_l, c_p],
+    "indm_conv2d_dgrad_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
+                               c_p, c_l, c_p],
+    "indm_conv2d_wgrad_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
+                               c_p, c_l, c_p],
     "indm_groupnorm_ws_floats": [c_i, c_i, c_i, c_i],
     "indm_groupnorm_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p],
     "indm_groupnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64,
@@ -143,6 +151,8 @@ def _ws(nfloats, device):
 SPLITK_WS_FLOATS = 1 << 25  # 128 MiB of fp32 partial slabs for weight-grad split-K
 
 
+_MFMA = {"dtype": "f32"}  # "f32" | "bf16": see set_compute_dtype()
+
 # --------------------------------------------------------------------------- live per-kernel timing (bench.py)
 class _Profile:
     """HIP-event timing of the dense (igemm) launches on the stream they are launched on.  Keys name the kernel
@@ -182,6 +192,8 @@ def _big_tile_n(M, N, K, batch):
 
 
 def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
+    if _MFMA["dtype"] == "bf16":  # the big-tile kernels are fp32-only
+        return _tile_8wave(M, N, amode, batch, splitk) + ",bf16"
     if amode == "A_COL" and bmode == "B_ROW" and M >= 256 and N >= 256 and M % 4 == 0 and N % 4 == 0 and \
             K % 16 == 0 and K >= 8192 and -(-M // 256) * -(-N // 256) * batch <= 64 and \
             K // max(1, 256 // (-(-M // 256) * -(-N // 256) * batch)) >= 512:
@@ -196,6 +208,10 @@ def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
         tn = _big_tile_n(M, N, K, batch)
         if tn and (amode == "A_ROW" or tn == 256):
             return f"big256x{tn}"
+    return _tile_8wave(M, N, amode, batch, splitk)
+
+
+def _tile_8wave(M, N, amode, batch, splitk):
     if N <= 32 and M > 32:
         return "128x32"
     if M <= 128 and -(-M // 32) * -(-N // 128) * batch <= 512:
@@ -231,6 +247,22 @@ class _timed:
 
 
 # --------------------------------------------------------------------------- GEMM / conv
+def set_compute_dtype(name):
+    """'f32' (default: exact fp32 MFMA) or 'bf16' (MFMA inputs rounded to bf16, fp32 accumulate -- the
+    "bf16 compute / fp32 accum" mode of BASELINE configs #3-#5).  Affects every dense contraction; tensors stay fp32."""
+    if name not in ("f32", "fp32", "bf16"):
+        raise ValueError(f"compute dtype {name} unknown")
+    _MFMA["dtype"] = "bf16" if name == "bf16" else "f32"
+
+
+def compute_dtype():
+    return _MFMA["dtype"]
+
+
+def _dense(name):
+    return getattr(lib(), f"indm_{name}_bf16" if _MFMA["dtype"] == "bf16" else f"indm_{name}_f32")
+
+
 def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, rows_per_group=1, res=None,
          beta=1.0, splitk=False, gate=None):
     """C[(batch),M,N] = alpha * (op(a * gate) @ op(b) + bias[N] + bias2[M//rows_per_group, N]) + beta*res.
@@ -256,7 +288,7 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
                   + (res.numel() if res is not None else 0))
     with _timed("A_COL" if trans_a else "A_ROW", "B_COL" if trans_b else "B_ROW", M, N, K, batch, splitk, nbytes,
                 gated=gate is not None):
-        st = lib().indm_gemm_f32(_ptr(a), _ptr(gate), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
+        st = _dense("gemm")(_ptr(a), _ptr(gate), _ptr(b), _ptr(out), M, N, K, int(trans_a), int(trans_b), a.shape[-1],
                                  b.shape[-1], N, batch, sA, sB, M * N, alpha, _ptr(bias), _ptr(bias2), rows_per_group,
                                  _ptr(res), N, M * N if res is not None and res.dim() == 3 else 0, beta,
                                  _ptr(ws), SPLITK_WS_FLOATS, _stream())
@@ -313,7 +345,7 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
     y = torch.empty((N, OH, OW, Co), dtype=torch.float32, device=x.device)
     with _timed("A_CONV", "B_ROW", N * OH * OW, Co, KH * KW * Ci, nbytes=4 * (x.numel() + w.numel() + y.numel())):
         ws = _ws(SPLITK_WS_FLOATS, x.device)
-        st = lib().indm_conv2d_fwd_f32(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, KH, KW, stride, pad, 1, OH, OW,
+        st = _dense("conv2d_fwd")(_ptr(x), _ptr(w), _ptr(y), N, H, W, Ci, Co, KH, KW, stride, pad, 1, OH, OW,
                                        alpha, _ptr(bias), _ptr(bias2), _ptr(res), beta, _ptr(ws), SPLITK_WS_FLOATS,
                                        _stream())
     _chk(st, "indm_conv2d_fwd_f32")
@@ -344,7 +376,7 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
     dx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=dy.device)
     with _timed("A_CONV", "B_DGRAD", N * H * W, Ci, KH * KW * Co, nbytes=4 * (dy.numel() + w.numel() + dx.numel())):
         ws = _ws(SPLITK_WS_FLOATS, dy.device)
-        st = lib().indm_conv2d_dgrad_f32(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride,
+        st = _dense("conv2d_dgrad")(_ptr(dy), _ptr(w), _ptr(dx), N, OH, OW, Ci, Co, KH, KW, KH - 1 - pad, stride,
                                          H, W, alpha, _ptr(res), beta, _ptr(ws), SPLITK_WS_FLOATS, _stream())
     _chk(st, "indm_conv2d_dgrad_f32")
     return dx
@@ -377,7 +409,7 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None):
     dw = torch.empty((kh, kw, Ci, Co), dtype=torch.float32, device=x.device)
     ws = _ws(SPLITK_WS_FLOATS, x.device)
     with _timed("A_WGRAD", "B_ROW", kh * kw * Ci, Co, N * OH * OW, nbytes=4 * (x.numel() + dy.numel() + dw.numel())):
-        st = lib().indm_conv2d_wgrad_f32(_ptr(x), _ptr(dy), _ptr(dw), N, H, W, Ci, Co, kh, kw, stride, pad, OH, OW,
+        st = _dense("conv2d_wgrad")(_ptr(x), _ptr(dy), _ptr(dw), N, H, W, Ci, Co, kh, kw, stride, pad, OH, OW,
                                          alpha, None, 0.0, _ptr(ws), SPLITK_WS_FLOATS, _stream())
     _chk(st, "indm_conv2d_wgrad_f32")
     return dw

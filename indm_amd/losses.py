@@ -125,6 +125,8 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
     the CPU, exactly like the reference.  `state` / `flow_state` are dicts(optimizer, model, ema, step)."""
     if not config.training.continuous:
         raise NotImplementedError("discrete SMLD/DDPM losses are not used by the INDM configs")
+    from . import hip
+    hip.set_compute_dtype(config.get("compute_dtype", "f32") if hasattr(config, "get") else "f32")
     loss_fn = get_sde_loss_fn(config, sde, train)
     if optimize_fn is None:
         optimize_fn = optimization_manager(config)

@@ -127,6 +127,54 @@ def test_wgrad_gemm_big_tile_splitk(M, N, K):
     close(out, ref, rtol=1e-5, atol=3e-3, name="big wgrad gated")
 
 
+# ---- "bf16 compute / fp32 accumulate" mode (BASELINE configs #3-#5) -----------------------------------------------
+def _r16(t):
+    return t.bfloat16().float()
+
+
+@pytest.fixture
+def bf16_mode():
+    hip.set_compute_dtype("bf16")
+    yield
+    hip.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(300, 70, 136, False, False), (513, 130, 48, False, True),
+                                         (28672 + 37, 512, 80, False, True), (96, 512, 20000, True, False),
+                                         (512, 512, 24576, True, False), (27, 512, 1000, False, False)])
+def test_bf16_gemm(bf16_mode, M, N, K, ta, tb):
+    """exact products of bf16-rounded inputs, fp32 accumulation: compare with the fp64 product of the rounded inputs"""
+    a = rnd(K, M) if ta else rnd(M, K)
+    b = rnd(N, K, seed=1) if tb else rnd(K, N, seed=1)
+    out = hip.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, splitk=ta)
+    ref = _emu.gemm(_r16(a).double(), _r16(b).double(), trans_a=ta, trans_b=tb)
+    close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), name="bf16 gemm")
+    g = rnd(*a.shape, seed=5)
+    bias, res = rnd(N, seed=2), rnd(M, N, seed=4)
+    out = hip.gemm(a.to(DEV), b.to(DEV), trans_a=ta, trans_b=tb, gate=g.to(DEV), alpha=0.5, bias=bias.to(DEV),
+                   res=res.to(DEV), beta=-1.5, splitk=ta)
+    ref = _emu.gemm(_r16(a * g).double(), _r16(b).double(), trans_a=ta, trans_b=tb, alpha=0.5, bias=bias.double(),
+                    res=res.double(), beta=-1.5)
+    close(out, ref, rtol=1e-5, atol=1e-4 * math.sqrt(K / 64 + 1), name="bf16 gemm gated + epilogue")
+
+
+@pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", [(2, 16, 16, 32, 64, 3, 1, 1), (32, 32, 32, 32, 128, 3, 1, 1),
+                                               (2, 16, 16, 48, 96, 3, 2, 1), (2, 16, 16, 3, 64, 3, 1, 1),
+                                               (2, 16, 16, 64, 12, 3, 1, 1)])
+def test_bf16_conv(bf16_mode, N, H, W, Ci, Co, k, s, p):
+    x, w = rnd(N, H, W, Ci), rnd(k, k, Ci, Co, seed=1, scale=0.2)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    out = hip.conv2d(x.to(DEV), w.to(DEV), stride=s, pad=p)
+    close(out, _emu.conv2d(_r16(x).double(), _r16(w).double(), stride=s, pad=p), rtol=1e-5, atol=1e-4, name="bf16 conv")
+    dy = rnd(N, OH, OW, Co, seed=4)
+    out = hip.conv2d_dgrad(dy.to(DEV), w.to(DEV), (H, W), stride=s, pad=p)
+    close(out, _emu.conv2d_dgrad(_r16(dy).double(), _r16(w).double(), (H, W), stride=s, pad=p), rtol=1e-5, atol=1e-4,
+          name="bf16 dgrad")
+    out = hip.conv2d_wgrad(x.to(DEV), dy.to(DEV), k, k, stride=s, pad=p)
+    close(out, _emu.conv2d_wgrad(_r16(x).double(), _r16(dy).double(), k, k, stride=s, pad=p), rtol=1e-5, atol=3e-3,
+          name="bf16 wgrad")
+
+
 CONV_CASES = [
     # N, H, W, Ci, Co, k, stride, pad
     (2, 16, 16, 32, 64, 3, 1, 1),

@@ -32,3 +32,28 @@ def test_no_cpu_fallback():
     from indm_amd import hip
     with pytest.raises(RuntimeError):
         hip.axpby(torch.zeros(4), None, 1.0, 0.0)
+
+
+def test_bf16_compute_mode_training_step():
+    """BASELINE configs #3-#5 ask for bf16 compute / fp32 accumulate: with config.compute_dtype = 'bf16' every dense
+    contraction rounds its MFMA inputs to bf16.  One mini training step must stay close to the reference's fp32
+    losses (tolerance 2 % relative -- bf16 has 8 significant bits) and leave the fp32 default untouched afterwards."""
+    from indm_amd import hip, losses, sde_lib, utils
+    from indm_amd.rng import ReplayRng
+    import golden_utils as gu
+    fx = "mini_vp_nll"
+    d, cfg, score, fl = pc.build(fx, "cuda")
+    cfg.compute_dtype = "bf16"
+    try:
+        state, flow_state, _ = utils.build_states(cfg, score, fl, "cuda")
+        step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+        assert hip.compute_dtype() == "bf16"
+        score.train(); fl.train()
+        out = step_fn(state, flow_state, torch.from_numpy(d["step0/x"]).cuda(), rng=ReplayRng(gu.events(d, "step0"), "cuda"))
+        for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+            ref = torch.from_numpy(d[f"step0/{nm}"])
+            assert torch.isfinite(v).all()
+            assert (v - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 2e-3, (nm, v, ref)
+    finally:
+        hip.set_compute_dtype("f32")
+    assert hip.compute_dtype() == "f32"
