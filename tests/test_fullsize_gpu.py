@@ -82,8 +82,10 @@ def test_full_size_training_step_matches_oracle(name):
         for k in list(o.trainable)[:: max(1, len(o.trainable) // 12)]:
             diff = (sd[k].cpu().double() - o.P[k].detach().double()).abs()
             assert diff.max().item() <= 2.2 * lr, (k, diff.max().item())
-            frac = (diff > 1e-6 + 1e-4 * o.P[k].detach().abs().double()).double().mean().item()
-            assert frac < 5e-3, (k, frac)
+            # AdamW's first update is ~lr*sign(g): an element whose gradient sits at rounding-noise level may move the
+            # other way under a different reduction order, so a few elements (<= 0.5 %, at least 2) may differ by 2*lr
+            bad = int((diff > 1e-6 + 1e-4 * o.P[k].detach().abs().double()).sum().item())
+            assert bad <= max(2, 5e-3 * diff.numel()), (k, bad, diff.numel())
 
 
 @pytest.mark.timeout(1500)
