@@ -1,0 +1,79 @@
+"""Size-independent properties at the BENCHMARK's full sizes (batch 128, 512-wide flow, production tile shapes), where
+an element-by-element oracle comparison would take minutes on the CPU:
+  * adjointness  <dy, conv(x, w)> == <dgrad(dy, w), x> == <wgrad(x, dy), w>   ties the forward, data-grad and
+    weight-grad kernels (8-wave, big-tile, split-K paths) to each other;
+  * linearity and cross-path consistency of the long GEMMs (big-tile vs 8-wave kernels, gated vs pre-multiplied);
+  * flow forward -> fixed-point inverse round trip of the full 16-16 residual flow."""
+import pytest
+import torch
+
+from indm_amd import configs, hip
+from indm_amd.flow import create_flow_model, flow_forward
+from indm_amd.rng import DeviceRng
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.rand(*shape, generator=g, device=DEV) * 2 - 1) * scale
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def _close(a, b, rel, name):
+    assert abs(a - b) <= rel * max(abs(a), abs(b), 1e-30), (name, a, b)
+
+
+@pytest.mark.parametrize("N,H,Ci,Co,k", [(128, 32, 128, 128, 3), (128, 16, 256, 256, 3), (128, 16, 512, 256, 3),
+                                         (128, 32, 256, 128, 1), (128, 32, 3, 512, 3), (128, 32, 512, 3, 3)])
+def test_conv_adjointness_full_size(N, H, Ci, Co, k):
+    p = k // 2
+    x, w, dy = _r(N, H, H, Ci, seed=1), _r(k, k, Ci, Co, seed=2, scale=0.1), _r(N, H, H, Co, seed=3)
+    y = hip.conv2d(x, w, 1, p)
+    dx = hip.conv2d_dgrad(dy, w, (H, H), 1, p)
+    dw = hip.conv2d_wgrad(x, dy, k, k, 1, p)
+    ref = _dot(dy, y)
+    _close(_dot(dx, x), ref, 2e-5, "dgrad adjoint")
+    _close(_dot(dw, w), ref, 2e-5, "wgrad adjoint")
+
+
+def test_flow_gemm_paths_full_size():
+    M = 128 * 1024
+    a, g, w = _r(M, 512, seed=1), _r(M, 512, seed=2), _r(512, 512, seed=3, scale=0.05)
+    wt = w.t().contiguous()
+    nn = hip.gemm(a, w)                          # big-tile 256x128, B row-contiguous
+    nt = hip.gemm(a, wt, trans_b=True)           # big-tile 256x128, B k-contiguous
+    assert (nn - nt).abs().max().item() <= 2e-5 * nn.abs().max().item()
+    gated = hip.gemm(a, wt, trans_b=True, gate=g)            # 8-wave kernel, gate in the loader
+    pre = hip.gemm(hip.mul(a, g), wt, trans_b=True)          # big-tile kernel on the pre-multiplied operand
+    assert (gated - pre).abs().max().item() <= 2e-5 * pre.abs().max().item()
+    a2 = _r(M, 512, seed=4)
+    lin = hip.gemm(hip.axpby(a, a2, 1.0, -2.0), w)
+    assert (lin - (nn - 2.0 * hip.gemm(a2, w))).abs().max().item() <= 5e-5 * nn.abs().max().item()
+    # weight-grad GEMM (big-tile split-K) against the adjoint identity  <dc, a w> = <a^T dc, w>
+    dc = _r(M, 512, seed=5)
+    dw = hip.gemm(a, dc, trans_a=True, splitk=True)
+    _close(_dot(dw, w), _dot(dc, nn), 2e-5, "1x1 wgrad adjoint")
+    dwg = hip.gemm(a, dc, trans_a=True, splitk=True, gate=g)
+    _close(_dot(dwg, w), _dot(dc, hip.gemm(a, w, gate=g)), 2e-5, "gated 1x1 wgrad adjoint")
+
+
+@pytest.mark.timeout(900)
+def test_full_size_flow_round_trip():
+    torch.manual_seed(3)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.device = torch.device(DEV)
+    fl = create_flow_model(cfg).to(DEV).eval()
+    x = _r(128, 3, 32, 32, seed=9)
+    with torch.no_grad():
+        z, _ = flow_forward(cfg, fl, x, log_det=None, reverse=False, rng=DeviceRng(DEV, 1))
+        iters = []
+        xr, _ = flow_forward(cfg, fl, z, log_det=None, reverse=True, rng=DeviceRng(DEV, 2), iters=iters)
+    assert len(iters) == 32 and max(iters) < 1000
+    # the reference's own stopping rule is (x - x_prev)^2 / (1e-5 + 1e-5 |y|) < 1 per element, per block
+    assert (xr - x).abs().max().item() < 5e-2 and (xr - x).abs().mean().item() < 5e-3, \
+        ((xr - x).abs().max().item(), (xr - x).abs().mean().item())
