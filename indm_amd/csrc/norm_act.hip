@@ -374,19 +374,30 @@ __global__ __launch_bounds__(256) void colreduce_part_kernel(const float* __rest
   }
 }
 // block = 64 columns x 4 partial-lanes; fixed combination order -> deterministic
-__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C,
-                                                               int P, float alpha, float beta) {
-  __shared__ float sh[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int l = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < C)
-    for (int p = l; p < P; p += 4) s += part[(long)p * C + c];
-  sh[l][threadIdx.x & 63] = s;
+// 64 columns x 16 row-lanes per block: every thread adds <= 16 partial rows with 4 independent accumulators, then a
+// fixed-order LDS combine (deterministic).  The old 4-lane version spent ~11 us per call in a 64-deep dependent chain.
+__global__ __launch_bounds__(1024) void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                                int C, int P, float alpha, float beta) {
+  __shared__ float sh[16][64];
+  const int t = threadIdx.x & 63, l = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + t;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int p = l;
+    for (; p + 48 < P; p += 64) {
+      s0 += part[(long)p * C + c];
+      s1 += part[(long)(p + 16) * C + c];
+      s2 += part[(long)(p + 32) * C + c];
+      s3 += part[(long)(p + 48) * C + c];
+    }
+    for (; p < P; p += 16) s0 += part[(long)p * C + c];
+  }
+  sh[l][t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (l == 0 && c < C) {
-    const int t = threadIdx.x & 63;
-    const float r = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r += sh[k][t];
     out[c] = alpha * r + (beta != 0.f ? beta * out[c] : 0.f);
   }
 }
@@ -553,7 +564,7 @@ INDM_API int indm_colreduce_f32(const float* x, const float* y, float* out, long
   const int C4 = (C + 3) / 4;
   hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C4, 64), (int)P), dim3(256), 0, st, x, y, ws, R, C, mode, rpb);
   INDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, out, C, (int)P, alpha, beta);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, ws, out, C, (int)P, alpha, beta);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }
