@@ -911,9 +911,18 @@ __global__ void igemm_splitk_reduce(IgemmParams p) {
     const int bz = (int)(i / mn);
     const long r = i - (long)bz * mn;
     const int m = (int)(r / p.N), n = (int)(r - (long)m * p.N);
-    float s = 0.f;
-    for (int kz = 0; kz < p.splitk; ++kz) s += p.ws[((long)(bz * p.splitk + kz) * p.M + m) * p.N + n];
-    float v = s;
+    // four independent partial sums keep 4+ loads in flight per thread (fixed order: deterministic)
+    const float* w = p.ws + ((long)bz * p.splitk * p.M + m) * p.N + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int kz = 0;
+    for (; kz + 3 < p.splitk; kz += 4) {
+      s0 += w[(long)kz * mn];
+      s1 += w[(long)(kz + 1) * mn];
+      s2 += w[(long)(kz + 2) * mn];
+      s3 += w[(long)(kz + 3) * mn];
+    }
+    for (; kz < p.splitk; ++kz) s0 += w[(long)kz * mn];
+    float v = (s0 + s1) + (s2 + s3);
     if (p.bias) v += p.bias[n];
     if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
     v *= p.alpha;
