@@ -152,6 +152,13 @@ int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, int dir, 
 /* Lop weight normalisation w / max(1, ||w[:,co]||_1 / coeff) and its gradient: LopConv2d.compute_weight,
  * layers/base/lipschitz.py:350-359 (domain = codomain = inf) */
 int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff, void* stream);
+/* The same for MANY weights in two launches each way (all 96 LopConv weights of the 16-16 flow are normalised once
+ * per flow call).  table: DEVICE array of count rows of six int64 {w, aux, out, red, R, Co} -- forward: out = wn,
+ * red = l1 (written); backward: aux = dwn, out = dw, red = scratch[Co], and l1_table[i] = the forward's l1. */
+int indm_lop_normalize_multi_fwd_f32(const void* table, int count, int max_cols, long max_elems, float coeff,
+                                     void* stream);
+int indm_lop_normalize_multi_bwd_f32(const void* table, const void* l1_table, int count, int max_cols, long max_elems,
+                                     float coeff, void* stream);
 int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const float* l1, float* dw, float* dot, int R,
                                int Co, float coeff, void* stream);
 /* 3x3 convolutions with a skinny channel side (flow edges 512 <-> 3/12, resflow_.py:442-476) are computed as ONE

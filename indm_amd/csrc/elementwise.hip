@@ -113,13 +113,13 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
                                                          float alpha) {
   const long total = (long)N * H * W * C;
   const int C9 = 9 * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    long r = i / C;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+    const unsigned pix = i / (unsigned)C;
+    const int c = (int)(i - pix * (unsigned)C);
+    const unsigned row = pix / (unsigned)W;
+    const int w = (int)(pix - row * (unsigned)W);
+    const int n = (int)(row / (unsigned)H);
+    const int h = (int)(row - (unsigned)n * (unsigned)H);
     float acc = bias ? bias[c] : 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -140,13 +140,14 @@ __global__ __launch_bounds__(256) void tap_spread_kernel(const float* __restrict
                                                          int H, int W, int C, int s, float alpha) {
   const int C9 = 9 * C;
   const long total = (long)N * H * W * C9;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i % C9);
-    long r = i / C9;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int n = (int)(r / H);
+  // index arithmetic in 32 bits (the host checks total < 2^31): 64-bit divisions made this kernel ALU-bound
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+    const unsigned pix = i / (unsigned)C9;
+    const int j = (int)(i - pix * (unsigned)C9);
+    const unsigned row = pix / (unsigned)W;
+    const int w = (int)(pix - row * (unsigned)W);
+    const int n = (int)(row / (unsigned)H);
+    const int h = (int)(row - (unsigned)n * (unsigned)H);
     const int tap = j / C, c = j - tap * C;
     const int kh = tap / 3, kw = tap - kh * 3;
     const int hh = h - s * (kh - 1), ww = w - s * (kw - 1);
@@ -382,6 +383,7 @@ INDM_API int indm_tap_gather_f32(const float* P, const float* bias, float* y, in
                                  float alpha, void* stream) {
   const long total = (long)N * H * W * C;
   if (total <= 0) return INDM_OK;
+  if (total >= (1L << 31)) return INDM_E_SHAPE;
   hipLaunchKernelGGL(tap_gather_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, P, bias, y, N, H,
                      W, C, sign, alpha);
   INDM_CHECK_LAUNCH();
@@ -391,8 +393,113 @@ INDM_API int indm_tap_spread_f32(const float* y, float* P, int N, int H, int W, 
                                  void* stream) {
   const long total = (long)N * H * W * C * 9;
   if (total <= 0) return INDM_OK;
+  if (total >= (1L << 31)) return INDM_E_SHAPE;
   hipLaunchKernelGGL(tap_spread_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, P, N, H, W, C,
                      sign, alpha);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+// ---- multi-tensor Lop normalisation: all LopConv weights of the flow in two launches (fwd) / two launches (bwd) ------
+// `table` is a DEVICE array of `count` rows of 6 int64: {w, aux, out, red, R, Co}
+//   forward : aux unused, out = wn, red = l1  (written here)
+//   backward: aux = dwn,  out = dw, red = scratch dot[Co]; l1 is read from table2 = {l1}
+namespace {
+struct LopRow {
+  const float* w;
+  const float* aux;
+  float* out;
+  float* red;
+  long R, Co;
+};
+
+// column reduction  red[c] = sum_r f(w[r,c], aux[r,c]);  one block per (64- or fewer-column group, tensor); rows are spread
+// over 1024/cols lanes with 4 independent accumulators and combined through LDS in a fixed order (deterministic)
+template <int MODE>
+__global__ __launch_bounds__(1024) void lop_multi_reduce_kernel(const LopRow* __restrict__ table) {
+  __shared__ float sh[1024];
+  const LopRow t = table[blockIdx.y];
+  const int Co = (int)t.Co, R = (int)t.R;
+  int cpb = 64;
+  while (cpb > 1 && (cpb >> 1) >= Co) cpb >>= 1;  // columns per block: 64, or the next power of two >= Co
+  const int c0 = blockIdx.x * cpb;
+  if (c0 >= Co) return;
+  const int lanes = 1024 / cpb;
+  const int tc = threadIdx.x % cpb, l = threadIdx.x / cpb;
+  const int c = c0 + tc;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < Co) {
+    auto f = [&](int r) {
+      const long i = (long)r * Co + c;
+      return MODE == 0 ? fabsf(t.w[i]) : t.w[i] * t.aux[i];
+    };
+    int r = l;
+    for (; r + 3 * lanes < R; r += 4 * lanes) {
+      s0 += f(r);
+      s1 += f(r + lanes);
+      s2 += f(r + 2 * lanes);
+      s3 += f(r + 3 * lanes);
+    }
+    for (; r < R; r += lanes) s0 += f(r);
+  }
+  sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  // fixed-order tree over the row lanes (lanes is a power of two)
+  for (int step = lanes >> 1; step >= 1; step >>= 1) {
+    if (l < step) sh[l * cpb + tc] += sh[(l + step) * cpb + tc];
+    __syncthreads();
+  }
+  if (l == 0 && c < Co) t.red[c] = sh[tc];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void lop_multi_apply_kernel(const LopRow* __restrict__ table,
+                                                              const float* const* __restrict__ l1tab, float coeff) {
+  const LopRow t = table[blockIdx.y];
+  const unsigned n = (unsigned)(t.R * t.Co), Co = (unsigned)t.Co;
+  const float* l1 = MODE == 0 ? t.red : l1tab[blockIdx.y];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned c = i % Co;
+    const float s = l1[c] / coeff;
+    const float fct = fmaxf(1.f, s);
+    if (MODE == 0) {
+      t.out[i] = t.w[i] / fct;
+    } else {
+      float g = t.aux[i] / fct;
+      if (s > 1.f) {
+        const float wv = t.w[i];
+        const float sg = wv > 0.f ? 1.f : (wv < 0.f ? -1.f : 0.f);
+        g -= sg * t.red[c] / (fct * fct * coeff);
+      }
+      t.out[i] = g;
+    }
+  }
+}
+}  // namespace
+
+// max_cols = largest Co, max_elems = largest R*Co over the table (grid sizing only)
+INDM_API int indm_lop_normalize_multi_fwd_f32(const void* table, int count, int max_cols, long max_elems, float coeff,
+                                              void* stream) {
+  if (count <= 0) return INDM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lop_multi_reduce_kernel<0>, dim3(cdiv(max_cols, 64) > 0 ? cdiv(max_cols, 64) : 1, count),
+                     dim3(1024), 0, st, (const LopRow*)table);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lop_multi_apply_kernel<0>, dim3(ew_grid(max_elems, 256) > 64 ? 64 : ew_grid(max_elems, 256), count),
+                     dim3(256), 0, st, (const LopRow*)table, (const float* const*)nullptr, coeff);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+INDM_API int indm_lop_normalize_multi_bwd_f32(const void* table, const void* l1_table, int count, int max_cols,
+                                              long max_elems, float coeff, void* stream) {
+  if (count <= 0) return INDM_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(lop_multi_reduce_kernel<1>, dim3(cdiv(max_cols, 64) > 0 ? cdiv(max_cols, 64) : 1, count),
+                     dim3(1024), 0, st, (const LopRow*)table);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(lop_multi_apply_kernel<1>, dim3(ew_grid(max_elems, 256) > 64 ? 64 : ew_grid(max_elems, 256), count),
+                     dim3(256), 0, st, (const LopRow*)table, (const float* const*)l1_table, coeff);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

@@ -58,11 +58,21 @@ class LopConv(nn.Module):
             h_net.net = net
             self.h_net = h_net
 
+    last_l1 = None  # l1 norms of the latest batched normalisation (ResidualFlow.prepare)
+
     def normalized(self):
         wn, l1 = ops.lop_normalize(self.weight, self.coeff)
         with torch.no_grad():
             self.scale.copy_(l1.max())  # lipschitz.py:353-354
+        self.last_l1 = None
         return wn
+
+    def sync_scale(self):
+        """write the `scale` buffer the reference updates on every call (lipschitz.py:353-354) from the last norms"""
+        if self.last_l1 is not None:
+            with torch.no_grad():
+                self.scale.copy_(self.last_l1.max())
+            self.last_l1 = None
 
 
 class Placeholder(nn.Module):
@@ -202,7 +212,11 @@ class ResidualFlow(nn.Module):
             GEMM + one batched [NB] x ([B,idim] x [idim,idim]) GEMM instead of 2*NB short-M launches.
         Returns {block: (W, cb)}."""
         blks = [b for sc in self.blocks() for b in sc]
-        Ws = [b.weights() for b in blks]
+        convs = [c for b in blks for c in b.convs]
+        wns, l1s = ops.lop_normalize_multi([c.weight for c in convs], convs[0].coeff)  # all weights: two launches
+        for c, l1 in zip(convs, l1s):
+            c.last_l1 = l1          # `scale` (= max l1, lipschitz.py:353-354) is materialised on demand: sync_scales()
+        Ws = [wns[3 * i:3 * i + 3] for i in range(len(blks))]
         nb, B = len(blks), h.shape[0]
         hw = torch.cat([b.convs[1].h_net.net.weight for b in blks], dim=0)      # [NB*idim, 64]
         hb = torch.cat([b.convs[1].h_net.net.bias for b in blks], dim=0)
@@ -621,7 +635,13 @@ class WolfCore(nn.Module):
     def from_reference_layout(self, k, v):
         return self._to_native(k, torch.as_tensor(v))
 
+    def sync_scales(self):
+        for m in self.modules():
+            if isinstance(m, LopConv):
+                m.sync_scale()
+
     def reference_state_dict(self, prefix="module."):
+        self.sync_scales()
         return {prefix + k: self.to_reference_layout(k, v) for k, v in self.state_dict().items()}
 
 

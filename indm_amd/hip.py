@@ -66,6 +66,8 @@ _SIGS = {
     "indm_nchw_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_lop_normalize_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "indm_lop_normalize_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "indm_lop_normalize_multi_fwd_f32": [c_p, c_i, c_i, c_l, c_f, c_p],
+    "indm_lop_normalize_multi_bwd_f32": [c_p, c_p, c_i, c_i, c_l, c_f, c_p],
     "indm_sde_perturb_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
     "indm_dsm_ws_floats": [c_l, c_l],
     "indm_dsm_loss_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p],
@@ -626,6 +628,48 @@ def lop_normalize_bwd(dwn, w, l1, coeff):
     _chk(lib().indm_lop_normalize_bwd_f32(_ptr(dwn), _ptr(w), _ptr(l1), _ptr(dw), _ptr(dot), R, Co, coeff, _stream()),
          "indm_lop_normalize_bwd_f32")
     return dw
+
+
+def _lop_table(rows, device):
+    return torch.tensor(rows, dtype=torch.int64).to(device, non_blocking=True)
+
+
+def lop_normalize_multi_fwd(ws, coeff):
+    """Lop-normalise a list of RSCK weights in two launches -> (list of wn, list of l1[Cout])."""
+    dev = ws[0].device
+    sizes = [w.numel() for w in ws]
+    cos = [w.shape[-1] for w in ws]
+    wn_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    l1_all = torch.empty(sum(cos), dtype=torch.float32, device=dev)
+    wns, l1s, rows, o, q = [], [], [], 0, 0
+    for w, n, co in zip(ws, sizes, cos):
+        wn, l1 = wn_all[o:o + n].view(w.shape), l1_all[q:q + co]
+        wns.append(wn); l1s.append(l1)
+        rows.append([_ptr(w), 0, wn.data_ptr(), l1.data_ptr(), n // co, co])
+        o += n; q += co
+    table = _lop_table(rows, dev)
+    _chk(lib().indm_lop_normalize_multi_fwd_f32(table.data_ptr(), len(ws), max(cos), max(sizes), coeff, _stream()),
+         "indm_lop_normalize_multi_fwd_f32")
+    return wns, l1s
+
+
+def lop_normalize_multi_bwd(dwns, ws, l1s, coeff):
+    dev = ws[0].device
+    sizes = [w.numel() for w in ws]
+    cos = [w.shape[-1] for w in ws]
+    dw_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    dot_all = torch.empty(sum(cos), dtype=torch.float32, device=dev)
+    dws, rows, o, q = [], [], 0, 0
+    for dwn, w, l1, n, co in zip(dwns, ws, l1s, sizes, cos):
+        dw = dw_all[o:o + n].view(w.shape)
+        dws.append(dw)
+        rows.append([_ptr(w), _ptr(dwn), dw.data_ptr(), dot_all[q:q + co].data_ptr(), n // co, co])
+        o += n; q += co
+    table = _lop_table(rows, dev)
+    l1tab = _lop_table([l1.data_ptr() for l1 in l1s], dev)
+    _chk(lib().indm_lop_normalize_multi_bwd_f32(table.data_ptr(), l1tab.data_ptr(), len(ws), max(cos), max(sizes),
+                                                coeff, _stream()), "indm_lop_normalize_multi_bwd_f32")
+    return dws
 
 
 # --------------------------------------------------------------------------- SDE / loss / sampler / optimiser

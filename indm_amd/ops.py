@@ -498,6 +498,34 @@ class _LopNormalize(Function):
         return hip.lop_normalize_bwd(_c(dwn), w, l1, ctx.coeff), None
 
 
+class _LopNormalizeMulti(Function):
+    """Lop normalisation of many weights at once (two launches forward, two backward)."""
+
+    @staticmethod
+    def forward(ctx, coeff, *ws):
+        ws = [_c(w) for w in ws]
+        wns, l1s = hip.lop_normalize_multi_fwd(ws, coeff)
+        ctx.save_for_backward(*ws, *l1s)
+        ctx.coeff, ctx.n = coeff, len(ws)
+        ctx.mark_non_differentiable(*l1s)
+        return tuple(wns) + tuple(l1s)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        ws, l1s = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dwns = [_c(g) if g is not None else torch.zeros_like(w) for g, w in zip(grads[:n], ws)]
+        dws = hip.lop_normalize_multi_bwd(dwns, list(ws), list(l1s), ctx.coeff)
+        return (None,) + tuple(dws)
+
+
+def lop_normalize_multi(ws, coeff=0.98):
+    """-> (list of normalised weights, list of l1[Cout] vectors)"""
+    out = _LopNormalizeMulti.apply(coeff, *ws)
+    n = len(ws)
+    return list(out[:n]), list(out[n:])
+
+
 def lop_normalize(w, coeff=0.98):
     """w / max(1, ||w[..., co]||_1 / coeff)  (layers/base/lipschitz.py:350-359 on RSCK weights) -> (wn, l1)."""
     return _LopNormalize.apply(w, coeff)

@@ -275,6 +275,15 @@ def lop_normalize_bwd(dwn, w, l1, coeff):
     return g - torch.where(s > 1, corr, torch.zeros_like(corr))
 
 
+def lop_normalize_multi_fwd(ws, coeff):
+    outs = [lop_normalize_fwd(w, coeff) for w in ws]
+    return [o[0] for o in outs], [o[1] for o in outs]
+
+
+def lop_normalize_multi_bwd(dwns, ws, l1s, coeff):
+    return [lop_normalize_bwd(d, w, l, coeff) for d, w, l in zip(dwns, ws, l1s)]
+
+
 def _b(v, x):
     return v.reshape(-1, *([1] * (x.dim() - 1)))
 

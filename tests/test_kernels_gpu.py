@@ -346,6 +346,22 @@ def test_resample_permutes():
                        torch.pixel_shuffle(ref, 2))
 
 
+def test_lop_normalize_multi():
+    shapes = [(3, 3, 3, 512), (512, 512), (3, 3, 512, 3), (3, 3, 12, 64), (64, 12), (3, 3, 512, 12)]
+    ws = [rnd(*sh, seed=i, scale=0.02 if i % 2 else 0.2) for i, sh in enumerate(shapes)]
+    gw = [w.to(DEV) for w in ws]
+    wns, l1s = hip.lop_normalize_multi_fwd(gw, 0.98)
+    rwn, rl1 = _emu.lop_normalize_multi_fwd([w.double() for w in ws], 0.98)
+    for a, b, c, d in zip(wns, rwn, l1s, rl1):
+        close(a, b, rtol=1e-6, atol=1e-7, name="lop multi wn")
+        close(c, d, rtol=2e-6, atol=1e-6, name="lop multi l1")
+    dwn = [rnd(*sh, seed=10 + i) for i, sh in enumerate(shapes)]
+    dws = hip.lop_normalize_multi_bwd([d.to(DEV) for d in dwn], gw, l1s, 0.98)
+    rdw = _emu.lop_normalize_multi_bwd([d.double() for d in dwn], [w.double() for w in ws], rl1, 0.98)
+    for a, b in zip(dws, rdw):
+        close(a, b, rtol=1e-5, atol=1e-5, name="lop multi dw")
+
+
 def test_lop_normalize():
     for shape, scale in [((3, 3, 3, 64), 0.5), ((1, 1, 64, 64), 0.01), ((3, 3, 32, 3), 0.2)]:
         w = rnd(*shape, scale=scale)
