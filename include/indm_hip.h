@@ -152,6 +152,11 @@ int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, int dir, 
 /* Lop weight normalisation w / max(1, ||w[:,co]||_1 / coeff) and its gradient: LopConv2d.compute_weight,
  * layers/base/lipschitz.py:350-359 (domain = codomain = inf) */
 int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff, void* stream);
+/* dst_i[0..n_i) = src_i[0..n_i) for a DEVICE table of count rows of three int64 {src, dst, n}: gathers the parameter
+ * gradients autograd produced into the flat gradient buffer in one launch (replaces one AccumulateGrad add per
+ * parameter; the flat buffer is what the single all-reduce and the fused optimiser of losses.py:51-60 read). */
+int indm_multi_copy_f32(const void* table, int count, long max_n, void* stream);
+
 /* The same for MANY weights in two launches each way (all 96 LopConv weights of the 16-16 flow are normalised once
  * per flow call).  table: DEVICE array of count rows of six int64 {w, aux, out, red, R, Co} -- forward: out = wn,
  * red = l1 (written); backward: aux = dwn, out = dw, red = scratch[Co], and l1_table[i] = the forward's l1. */

@@ -503,3 +503,31 @@ INDM_API int indm_lop_normalize_multi_bwd_f32(const void* table, const void* l1_
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }
+
+// ---- multi-tensor copy: dst_i[0..n_i) = src_i[0..n_i) for a DEVICE table of count rows {src, dst, n} (int64) -----------
+// Gathers every parameter gradient autograd produced into the flat gradient buffer in ONE launch (optim.py), instead of
+// one accumulate kernel per parameter.
+namespace {
+struct CopyRow {
+  const float* src;
+  float* dst;
+  long n;
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyRow* __restrict__ table) {
+  const CopyRow t = table[blockIdx.y];
+  const long n4 = (((uintptr_t)t.src | (uintptr_t)t.dst) & 15) == 0 ? t.n >> 2 : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    ((float4*)t.dst)[i] = ((const float4*)t.src)[i];
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (long)gridDim.x * blockDim.x)
+    t.dst[i] = t.src[i];
+}
+}  // namespace
+
+INDM_API int indm_multi_copy_f32(const void* table, int count, long max_n, void* stream) {
+  if (count <= 0) return INDM_OK;
+  int gx = ew_grid((max_n + 3) / 4, 256);
+  if (gx > 32) gx = 32;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(gx, count), dim3(256), 0, (hipStream_t)stream, (const CopyRow*)table);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}

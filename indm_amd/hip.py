@@ -66,6 +66,7 @@ _SIGS = {
     "indm_nchw_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_lop_normalize_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "indm_lop_normalize_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
+    "indm_multi_copy_f32": [c_p, c_i, c_l, c_p],
     "indm_lop_normalize_multi_fwd_f32": [c_p, c_i, c_i, c_l, c_f, c_p],
     "indm_lop_normalize_multi_bwd_f32": [c_p, c_p, c_i, c_i, c_l, c_f, c_p],
     "indm_sde_perturb_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
@@ -628,6 +629,16 @@ def lop_normalize_bwd(dwn, w, l1, coeff):
     _chk(lib().indm_lop_normalize_bwd_f32(_ptr(dwn), _ptr(w), _ptr(l1), _ptr(dw), _ptr(dot), R, Co, coeff, _stream()),
          "indm_lop_normalize_bwd_f32")
     return dw
+
+
+def multi_copy(srcs, dsts):
+    """dsts[i][...] = srcs[i] (contiguous fp32, same numel) for all i in ONE launch."""
+    if not srcs:
+        return
+    rows = [[_ptr(s_), _ptr(d), d.numel()] for s_, d in zip(srcs, dsts)]
+    table = _lop_table(rows, dsts[0].device)
+    _chk(lib().indm_multi_copy_f32(table.data_ptr(), len(rows), max(r[2] for r in rows), _stream()),
+         "indm_multi_copy_f32")
 
 
 def _lop_table(rows, device):

@@ -143,6 +143,8 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         state["optimizer"].zero_grad()
 
     def _reduce_and_step(states):
+        for s in states:
+            s["optimizer"].flat.gather_grads()   # autograd's per-parameter grads -> the flat buffer (one launch)
         if allreduce is not None:
             allreduce()
         for s in states:

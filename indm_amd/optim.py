@@ -4,7 +4,8 @@ Reference: losses.py:30-62 (get_optimizer / optimization_manager), models/ema.py
 MI355X design: all trainable parameters of BOTH networks are views into one flat fp32 buffer and
 all their gradients are views into one flat gradient buffer, so
   * the data-parallel exchange is ONE RCCL all-reduce over xGMI per step (parallel.py),
-  * zero_grad is one memset,
+  * zero_grad is one memset; the gradients autograd hands out are gathered into the flat buffer by ONE
+    multi-tensor copy (indm_multi_copy_f32) instead of one accumulate kernel per parameter,
   * clip_grad_norm_ + AdamW + EMA is one read-modify-write pass per network
     (indm_adamw_ema_f32; the global norm comes from indm_sqnorm_f32 and stays on the device).
 Parameters that never receive a gradient in the reference (iResBlock.lamb / geom_p, which are only
@@ -46,13 +47,28 @@ class FlatParams:
             o += _pad4(n)
 
     def zero_grad(self):
+        """One memset of the flat buffer; the parameters' .grad go back to None so that autograd ASSIGNS the first
+        gradient of each parameter (no accumulate kernel per parameter); gather_grads() collects them."""
         self.g.zero_()
-        o = 0
-        for _, p in self.named:  # keep .grad pointing into the flat buffer
+        for _, p in self.named:
+            p.grad = None
+        self.gathered = False
+
+    def gather_grads(self):
+        """Copy every parameter's .grad into its slice of the flat gradient buffer: ONE multi-tensor launch.
+        Idempotent until the next zero_grad() (the all-reduce and the optimiser then work on the flat buffer)."""
+        if getattr(self, "gathered", False):
+            return
+        srcs, dsts, o = [], [], 0
+        for _, p in self.named:
             n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.g[o:o + n].data_ptr():
-                p.grad = self.g[o:o + n].view(p.shape)
+            g = p.grad
+            if g is not None and g.data_ptr() != self.g[o:o + n].data_ptr():
+                srcs.append(g if g.is_contiguous() else g.contiguous())
+                dsts.append(self.g[o:o + n])
             o += _pad4(n)
+        hip.multi_copy(srcs, dsts)
+        self.gathered = True
 
     def parameters(self):
         return [p for _, p in self.named]
@@ -97,6 +113,7 @@ class FusedAdamW:
         grad_scale multiplies the raw gradient first (1/world_size after a SUM all-reduce)."""
         g = self.param_groups[0]
         self.t += 1
+        self.flat.gather_grads()
         gn = hip.sqnorm(self.flat.g) if grad_clip >= 0 else None
         omd = 0.0
         shadow = None

@@ -275,6 +275,11 @@ def lop_normalize_bwd(dwn, w, l1, coeff):
     return g - torch.where(s > 1, corr, torch.zeros_like(corr))
 
 
+def multi_copy(srcs, dsts):
+    for s_, d in zip(srcs, dsts):
+        d.copy_(s_.reshape(d.shape))
+
+
 def lop_normalize_multi_fwd(ws, coeff):
     outs = [lop_normalize_fwd(w, coeff) for w in ws]
     return [o[0] for o in outs], [o[1] for o in outs]

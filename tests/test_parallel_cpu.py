@@ -58,6 +58,7 @@ def _run_steps(rank, world, port, out_path):
     ls = loss_fn(score2, parallel.shard_batch(zfix, rank, world) if world > 1 else zfix,
                  rng=ReplayRng([("rand", u[sl].numpy()), ("randn", noise[sl])], "cpu"))
     ls.mean().backward()
+    f2.gather_grads()            # autograd's per-parameter grads -> the flat buffer, before anything reads it
     if world > 1:
         parallel.make_allreduce(g2, world)()
     opt2.step(grad_clip=cfg.optim.grad_clip, grad_scale=1.0 / world)
