@@ -588,10 +588,8 @@ class WolfCore(nn.Module):
         with torch.no_grad():
             L = torch.stack([ld for _, _, ld in st])  # [nblocks, B]
             fir, sec = L.mean(1), (L * L).mean(1)
-            for i, (blk, n, _) in enumerate(st):
-                blk.last_n_samples.fill_(float(n))
-                blk.last_firmom.copy_(fir[i:i + 1])
-                blk.last_secmom.copy_(sec[i:i + 1])
+            for i, (blk, n, _) in enumerate(st):   # written into the buffers on demand (sync_scales): 96 launches saved
+                blk.pending_moments = (float(n), fir[i:i + 1], sec[i:i + 1])
 
     # ------------------------------------------------------------------ checkpoint boundary
     @staticmethod
@@ -617,6 +615,7 @@ class WolfCore(nn.Module):
         if missing:
             raise KeyError(f"missing keys: {sorted(missing)[:5]}")
         self.load_state_dict(new)
+        self._drop_pending()
         for m in self.modules():
             if isinstance(m, IResBlock):
                 m.lamb_value = float(m.lamb.detach())
@@ -636,12 +635,30 @@ class WolfCore(nn.Module):
         return self._to_native(k, torch.as_tensor(v))
 
     def sync_scales(self):
+        """materialise the buffers the reference updates eagerly on every call (Lop `scale`, iResBlock moments)"""
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, LopConv):
+                    m.sync_scale()
+                elif isinstance(m, IResBlock) and getattr(m, "pending_moments", None) is not None:
+                    n, fir, sec = m.pending_moments
+                    m.last_n_samples.fill_(n)
+                    m.last_firmom.copy_(fir)
+                    m.last_secmom.copy_(sec)
+                    m.pending_moments = None
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_scales()
+        return super().state_dict(*args, **kwargs)
+
+    def _drop_pending(self):
         for m in self.modules():
             if isinstance(m, LopConv):
-                m.sync_scale()
+                m.last_l1 = None
+            elif isinstance(m, IResBlock):
+                m.pending_moments = None
 
     def reference_state_dict(self, prefix="module."):
-        self.sync_scales()
         return {prefix + k: self.to_reference_layout(k, v) for k, v in self.state_dict().items()}
 
 

@@ -299,6 +299,30 @@ def gemm(a, b, trans_a=False, trans_b=False, alpha=1.0, bias=None, bias2=None, r
     return out
 
 
+_packed = {}  # id(weight) -> (weakref(weight), version, kind, packed copy)
+
+
+def _packed_weight(w, kind):
+    """Re-laid-out copies of a (small) conv weight used by the skinny-conv GEMM forms, cached per weight OBJECT: the
+    residual flow multiplies by the same normalised weights n+4 times per call, and each call used to re-permute them.
+    An entry is valid only while the very same tensor object is alive and unmodified (weakref + version counter)."""
+    import weakref
+    key = (id(w), kind)
+    hit = _packed.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    KH, KW, Ci, Co = w.shape
+    if kind == "ci_tapco":      # [Ci, (tap, co)] : 3x3 conv with a skinny OUTPUT as one GEMM with N = 9*Co
+        out = w.permute(2, 0, 1, 3).reshape(Ci, KH * KW * Co).contiguous()
+    else:                       # "tapco_ci": [(tap, co), Ci] : transposed conv with a skinny INPUT
+        out = w.permute(0, 1, 3, 2).reshape(KH * KW * Co, Ci).contiguous()
+    if len(_packed) > 1024:
+        for k in [k for k, v in _packed.items() if v[0]() is None]:
+            del _packed[k]
+    _packed[key] = (weakref.ref(w), w._version, out)
+    return out
+
+
 def _skinny(kh, kw, stride, pad, c_small, c_wide):
     return kh == 3 and kw == 3 and stride == 1 and pad == 1 and c_small <= 16 and c_wide >= 64
 
@@ -333,8 +357,7 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
         raise RuntimeError("conv2d: channel mismatch")
     if _skinny(KH, KW, stride, pad, Co, Ci) and bias2 is None and res is None:
         # 3x3 conv with a skinny output (flow edges 512 -> 3 / 12): one MFMA GEMM with N = 9*Co + a tap gather
-        wr = w.permute(2, 0, 1, 3).reshape(Ci, 9 * Co).contiguous()
-        P = gemm(x.reshape(-1, Ci), wr)
+        P = gemm(x.reshape(-1, Ci), _packed_weight(w, "ci_tapco"))
         return tap_gather(P.view(N, H, W, 9 * Co), bias, 1, alpha)
     if _skinny(KH, KW, stride, pad, Ci, Co):
         # skinny INPUT (flow edges 3 / 12 -> 512): spread x over the 9 taps (a [pixels, 9*Ci] panel, a few MB) and
@@ -373,9 +396,9 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
     if _skinny(KH, KW, stride, pad, Co, Ci):
         # transposed conv with a skinny INPUT dy: spread dy (+1), then [pixels, 9*Co] x [(tap,co), ci]
         dycol = tap_spread(dy, 1)
-        wt = w.permute(0, 1, 3, 2).reshape(9 * Co, Ci).contiguous()
         r = res.reshape(-1, Ci) if res is not None else None
-        return gemm(dycol.reshape(-1, 9 * Co), wt, alpha=alpha, res=r, beta=beta).view(N, H, W, Ci)
+        return gemm(dycol.reshape(-1, 9 * Co), _packed_weight(w, "tapco_ci"), alpha=alpha, res=r,
+                    beta=beta).view(N, H, W, Ci)
     dx = torch.empty((N, H, W, Ci), dtype=torch.float32, device=dy.device)
     with _timed("A_CONV", "B_DGRAD", N * H * W, Ci, KH * KW * Co, nbytes=4 * (dy.numel() + w.numel() + dx.numel())):
         ws = _ws(SPLITK_WS_FLOATS, dy.device)
