@@ -135,6 +135,9 @@ def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
                    max_abs_diff_bpd=float((got.cpu() - oracle_nelbo["bpd"]).abs().max()),
                    max_abs_diff_residual_bpd=float((got_r.cpu() - oracle_nelbo["bpd_residual"]).abs().max()),
                    cpu_oracle_images_per_s=2.0 / oracle_nelbo["seconds"])
+        out["within_north_star_band"] = bool(out["max_abs_diff_bpd"] <= 0.01)
+        if not out["within_north_star_band"]:
+            print("[bench] WARNING: NELBO differs from the CPU oracle by more than 0.01 bits/dim", file=sys.stderr)
     xb = synthetic_batch(32, cfg.data.image_size, 777, dev)
     rng = DeviceRng(dev, seed=5)
     fn(score, flow, xb, rng=rng)

@@ -307,8 +307,11 @@ def _packed_weight(w, kind):
     residual flow multiplies by the same normalised weights n+4 times per call, and each call used to re-permute them.
     An entry is valid only while the very same tensor object is alive and unmodified (weakref + version counter)."""
     import weakref
+    # never cache a Parameter: the fused optimiser rewrites parameter memory through the flat buffer, which no version
+    # counter sees.  The flow's normalised weights are fresh non-parameter tensors on every flow call.
+    cacheable = not isinstance(w, torch.nn.Parameter)
     key = (id(w), kind)
-    hit = _packed.get(key)
+    hit = _packed.get(key) if cacheable else None
     if hit is not None and hit[0]() is w and hit[1] == w._version:
         return hit[2]
     KH, KW, Ci, Co = w.shape
@@ -319,7 +322,8 @@ def _packed_weight(w, kind):
     if len(_packed) > 1024:
         for k in [k for k, v in _packed.items() if v[0]() is None]:
             del _packed[k]
-    _packed[key] = (weakref.ref(w), w._version, out)
+    if cacheable:
+        _packed[key] = (weakref.ref(w), w._version, out)
     return out
 
 

@@ -64,24 +64,26 @@ def test_full_size_training_step_matches_oracle(name):
 
     ost = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, cfg)
     ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
-    rec = RecordingRng()
     torch.set_num_threads(min(16, torch.get_num_threads()))
     ostep = O.flow_step_fn_nll if cfg.training.likelihood_weighting else O.flow_step_fn_fid
-    want = ostep(cfg, O.get_sde(cfg), ost, ofst, x, rec)
-
     state, fstate, _ = utils.build_states(cfg, score, fl, dev)
     step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
     score.train(); fl.train()
-    rng = ReplayRng(rec.events, dev)
-    got = step_fn(state, fstate, x.to(dev), rng=rng)
-    assert rng.done()
-    for name, a, b in zip(("loss", "score", "flow", "logp"), got, want):
-        gu.assert_close(a, b, 1e-3, 1e-5, "full-size " + name)
+    # TWO steps: the second one runs on weights the fused optimiser wrote through the flat buffer (anything that
+    # cached a view or a re-laid-out copy of a parameter would show up here)
+    for it in range(2):
+        rec = RecordingRng()
+        want = ostep(cfg, O.get_sde(cfg), ost, ofst, x, rec)
+        rng = ReplayRng(rec.events, dev)
+        got = step_fn(state, fstate, x.to(dev), rng=rng)
+        assert rng.done()
+        for name, a, b in zip(("loss", "score", "flow", "logp"), got, want):
+            gu.assert_close(a, b, 1e-3 * (1 + 2 * it), 1e-5 * (1 + 2 * it), f"full-size step {it} {name}")
     ss, sf = score.reference_state_dict(prefix=""), fl.reference_state_dict(prefix="")
     for sd, o, lr in ((ss, ost, cfg.optim.lr), (sf, ofst, cfg.flow.lr)):
         for k in list(o.trainable)[:: max(1, len(o.trainable) // 12)]:
             diff = (sd[k].cpu().double() - o.P[k].detach().double()).abs()
-            assert diff.max().item() <= 2.2 * lr, (k, diff.max().item())
+            assert diff.max().item() <= 4.4 * lr, (k, diff.max().item())
             # AdamW's first update is ~lr*sign(g): an element whose gradient sits at rounding-noise level may move the
             # other way under a different reduction order, so a few elements (<= 0.5 %, at least 2) may differ by 2*lr
             bad = int((diff > 1e-6 + 1e-4 * o.P[k].detach().abs().double()).sum().item())

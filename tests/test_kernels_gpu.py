@@ -214,6 +214,26 @@ def test_conv2d_wgrad_gated(Ci, Co):
     close(out, ref, rtol=1e-5, atol=2e-4, name="wgrad gated")
 
 
+def test_skinny_conv_sees_out_of_band_parameter_updates():
+    """The fused optimiser rewrites parameter memory through the flat buffer (raw kernel, no autograd version bump):
+    the packed-weight cache of the skinny conv forms must never serve a stale copy of a Parameter."""
+    x = rnd(2, 16, 16, 64).to(DEV)
+    w = torch.nn.Parameter(rnd(3, 3, 64, 3, seed=1, scale=0.2).to(DEV))
+    y1 = hip.conv2d(x, w)
+    alias = w.data.view(-1)
+    hip.ema_update(alias, torch.zeros_like(alias), 1.0)      # shadow <- shadow - 1.0*(shadow - 0) = 0, in place
+    y2 = hip.conv2d(x, w)
+    assert float(y1.abs().max()) > 0 and float(y2.abs().max()) == 0.0
+    # the transposed form (skinny INPUT) packs the weight the other way round: same guarantee
+    dy = rnd(2, 16, 16, 3, seed=2).to(DEV)
+    w2 = torch.nn.Parameter(rnd(3, 3, 64, 3, seed=3, scale=0.2).to(DEV))
+    d1 = hip.conv2d_dgrad(dy, w2, (16, 16))
+    a2 = w2.data.view(-1)
+    hip.ema_update(a2, torch.zeros_like(a2), 1.0)
+    d2 = hip.conv2d_dgrad(dy, w2, (16, 16))
+    assert float(d1.abs().max()) > 0 and float(d2.abs().max()) == 0.0
+
+
 def test_tap_gather_spread():
     P = rnd(2, 6, 5, 27)
     bias = rnd(3, seed=1)

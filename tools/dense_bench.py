@@ -54,3 +54,26 @@ p = r(M, 512)
 timeit(lambda: hip.sincos_fwd(p), 1, "sincos fwd [131072,512] (256 MB r, 512 MB w)")
 timeit(lambda: hip.mul(p, p), 1, "mul [131072,512] (512 MB r, 256 MB w)")
 timeit(lambda: hip.colreduce(p, None, 0), 1, "colreduce [131072,512]")
+print("--- HBM-bound helpers at the flow's scale-1 size [131072, 512] (268 MB per tensor)")
+def bw(fn, nbytes, name, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"{name:58s} {ms*1000:9.1f} us  {nbytes/ms/1e9:7.2f} TB/s", flush=True)
+T = 4 * M * 512
+q = r(M, 512)
+bw(lambda: hip.sincos_fwd(p, True), 3 * T, "sincos fwd (1 read, 2 writes)")
+bw(lambda: hip.sincos_bwd(p, q, p, q), 5 * T, "sincos bwd (4 reads, 1 write)")
+bw(lambda: hip.mul(p, q), 3 * T, "mul")
+bw(lambda: hip.axpby(p, q, 1.0, -1.0), 3 * T, "axpby")
+bw(lambda: hip.colreduce(p, None, 0), T, "colreduce")
+v3 = r(B, 32, 32, 3)
+bw(lambda: hip.tap_spread(v3, -1), 4 * M * 30, "tap_spread 3 -> 27 ch")
+P27 = r(B, 32, 32, 27)
+bw(lambda: hip.tap_gather(P27, None, 1), 4 * M * 30, "tap_gather 27 -> 3 ch")
+bw(lambda: hip.rowreduce(v3, v3, 0, 1.0), 2 * 4 * M * 3, "rowreduce [128, 3072]")
+g5 = r(B, 32, 32, 128); gm, bt = r(128), r(128)
+bw(lambda: hip.groupnorm_fwd(g5, gm, bt, 32, 1e-6, 1), 3 * g5.numel() * 4, "groupnorm+silu fwd [128,32,32,128]")
