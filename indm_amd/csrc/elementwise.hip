@@ -138,22 +138,25 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
 // adjoint of the gather: Pout[n,h',w',(tap,c)] = alpha * y[n, h' - s*(kh-1), w' - s*(kw-1), c]  (0 outside)
 __global__ __launch_bounds__(256) void tap_spread_kernel(const float* __restrict__ y, float* __restrict__ P, int N,
                                                          int H, int W, int C, int s, float alpha) {
-  const int C9 = 9 * C;
-  const long total = (long)N * H * W * C9;
-  // index arithmetic in 32 bits (the host checks total < 2^31): 64-bit divisions made this kernel ALU-bound
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
-    const unsigned pix = i / (unsigned)C9;
-    const int j = (int)(i - pix * (unsigned)C9);
+  // one thread per (pixel, tap): the C (3 or 12) channels of a tap are contiguous in both tensors, so the index
+  // arithmetic (32-bit; the host checks the sizes) is paid once per tap instead of once per element
+  const unsigned total = (unsigned)N * H * W * 9u;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned pix = i / 9u;
+    const int tap = (int)(i - pix * 9u);
     const unsigned row = pix / (unsigned)W;
     const int w = (int)(pix - row * (unsigned)W);
     const int n = (int)(row / (unsigned)H);
     const int h = (int)(row - (unsigned)n * (unsigned)H);
-    const int tap = j / C, c = j - tap * C;
     const int kh = tap / 3, kw = tap - kh * 3;
     const int hh = h - s * (kh - 1), ww = w - s * (kw - 1);
-    float v = 0.f;
-    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = alpha * y[(((long)n * H + hh) * W + ww) * C + c];
-    P[i] = v;
+    float* dst = P + (long)i * C;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+      const float* src = y + (((long)n * H + hh) * W + ww) * C;
+      for (int c = 0; c < C; ++c) dst[c] = alpha * src[c];
+    } else {
+      for (int c = 0; c < C; ++c) dst[c] = 0.f;
+    }
   }
 }
 
@@ -394,7 +397,7 @@ INDM_API int indm_tap_spread_f32(const float* y, float* P, int N, int H, int W, 
   const long total = (long)N * H * W * C * 9;
   if (total <= 0) return INDM_OK;
   if (total >= (1L << 31)) return INDM_E_SHAPE;
-  hipLaunchKernelGGL(tap_spread_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, y, P, N, H, W, C,
+  hipLaunchKernelGGL(tap_spread_kernel, dim3(ew_grid(total / C, 256)), dim3(256), 0, (hipStream_t)stream, y, P, N, H, W, C,
                      sign, alpha);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
