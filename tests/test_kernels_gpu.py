@@ -510,3 +510,16 @@ def test_fused_bias_act():
             close(o, r, name=f"fba {act}{grad}")
     o, r = run_both("fused_bias_act", x, None, ref, 3, 1, 0.1, 1.0)
     close(o, r, name="fba nobias")
+
+
+def test_empty_inputs_are_no_ops():
+    """zero-sized batches go through the C ABI without a launch and without an error (status INDM_OK)"""
+    e = torch.empty
+    assert hip.gemm(e(0, 64, device=DEV), rnd(64, 32).to(DEV)).shape == (0, 32)
+    assert hip.conv2d(e(0, 8, 8, 16, device=DEV), rnd(3, 3, 16, 32).to(DEV)).shape == (0, 8, 8, 32)
+    assert hip.conv2d_dgrad(e(0, 8, 8, 32, device=DEV), rnd(3, 3, 16, 32).to(DEV), (8, 8)).shape == (0, 8, 8, 16)
+    assert hip.mul(e(0, 4, device=DEV), e(0, 4, device=DEV)).numel() == 0
+    assert hip.axpby(e(0, device=DEV), None, 1.0, 0.0).numel() == 0
+    a, d = hip.sincos_fwd(e(0, 5, device=DEV), True)
+    assert a.numel() == 0 and d.numel() == 0
+    assert hip.tap_spread(e(0, 4, 4, 3, device=DEV), 1).shape == (0, 4, 4, 27)
