@@ -523,3 +523,47 @@ def test_empty_inputs_are_no_ops():
     a, d = hip.sincos_fwd(e(0, 5, device=DEV), True)
     assert a.numel() == 0 and d.numel() == 0
     assert hip.tap_spread(e(0, 4, 4, 3, device=DEV), 1).shape == (0, 4, 4, 27)
+
+
+def test_gemm_conv_randomised_shapes():
+    """randomised sweep across the dispatch boundaries of the igemm engine (8-wave tiles, big tiles, split-K, skinny
+    forms): every case against the fp64 statement"""
+    g = torch.Generator().manual_seed(1234)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+    for case in range(36):
+        kind = case % 4
+        if kind == 0:      # long-M GEMM around the big-tile thresholds
+            M = ri(200, 300) * 256 + ri(0, 255) if case % 8 == 0 else ri(1, 40) * 128 + ri(0, 127)
+            N, K = [64, 96, 128, 192, 256, 320, 512][ri(0, 6)], 16 * ri(1, 40) + (ri(0, 15) if case % 3 == 0 else 0)
+            ta, tb = False, bool(ri(0, 1))
+        elif kind == 1:    # weight-grad GEMM (A stored [K, M]) around the split-K / big-tile thresholds
+            M, N, K = [27, 108, 256, 512, 260][ri(0, 4)], [27, 128, 256, 512][ri(0, 3)], 16 * ri(100, 2500)
+            ta, tb = True, False
+        elif kind == 2:    # small / ragged
+            M, N, K, ta, tb = ri(1, 300), ri(1, 300), ri(1, 300), bool(ri(0, 1)), bool(ri(0, 1))
+        else:
+            M = None
+        if M is not None:
+            a = rnd(K, M, seed=case) if ta else rnd(M, K, seed=case)
+            b = rnd(N, K, seed=case + 1) if tb else rnd(K, N, seed=case + 1)
+            gate = rnd(*a.shape, seed=case + 2) if case % 5 == 0 else None
+            out, ref = run_both("gemm", a, b, trans_a=ta, trans_b=tb, splitk=ta, gate=gate)
+            close(out, ref, rtol=1e-5, atol=2e-5 * math.sqrt(K) + (2e-3 if ta else 0), name=f"gemm case {case} {M}x{N}x{K} {ta}{tb}")
+        else:              # convolution: fwd, dgrad, wgrad
+            Nimg, H = ri(1, 40), [8, 16, 32][ri(0, 2)]
+            Ci, Co = [3, 12, 16, 32, 64, 128][ri(0, 5)], [3, 12, 32, 64, 128, 256][ri(0, 5)]
+            k = [1, 3][ri(0, 1)]
+            s = [1, 2][ri(0, 1)] if k == 3 else 1
+            p = k // 2
+            OH = (H + 2 * p - k) // s + 1
+            x, w = rnd(Nimg, H, H, Ci, seed=case), rnd(k, k, Ci, Co, seed=case + 1, scale=0.2)
+            dy = rnd(Nimg, OH, OH, Co, seed=case + 2)
+            out, ref = run_both("conv2d", x, w, stride=s, pad=p)
+            close(out, ref, rtol=1e-5, atol=1e-4, name=f"conv case {case}")
+            out, ref = run_both("conv2d_dgrad", dy, w, (H, H), stride=s, pad=p)
+            close(out, ref, rtol=1e-5, atol=1e-4, name=f"dgrad case {case}")
+            out, ref = run_both("conv2d_wgrad", x, dy, k, k, stride=s, pad=p)
+            close(out, ref, rtol=1e-5, atol=3e-3, name=f"wgrad case {case}")
