@@ -903,6 +903,180 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Gated plain GEMM with DIRECT global -> LDS staging (global_load_lds_dwordx4, gfx950).  The flow's dominant
+// contraction (v .* cos) W^T keeps two streams in flight for its A operand (the tensor and its gate); with register
+// staging that overflows the 128 x 64 register tile's budget (igemm_big_kernel) -- here nothing is staged in VGPRs:
+// every wave DMA-copies its share of the next slab (A, gate, B) straight into the other LDS buffer while the MFMAs
+// of the current slab run, and the gate is multiplied in when the fragments are read.
+//   * LDS images: A / gate / k-contiguous B as [row][16 k] with the XOR chunk swizzle applied on the SOURCE address
+//     (the DMA writes lane-linear: LDS slot = lane), row-contiguous B as plain [16 k][128 n]
+//   * 256 x 128 block tile, 4 waves of 128 x 64, two blocks per CU; 80 KB of LDS per block when gated
+template <int BMODE, bool HAS_G, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
+  static_assert(BK == 16, "written for 16-deep slabs");
+  // NW = 4: waves 2 x 2 of 128 x 64;  NW = 8: waves 4 x 2 of 64 x 64 (four waves per SIMD with two blocks per CU)
+  constexpr int TM = 256, TN = 128, WM = (NW == 8 ? 64 : 128), WN = 64, RM = WM / 32, RN = 2;
+  constexpr bool BKC = (BMODE == B_COL);
+  constexpr int A_SZ = TM * BK, G_SZ = HAS_G ? TM * BK : 0, B_SZ = TN * BK, BUF = A_SZ + G_SZ + B_SZ;
+  extern __shared__ __attribute__((aligned(16))) float glds_smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
+  const int lt = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int bz = blockIdx.y;
+  const float* A = p.A + (long)bz * p.sA;
+  const float* G = HAS_G ? p.G + (long)bz * p.sA : nullptr;
+  const float* B = p.B + (long)bz * p.sB;
+  const int nk = p.K / BK;
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto dma = [&](const float* src, float* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+  };
+  // this wave's share of slab kt -> LDS buffer buf
+  auto stage = [&](int buf, int kt) {
+    float* base = glds_smem + buf * BUF;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int q = 0; q < 16 / NW; ++q) {  // A (+ gate): 16 rows per instruction, 256 / NW rows per wave
+      const int r0 = wave * (256 / NW) + q * 16;
+      const int row = r0 + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);  // the k-chunk that belongs in LDS slot (row, lane&3)
+      const long off = (long)min(m0 + row, p.M - 1) * p.lda + k0 + 4 * c;
+      dma(A + off, base + r0 * BK);
+      if constexpr (HAS_G) dma(G + off, base + A_SZ + r0 * BK);
+    }
+    float* bb = base + A_SZ + G_SZ;
+#pragma unroll
+    for (int q = 0; q < 8 / NW; ++q) {
+      if constexpr (BKC) {  // [128 n-rows][16 k]: 128 / NW rows per wave
+        const int r0 = wave * (128 / NW) + q * 16;
+        const int row = r0 + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        dma(B + (long)min(n0 + row, p.N - 1) * p.ldb + k0 + 4 * c, bb + r0 * BK);
+      } else {              // [16 k][128 n]: two k-rows per instruction, 16 / NW k-rows per wave
+        const int kr0 = wave * (16 / NW) + q * 2;
+        dma(B + (long)(k0 + kr0 + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4), bb + kr0 * TN);
+      }
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mw = wm * WM, nw = wn * WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int swz = (l31 >> 2) & 3;
+
+  auto frags = [&](int buf, int sg, float4 (&fa)[RM], float4 (&fb)[RN]) {
+    const float* as = glds_smem + buf * BUF;
+    const float* bs = as + A_SZ + G_SZ;
+    const int ch = ((sg * 2 + lhi) ^ swz) << 2;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+      const int o = (mw + i * 32 + l31) * BK + ch;
+      fa[i] = *(const float4*)(as + o);
+      if constexpr (HAS_G) {
+        const float4 g = *(const float4*)(as + A_SZ + o);
+        fa[i].x *= g.x; fa[i].y *= g.y; fa[i].z *= g.z; fa[i].w *= g.w;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      if constexpr (BKC) {
+        fb[j] = *(const float4*)(bs + (nw + j * 32 + l31) * BK + ch);
+      } else {
+        const float* q = bs + (sg * 8 + lhi * 4) * TN + nw + j * 32 + l31;
+        fb[j] = make_float4(q[0], q[TN], q[2 * TN], q[3 * TN]);
+      }
+    }
+  };
+  auto mfmas = [&](const float4 (&fa)[RM], const float4 (&fb)[RN]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+          const float a = t == 0 ? fa[i].x : t == 1 ? fa[i].y : t == 2 ? fa[i].z : fa[i].w;
+          const float b = t == 0 ? fb[j].x : t == 1 ? fb[j].y : t == 2 ? fb[j].z : fb[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+        }
+  };
+
+  // Skewed by half a slab (as in igemm_big_kernel): after each barrier the fragments of the new slab are requested
+  // first, then the MFMAs of the PREVIOUS slab's second k-group run (their operands are already in registers), so the
+  // LDS latency right after the barrier is covered.
+  float4 fa0[RM], fb0[RN], fa1[RM], fb1[RN];
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nk > 1) stage(1, 1);
+  frags(0, 0, fa0, fb0);
+  frags(0, 1, fa1, fb1);
+  mfmas(fa0, fb0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed ...
+  __syncthreads();                                    // ... and so has everybody else's
+  for (int s = 1; s < nk; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nk) stage(buf ^ 1, s + 1);  // lands while this slab is multiplied; that buffer was last read in slab s-1
+    frags(buf, 0, fa0, fb0);
+    mfmas(fa1, fb1);                        // k-group 1 of slab s-1
+    frags(buf, 1, fa1, fb1);
+    mfmas(fa0, fb0);                        // k-group 0 of slab s
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  mfmas(fa1, fb1);
+
+  float* C = p.C + (long)bz * p.sC;
+  const float* R = p.R ? p.R + (long)bz * p.sR : nullptr;
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int n = n0 + nw + j * 32 + l31;
+      if (n >= p.N) continue;
+      const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bn;
+        if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
+        v *= p.alpha;
+        if (R) v += p.beta * R[(long)m * p.ldr + n];
+        C[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int BMODE, bool HAS_G, int NW>
+int launch_glds(const IgemmParams& p, hipStream_t st) {
+  constexpr int BUF = 256 * BK + (HAS_G ? 256 * BK : 0) + 128 * BK;
+  constexpr size_t bytes = 2 * BUF * sizeof(float);
+  static bool ready = false;  // > 64 KB of LDS needs the opt-in once per kernel
+  if (!ready) {
+    if (hipFuncSetAttribute((const void*)igemm_glds_kernel<BMODE, HAS_G, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+      return INDM_E_LAUNCH;
+    ready = true;
+  }
+  dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch);
+  hipLaunchKernelGGL((igemm_glds_kernel<BMODE, HAS_G, NW>), grid, dim3(NW * 64), bytes, st, p);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
 // Deterministic split-K combine + epilogue.
 __global__ void igemm_splitk_reduce(IgemmParams p) {
   const long total = (long)p.batch * p.M * p.N;
@@ -958,6 +1132,16 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
   // tile choice: skinny N (flow 3/12-channel edges, last score conv) -> 128x32;
   // skinny M (27-/108-row weight grads) -> 32x128; everything else 128x128.
   dim3 block(256);
+  if constexpr (AM == A_ROW && (BMODE == B_ROW || BMODE == B_COL)) {
+    // long plain GEMMs, gated or not: direct-to-LDS staging kernel (igemm_glds_kernel), 8 waves
+    // (plain ones with a long K loop and 256-wide N stay on the 256 x 256 big tile: 142 vs 138 TF at K = 4096)
+    const bool big256 = !p.G && p.K >= 1024 && big_tile_n(p) == 256;
+    if (!big256 && !p.bf16 && p.splitk == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.M >= 1024 &&
+        p.N >= 64 && (BMODE == B_COL || !(p.N & 3)) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224) {
+      if (p.G) return launch_glds<BMODE, true, 8>(p, st);
+      return launch_glds<BMODE, false, 8>(p, st);
+    }
+  }
   if constexpr (AM == A_ROW || (AM == A_CONV && BMODE == B_DGRAD)) {  // the long forward / data-grad contractions
     // measured on MI355X (tools/dense_bench.py): the big tile wins on ungated plain GEMMs (+7-8 %) and on data-grad
     // convolutions that fill 256x256 tiles (+7-14 %); gated GEMMs (two operand streams in flight do not fit the

@@ -206,6 +206,10 @@ def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
         tiles = -(-M // 256) * -(-N // tn)
         if tiles <= 128 and K // max(1, (256 if tn == 256 else 512) // tiles) >= 512:
             return f"big256x{tn}"  # convolution weight grad on the big-tile split-K path
+    if amode == "A_ROW" and bmode in ("B_ROW", "B_COL") and not splitk and K % 16 == 0 and M >= 1024 and N >= 64 and \
+            (bmode == "B_COL" or N % 4 == 0) and -(-M // 256) * -(-N // 128) * batch >= 224 and \
+            not (not gated and K >= 1024 and _big_tile_n(M, N, K, batch) == 256):
+        return "glds256x128"  # direct-to-LDS staging kernel (gated or not)
     if not gated and not splitk and (amode == "A_ROW" or (amode == "A_CONV" and bmode == "B_DGRAD")) and \
             (bmode != "B_ROW" or N % 4 == 0):
         tn = _big_tile_n(M, N, K, batch)
