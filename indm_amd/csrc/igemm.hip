@@ -912,12 +912,16 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
 //   * LDS images: A / gate / k-contiguous B as [row][16 k] with the XOR chunk swizzle applied on the SOURCE address
 //     (the DMA writes lane-linear: LDS slot = lane), row-contiguous B as plain [16 k][128 n]
 //   * 256 x 128 block tile, 4 waves of 128 x 64, two blocks per CU; 80 KB of LDS per block when gated
-template <int BMODE, bool HAS_G, int NW>
+// 16 bytes of zeros in device memory: the source of a padded tap's DMA copy
+__device__ __attribute__((aligned(16))) float indm_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int AM, int BMODE, bool HAS_G, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
+  static_assert(AM == A_ROW || AM == A_CONV, "k-contiguous A operands");
   static_assert(BK == 16, "written for 16-deep slabs");
   // NW = 4: waves 2 x 2 of 128 x 64;  NW = 8: waves 4 x 2 of 64 x 64 (four waves per SIMD with two blocks per CU)
   constexpr int TM = 256, TN = 128, WM = (NW == 8 ? 64 : 128), WN = 64, RM = WM / 32, RN = 2;
-  constexpr bool BKC = (BMODE == B_COL);
+  constexpr bool BKC = (BMODE == B_COL || BMODE == B_DGRAD);
   constexpr int A_SZ = TM * BK, G_SZ = HAS_G ? TM * BK : 0, B_SZ = TN * BK, BUF = A_SZ + G_SZ + B_SZ;
   extern __shared__ __attribute__((aligned(16))) float glds_smem[];
 
@@ -944,18 +948,45 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
   };
+  // implicit-GEMM A operand: the output pixel of each of this lane's LDS rows (fixed over the K loop)
+  PixDec pix[16 / NW];
+  if constexpr (AM == A_CONV) {
+#pragma unroll
+    for (int q = 0; q < 16 / NW; ++q)
+      pix[q] = decode_pix(min(m0 + wave * (256 / NW) + q * 16 + (lane >> 2), p.M - 1), p.OH, p.OW);
+  }
   // this wave's share of slab kt -> LDS buffer buf
   auto stage = [&](int buf, int kt) {
     float* base = glds_smem + buf * BUF;
     const int k0 = kt * BK;
+    int kh = 0, kw = 0, ci0 = 0;
+    if constexpr (AM == A_CONV) {  // one tap per slab (host checks Cin % 16 == 0)
+      const int tap = k0 / p.Cin;
+      ci0 = k0 - tap * p.Cin;
+      kh = tap / p.KW;
+      kw = tap - kh * p.KW;
+    }
 #pragma unroll
     for (int q = 0; q < 16 / NW; ++q) {  // A (+ gate): 16 rows per instruction, 256 / NW rows per wave
       const int r0 = wave * (256 / NW) + q * 16;
       const int row = r0 + (lane >> 2);
       const int c = (lane & 3) ^ ((row >> 2) & 3);  // the k-chunk that belongs in LDS slot (row, lane&3)
-      const long off = (long)min(m0 + row, p.M - 1) * p.lda + k0 + 4 * c;
-      dma(A + off, base + r0 * BK);
-      if constexpr (HAS_G) dma(G + off, base + A_SZ + r0 * BK);
+      if constexpr (AM == A_ROW) {
+        const long off = (long)min(m0 + row, p.M - 1) * p.lda + k0 + 4 * c;
+        dma(A + off, base + r0 * BK);
+        if constexpr (HAS_G) dma(G + off, base + A_SZ + r0 * BK);
+      } else {
+        int ih = pix[q].oh * p.stride + kh - p.pad, iw = pix[q].ow * p.stride + kw - p.pad;
+        bool ok = ih >= 0 && iw >= 0;
+        if (p.dil > 1) {
+          ok = ok && ((ih % p.dil) | (iw % p.dil)) == 0;
+          ih /= p.dil;
+          iw /= p.dil;
+        }
+        ok = ok && ih < p.H && iw < p.W;
+        const float* src = A + (((long)pix[q].img * p.H + ih) * p.W + iw) * p.Cin + ci0 + 4 * c;
+        dma(ok ? src : indm_zero16, base + r0 * BK);  // zero padding: the DMA copies from a 16-byte zero page
+      }
     }
     float* bb = base + A_SZ + G_SZ;
 #pragma unroll
@@ -964,7 +995,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         const int r0 = wave * (128 / NW) + q * 16;
         const int row = r0 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
-        dma(B + (long)min(n0 + row, p.N - 1) * p.ldb + k0 + 4 * c, bb + r0 * BK);
+        if constexpr (BMODE == B_COL) {
+          dma(B + (long)min(n0 + row, p.N - 1) * p.ldb + k0 + 4 * c, bb + r0 * BK);
+        } else {  // B_DGRAD: packed weight [T][N][Cout], taps flipped; one tap per slab
+          const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
+          dma(B + ((long)(p.KH * p.KW - 1 - tap) * p.N + min(n0 + row, p.N - 1)) * p.Cout + co0 + 4 * c, bb + r0 * BK);
+        }
       } else {              // [16 k][128 n]: two k-rows per instruction, 16 / NW k-rows per wave
         const int kr0 = wave * (16 / NW) + q * 2;
         dma(B + (long)(k0 + kr0 + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4), bb + kr0 * TN);
@@ -1061,19 +1097,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   }
 }
 
-template <int BMODE, bool HAS_G, int NW>
+template <int AM, int BMODE, bool HAS_G, int NW>
 int launch_glds(const IgemmParams& p, hipStream_t st) {
   constexpr int BUF = 256 * BK + (HAS_G ? 256 * BK : 0) + 128 * BK;
   constexpr size_t bytes = 2 * BUF * sizeof(float);
   static bool ready = false;  // > 64 KB of LDS needs the opt-in once per kernel
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)igemm_glds_kernel<BMODE, HAS_G, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)igemm_glds_kernel<AM, BMODE, HAS_G, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess)
       return INDM_E_LAUNCH;
     ready = true;
   }
   dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch);
-  hipLaunchKernelGGL((igemm_glds_kernel<BMODE, HAS_G, NW>), grid, dim3(NW * 64), bytes, st, p);
+  hipLaunchKernelGGL((igemm_glds_kernel<AM, BMODE, HAS_G, NW>), grid, dim3(NW * 64), bytes, st, p);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
@@ -1138,9 +1174,18 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     const bool big256 = !p.G && p.K >= 1024 && big_tile_n(p) == 256;
     if (!big256 && !p.bf16 && p.splitk == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.M >= 1024 &&
         p.N >= 64 && (BMODE == B_COL || !(p.N & 3)) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224) {
-      if (p.G) return launch_glds<BMODE, true, 8>(p, st);
-      return launch_glds<BMODE, false, 8>(p, st);
+      if (p.G) return launch_glds<A_ROW, BMODE, true, 8>(p, st);
+      return launch_glds<A_ROW, BMODE, false, 8>(p, st);
     }
+  }
+  if constexpr (AM == A_CONV && (BMODE == B_ROW || BMODE == B_DGRAD)) {
+    // long convolutions (forward and data-grad): the same direct-to-LDS kernel on the implicit-GEMM A operand;
+    // data-grads that fill 256 x 256 tiles stay on the big-tile kernel (118-123 TF)
+    const bool big256 = BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform && big_tile_n(p) == 256;
+    if (!big256 && !p.G && !p.bf16 && p.splitk == 1 && p.a_vec && p.b_vec && p.a_tap_uniform &&
+        (BMODE == B_ROW ? !(p.N & 3) : p.b_tap_uniform != 0) && p.M >= 1024 && p.N >= 64 &&
+        (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224)
+      return launch_glds<A_CONV, BMODE, false, 8>(p, st);
   }
   if constexpr (AM == A_ROW || (AM == A_CONV && BMODE == B_DGRAD)) {  // the long forward / data-grad contractions
     // measured on MI355X (tools/dense_bench.py): the big tile wins on ungated plain GEMMs (+7-8 %) and on data-grad

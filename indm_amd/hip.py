@@ -210,6 +210,10 @@ def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
             (bmode == "B_COL" or N % 4 == 0) and -(-M // 256) * -(-N // 128) * batch >= 224 and \
             not (not gated and K >= 1024 and _big_tile_n(M, N, K, batch) == 256):
         return "glds256x128"  # direct-to-LDS staging kernel (gated or not)
+    if amode == "A_CONV" and bmode in ("B_ROW", "B_DGRAD") and not gated and not splitk and K % 16 == 0 and \
+            M >= 1024 and N >= 64 and N % 4 == 0 and -(-M // 256) * -(-N // 128) * batch >= 224 and \
+            not (bmode == "B_DGRAD" and _big_tile_n(M, N, K, batch) == 256):
+        return "glds256x128"  # implicit-GEMM convolution on the direct-to-LDS kernel (needs Cin % 16 == 0: K % 144)
     if not gated and not splitk and (amode == "A_ROW" or (amode == "A_CONV" and bmode == "B_DGRAD")) and \
             (bmode != "B_ROW" or N % 4 == 0):
         tn = _big_tile_n(M, N, K, batch)
