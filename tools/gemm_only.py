@@ -8,12 +8,15 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "nn"
 M, N, K = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (128 * 1024, 512, 512)
 a, w = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda")
 wt = w.t().contiguous()
+g_ = torch.randn(M, K, device="cuda")
 x, cw = torch.randn(128, 32, 32, 128, device="cuda"), torch.randn(3, 3, 128, 128, device="cuda")
 for _ in range(5):
     if mode == "nn":
         hip.gemm(a, w)
     elif mode == "nt":
         hip.gemm(a, wt, trans_b=True)
+    elif mode == "ntg":
+        hip.gemm(a, wt, trans_b=True, gate=g_)
     elif mode == "vnn":
         torch.matmul(a, w)
     elif mode == "vnt":
