@@ -234,7 +234,10 @@ def _tile_8wave(M, N, amode, batch, splitk):
 
 class _timed:
     def __init__(self, amode, bmode, M, N, K, batch=1, splitk=False, nbytes=None, gated=False):
-        self.key = f"igemm<{amode},{bmode},{_tile(M, N, K, amode, bmode, batch, splitk, gated)}>"
+        tile = _tile(M, N, K, amode, bmode, batch, splitk, gated)
+        if gated and tile.startswith("glds"):
+            tile += ",gated"      # its own template instantiation (igemm_glds_kernel<..., true, 8>): its own class
+        self.key = f"igemm<{amode},{bmode},{tile}>"
         self.flops = 2.0 * M * N * K * batch
         # algorithmic bytes: every operand read once, the result written once (conv callers pass the image size)
         self.bytes = float(nbytes) if nbytes is not None else 4.0 * batch * (M * K + K * N + M * N)
