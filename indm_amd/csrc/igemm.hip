@@ -930,11 +930,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   const int lt = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
-  const int bz = blockIdx.y;
+  const int z = blockIdx.y;
+  const int bz = z / p.splitk, kz = z - bz * p.splitk;
   const float* A = p.A + (long)bz * p.sA;
   const float* G = HAS_G ? p.G + (long)bz * p.sA : nullptr;
   const float* B = p.B + (long)bz * p.sB;
-  const int nk = p.K / BK;
+  const int kbeg = kz * p.kps;                         // split-K: this block reduces over [kbeg, kbeg + kps)
+  const int nk = (min(p.K, kbeg + p.kps) - kbeg) / BK;
 
   f32x16 acc[RM][RN];
 #pragma unroll
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   // this wave's share of slab kt -> LDS buffer buf
   auto stage = [&](int buf, int kt) {
     float* base = glds_smem + buf * BUF;
-    const int k0 = kt * BK;
+    const int k0 = kbeg + kt * BK;
     int kh = 0, kw = 0, ci0 = 0;
     if constexpr (AM == A_CONV) {  // one tap per slab (host checks Cin % 16 == 0)
       const int tap = k0 / p.Cin;
@@ -1074,28 +1076,35 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   }
   mfmas(fa1, fb1);
 
-  float* C = p.C + (long)bz * p.sC;
-  const float* R = p.R ? p.R + (long)bz * p.sR : nullptr;
+  const bool partial = p.splitk > 1;  // partial sums -> workspace slab z; igemm_splitk_reduce applies the epilogue
+  float* C = partial ? p.ws + ((long)z * p.M) * p.N : p.C + (long)bz * p.sC;
+  const long ldc = partial ? p.N : p.ldc;
+  const float* R = (!partial && p.R) ? p.R + (long)bz * p.sR : nullptr;
 #pragma unroll
   for (int i = 0; i < RM; ++i) {
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
       const int n = n0 + nw + j * 32 + l31;
       if (n >= p.N) continue;
-      const float bn = p.bias ? p.bias[n] : 0.f;
+      const float bn = (!partial && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         if (m >= p.M) continue;
-        float v = acc[i][j][r] + bn;
-        if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
-        v *= p.alpha;
-        if (R) v += p.beta * R[(long)m * p.ldr + n];
-        C[(long)m * p.ldc + n] = v;
+        float v = acc[i][j][r];
+        if (!partial) {
+          v += bn;
+          if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
+          v *= p.alpha;
+          if (R) v += p.beta * R[(long)m * p.ldr + n];
+        }
+        C[(long)m * ldc + n] = v;
       }
     }
   }
 }
+
+__global__ void igemm_splitk_reduce(IgemmParams p);
 
 template <int AM, int BMODE, bool HAS_G, int NW>
 int launch_glds(const IgemmParams& p, hipStream_t st) {
@@ -1108,9 +1117,14 @@ int launch_glds(const IgemmParams& p, hipStream_t st) {
       return INDM_E_LAUNCH;
     ready = true;
   }
-  dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch);
+  dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch * p.splitk);
   hipLaunchKernelGGL((igemm_glds_kernel<AM, BMODE, HAS_G, NW>), grid, dim3(NW * 64), bytes, st, p);
-  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+  if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+  if (p.splitk > 1) {
+    hipLaunchKernelGGL(igemm_splitk_reduce, dim3(ew_grid((long)p.batch * p.M * p.N, 256)), dim3(256), 0, st, p);
+    if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+  }
+  return INDM_OK;
 }
 
 // Deterministic split-K combine + epilogue.
@@ -1291,6 +1305,21 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
       hipLaunchKernelGGL(igemm_splitk_reduce, dim3(ew_grid((long)p.M * p.N, 256)), dim3(256), 0, st, p);
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+    }
+  }
+  if (am == A_CONV && (bm == B_ROW || bm == B_DGRAD) && ws && !p.bf16 && !p.G && p.a_vec && p.b_vec &&
+      p.a_tap_uniform && (bm == B_ROW ? !(p.N & 3) : p.b_tap_uniform != 0) && p.M >= 1024 && p.N >= 64) {
+    // mid-size convolutions (8x8 / 16x16 maps): too few 256 x 128 tiles to fill the chip -> split-K on the
+    // direct-to-LDS kernel, chunks of at least 8 slabs
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch;
+    if (tiles < 224 && tiles >= 16) {
+      long want = 448 / tiles;
+      while (want > 1 && (p.K / want < 8 * BK || want * p.batch * p.M * p.N > ws_floats)) --want;
+      if (want > 1) {
+        p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
+        p.splitk = cdiv(p.K, p.kps);
+        return bm == B_ROW ? launch_glds<A_CONV, B_ROW, false, 8>(p, st) : launch_glds<A_CONV, B_DGRAD, false, 8>(p, st);
+      }
     }
   }
   p.splitk = ws ? choose_splitk(p.M, p.N, p.K, p.batch, ws_floats) : 1;

@@ -30,7 +30,7 @@ timeit(lambda: hip.gemm(a4, w4, trans_b=True), 2*4096**3, "gemm NT  4096^3")
 M1 = B * 256
 a1 = r(M1, 512)
 timeit(lambda: hip.gemm(a1, w), 2*M1*512*512, "gemm NN  [32768,512]x[512,512] (flow scale 1)")
-for (H, C, Co) in [(32, 128, 128), (16, 256, 256), (16, 512, 256), (8, 256, 256), (32, 256, 128), (32, 384, 128)]:
+for (H, C, Co) in [(32, 128, 128), (16, 256, 256), (16, 512, 256), (8, 256, 256), (8, 512, 256), (4, 256, 256), (32, 256, 128), (32, 384, 128)]:
     x, wt = r(B, H, H, C), r(3, 3, C, Co)
     fl = 2 * B * H * H * 9 * C * Co
     timeit(lambda: hip.conv2d(x, wt), fl, f"conv3x3 fwd   {H}x{H} {C}->{Co}")
