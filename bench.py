@@ -234,7 +234,7 @@ def main():
                 if rank == 0 and os.environ.get("INDM_BENCH_PROFILE"):
                     for k in sorted(prof, key=lambda k: -prof[k]["ms"]):
                         p = prof[k]
-                        print(f"[bench] {k:36s} launches {p['launches']:5d}  {p['ms']:8.2f} ms  "
+                        print(f"[bench] {k:72s} launches {p['launches']:5d}  {p['ms']:8.2f} ms  "
                               f"{p['flops'] / 1e9:10.1f} GFLOP  {p['flops'] / p['ms'] / 1e9:7.2f} TF/s",
                               file=sys.stderr, flush=True)
     barrier()

@@ -75,6 +75,10 @@ int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, 
                           int KH, int KW, int stride, int pad, int OH, int OW, float alpha, const float* R,
                           float beta, float* ws, long ws_floats, void* stream);
 
+/* Name of the kernel variant this thread's last dense launch (gemm / conv2d_*) was dispatched to, e.g.
+ * "glds256x128,gated", "big256x256", "thin128x128", "128x32": bench.py labels its live per-kernel timings with it. */
+const char* indm_igemm_last_variant(void);
+
 /* "bf16 compute / fp32 accumulate" variants (BASELINE configs #3-#5): identical contracts and fp32 tensors, but the
  * MFMA inputs are rounded to bf16 (round-to-nearest-even) and multiplied with v_mfma_f32_32x32x16_bf16. */
 int indm_gemm_bf16(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
@@ -121,6 +125,12 @@ int indm_softmax_bwd_f32(const float* dy, const float* y, float* dx, long rows, 
 long indm_colreduce_ws_floats(long R, int C);
 int indm_colreduce_f32(const float* x, const float* y, float* out, long R, int C, int mode, float alpha, float beta,
                        float* ws, void* stream);
+
+/* Segmented column sums out[s][c] = alpha * sum_{r < rows_per_seg} x[s*rows_per_seg + r][c]: gradient of the per-image
+ * bias (the `+ Dense(temb)[:, :, None, None]` of layerspp.py:262-263 and the flow's conditioning bias lipschitz.py:433). */
+long indm_segreduce_ws_floats(long nseg, long rows_per_seg, int C);
+int indm_segreduce_f32(const float* x, float* out, long nseg, long rows_per_seg, int C, float alpha, float* ws,
+                       void* stream);
 
 /* out[b] = alpha * sum_i f(x[b,i], y[b,i])  (mode 0: x*y, 1: x*x, 2: x): Hutchinson traces
  * (iresblock.py:258,272; likelihood.py:37,206-213), prior_logp (sde_lib.py:165-169), Langevin norms. */

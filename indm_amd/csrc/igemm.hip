@@ -16,6 +16,7 @@
 //   * XCD-aware tile order: the N-tiles that share an A row-panel land on one XCD's L2
 //   * optional split-K into a caller-provided workspace (deterministic reduce kernel)
 #include "indm_common.h"
+#include "igemm_thin.h"
 #include <type_traits>
 
 namespace {
@@ -57,6 +58,9 @@ struct IgemmParams {
   int wg_inc;                        // A_WGRAD: pixel decode advanced incrementally (needs OH*OW >= BK)
   int bf16;                          // MFMA inputs rounded to bf16 (RNE), fp32 accumulate (BASELINE configs #3-#5)
 };
+
+// name of the kernel variant the last launch of this thread went to (bench.py labels its live timings with it)
+thread_local const char* last_variant = "";
 
 struct PixDec {
   int img, oh, ow;
@@ -1118,6 +1122,8 @@ int launch_glds(const IgemmParams& p, hipStream_t st) {
     ready = true;
   }
   dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch * p.splitk);
+  last_variant = HAS_G ? (p.splitk > 1 ? "glds256x128,splitk,gated" : "glds256x128,gated")
+                       : (p.splitk > 1 ? "glds256x128,splitk" : "glds256x128");
   hipLaunchKernelGGL((igemm_glds_kernel<AM, BMODE, HAS_G, NW>), grid, dim3(NW * 64), bytes, st, p);
   if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
   if (p.splitk > 1) {
@@ -1212,6 +1218,7 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     if (btn) {
       // one wave per SIMD with a 128x128 / 128x64 register tile (see igemm_big_kernel)
       dim3 grid(cdiv(p.M, 256) * cdiv(p.N, btn), p.batch);
+      last_variant = btn == 256 ? "big256x256" : "big256x128";
       if (btn == 256) hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 256, false>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 128, false>), grid, block, 0, st, p);
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
@@ -1224,17 +1231,21 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
   } while (0)
   if (p.N <= 32 && p.M > 32) {
     dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 32), p.batch * p.splitk);
+    last_variant = p.bf16 ? "128x32,bf16" : "128x32";
     INDM_LAUNCH(128, 32, 4, 1, grid, block);
   } else if (p.M <= 128 && cdiv(p.M, 32) * cdiv(p.N, 128) * p.batch * p.splitk <= 512) {
     // short-M GEMMs (per-image vectors x weights): 32-row tiles so more than a handful of CUs get work
     dim3 grid(cdiv(p.M, 32) * cdiv(p.N, 128), p.batch * p.splitk);
+    last_variant = p.bf16 ? "32x128,bf16" : "32x128";
     INDM_LAUNCH(32, 128, 1, 4, grid, block);
   } else if (use_tall_tile<AM>(p)) {
     // 8-wave 256x128 tile: +8-10 % on the long-M forward / data-grad contractions (measured)
     dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch * p.splitk);
+    last_variant = p.bf16 ? "256x128,bf16" : "256x128";
     INDM_LAUNCH(256, 128, 4, 2, grid, dim3(512));
   } else {
     dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128), p.batch * p.splitk);
+    last_variant = p.bf16 ? "128x128,bf16" : "128x128";
     INDM_LAUNCH(128, 128, 2, 2, grid, block);
   }
 #undef INDM_LAUNCH
@@ -1267,6 +1278,16 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return INDM_OK;
   if (p.K < 0) return INDM_E_SHAPE;
   p.ws = ws;
+  if (!p.bf16 && (am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
+    // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip
+    const ThinGemmArgs t = {p.A, p.G, p.B, p.C, p.M, p.N, p.K, am == A_COL, bm == B_COL, p.lda, p.ldb, p.ldc, p.batch,
+                            p.alpha, p.beta, p.bias, p.bias2, p.rpg, p.R, p.ldr, ws, ws_floats};
+    const int r = indm_thin_gemm(t, st);
+    if (r != THIN_NA) {
+      last_variant = "thin128x128";
+      return r;
+    }
+  }
   if (am == A_COL && bm == B_ROW && ws && !p.bf16) {
     // weight-grad GEMMs (tiny output, K = pixels): 256x256 big tiles, one block per CU, split-K sized to 256 blocks
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
@@ -1274,10 +1295,13 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
         p.K >= 8192) {
       long want = 256 / tiles;
       while (want > 1 && (p.K / want < 512 || want * p.batch * p.M * p.N > ws_floats)) --want;
-      if (want > 1) {
+      // fewer than 128 blocks (e.g. the 256 x 256 NIN weight grads at K = 32768: 64 blocks, 31 TF) leave most of the
+      // chip idle: those go to the 128 x 128 split-K path below
+      if (want > 1 && tiles * want >= 128) {
         int kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
         p.kps = kps;
         p.splitk = cdiv(p.K, kps);
+        last_variant = "big256x256";
         dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, 256)), (unsigned)(p.batch * p.splitk));
         if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
@@ -1300,6 +1324,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       p.kps = kps;
       p.splitk = cdiv(p.K, kps);
       dim3 grid((unsigned)tiles, (unsigned)p.splitk);
+      last_variant = tn == 256 ? "big256x256" : "big256x128";
       if (tn == 256) hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 128, false>), grid, dim3(256), 0, st, p);
       if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
@@ -1319,6 +1344,22 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
         p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
         p.splitk = cdiv(p.K, p.kps);
         return bm == B_ROW ? launch_glds<A_CONV, B_ROW, false, 8>(p, st) : launch_glds<A_CONV, B_DGRAD, false, 8>(p, st);
+      }
+    }
+  }
+  if (am == A_ROW && (bm == B_ROW || bm == B_COL) && ws && !p.bf16 && p.batch == 1 && p.a_vec && p.b_vec && !(p.K & 15) &&
+      p.K >= 512 && p.M >= 1024 && p.N >= 64 && (bm == B_COL || !(p.N & 3))) {
+    // plain GEMMs with too few 256 x 128 tiles to fill the chip (the flow's scale-1 edge [32768, 512] x [512, 108],
+    // gated or not: 128 tiles, one 4-wave block per CU on the 8-wave engine = 40 TF): split-K on the direct-to-LDS kernel
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
+    if (tiles < 224 && tiles >= 16) {
+      long want = 448 / tiles;
+      while (want > 1 && (p.K / want < 8 * BK || want * p.M * p.N > ws_floats)) --want;
+      if (want > 1) {
+        p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
+        p.splitk = cdiv(p.K, p.kps);
+        if (bm == B_ROW) return p.G ? launch_glds<A_ROW, B_ROW, true, 8>(p, st) : launch_glds<A_ROW, B_ROW, false, 8>(p, st);
+        return p.G ? launch_glds<A_ROW, B_COL, true, 8>(p, st) : launch_glds<A_ROW, B_COL, false, 8>(p, st);
       }
     }
   }
@@ -1345,6 +1386,9 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
 // ---------------------------------------------------------------------------
 // C ABI (declared in include/indm_hip.h)
 // ---------------------------------------------------------------------------
+
+// Kernel variant chosen by this thread's last dense launch ("glds256x128,gated", "big256x256", "thin128x128", ...).
+INDM_API const char* indm_igemm_last_variant(void) { return last_variant; }
 
 // C[b] = alpha * (opA(A[b] .* gateA[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]   (gateA optional)
 //   transA == 0: A is [M,K] row-major (lda);  transA == 1: A is stored [K,M] (lda)

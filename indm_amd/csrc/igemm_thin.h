@@ -1,0 +1,28 @@
+// Thin GEMMs of the flow's 3-/12-channel edges: one dimension of the contraction is <= 128 (27 = 9 taps x 3 channels,
+// 108 = 9 x 12), so the launch is bound by streaming the wide [pixels, 512] tensor through HBM, not by the MFMA pipe.
+// igemm.hip tries these kernels first (indm_thin_gemm returns THIN_NA when the problem is not one of theirs).
+#pragma once
+#include "indm_common.h"
+
+struct ThinGemmArgs {
+  const float* A;
+  const float* G;  // optional gate on A (same layout)
+  const float* B;
+  float* C;
+  int M, N, K;
+  int transA, transB;  // 0: [M,K] / [K,N] row-major; 1: stored [K,M] / [N,K]
+  long lda, ldb, ldc;
+  int batch;
+  float alpha, beta;
+  const float* bias;
+  const float* bias2;
+  int rpg;
+  const float* R;
+  long ldr;
+  float* ws;  // split-K workspace (weight-grad forms)
+  long ws_floats;
+};
+
+enum { THIN_NA = 1 };
+
+int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st);

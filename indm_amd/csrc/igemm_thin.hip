@@ -1,0 +1,380 @@
+// Thin GEMMs (see igemm_thin.h): HBM-streaming contractions of the flow's 3-/12-channel edges on gfx950.
+//
+//   thin-K   C[M,N] = epi(A[M,K] B[K,N]),  K <= 128, N >= 128     (3x3 conv with a skinny INPUT after tap_spread:
+//            K = 27 / 108).  Write-bound: 268 MB of C per launch at M = 131072.  The generic engine spends its time on
+//            scalar operand loads (lda = 27 is not float4-aligned) and on 64 dword-store instructions per wave; here the
+//            A tile is fetched as ONE contiguous run, the whole reduction sits in LDS at once, and the accumulators go
+//            back through LDS so that every store instruction writes two full 512-byte rows (float4 per lane).
+#include "igemm_thin.h"
+
+namespace {
+
+// Bijective XCD-aware remap (same as igemm.hip): workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin-K kernel.  128 x 128 tile, 4 waves, wave w owns rows [32w, 32w+32) x 128 columns (1 x 4 MFMA 32x32 tiles).
+// FLAT: lda == K <= 32 -> the tile's A rows are one contiguous run of 128*K floats (float4 loads whatever K is).
+// otherwise K % 4 == 0 and lda % 4 == 0, the reduction walks in chunks of 32.
+constexpr int TK_TM = 128, TK_TN = 128, TK_KC = 32;
+constexpr int TK_LDA = TK_TM + 2;   // [k][row], transposing ds_write_b32: 2*(k4) + row distinct over a half-wave
+constexpr int TK_LDB = TK_TN + 4;   // [k][col], 16-byte aligned rows: one ds_write_b128 per float4
+constexpr int TK_LDS = TK_TN + 8;   // staging rows for the epilogue (16-byte aligned; 4 rows apart = 32 banks apart)
+constexpr int TK_OPER = TK_KC * (TK_LDA + TK_LDB);
+constexpr int TK_STAGE = 4 * 16 * TK_LDS;
+constexpr int TK_SMEM = TK_OPER > TK_STAGE ? TK_OPER : TK_STAGE;
+
+template <bool FLAT>
+__global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[TK_SMEM];
+  float* as = smem;
+  float* bs = smem + TK_KC * TK_LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int tiles_n = (p.N + TK_TN - 1) / TK_TN, tiles_m = (p.M + TK_TM - 1) / TK_TM;
+  const int lt = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
+  const int m0 = tm * TK_TM, n0 = tn * TK_TN;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int k0 = 0; k0 < p.K; k0 += TK_KC) {
+    const int kc = min(TK_KC, p.K - k0);
+    if (k0) __syncthreads();  // previous chunk's fragments are consumed
+    // ---- B chunk: [kc x 128] float4 row groups (zero beyond K / N)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid + j * 256;
+      const int k = g >> 5, c4 = (g & 31) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < kc && n0 + c4 < p.N) v = *(const float4*)(p.B + (long)(k0 + k) * p.ldb + n0 + c4);
+      *(float4*)(bs + k * TK_LDB + c4) = v;
+    }
+    // ---- A chunk
+    if constexpr (FLAT) {
+      const int rows = min(TK_TM, p.M - m0);
+      const int total = rows * p.K;
+      const float* src = p.A + (long)m0 * p.K;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e0 = (tid + j * 256) * 4;
+        if (e0 < total) {
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (e0 + 3 < total) {
+            const float4 q = *(const float4*)(src + e0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+          } else {
+            for (int t = 0; t < 4; ++t)
+              if (e0 + t < total) v[t] = src[e0 + t];
+          }
+          int row = e0 / p.K, k = e0 - row * p.K;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (e0 + t < total) as[k * TK_LDA + row] = v[t];
+            if (++k == p.K) { k = 0; ++row; }
+          }
+        }
+      }
+      if ((p.K & 1) && tid < TK_TM) as[p.K * TK_LDA + tid] = 0.f;  // odd K: the last k-pair's second half
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int g = tid + j * 256;
+        const int row = g >> 3, k4 = (g & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + row < p.M && k4 < kc) v = *(const float4*)(p.A + (long)(m0 + row) * p.lda + k0 + k4);
+        as[(k4 + 0) * TK_LDA + row] = v.x;
+        as[(k4 + 1) * TK_LDA + row] = v.y;
+        as[(k4 + 2) * TK_LDA + row] = v.z;
+        as[(k4 + 3) * TK_LDA + row] = v.w;
+      }
+    }
+    __syncthreads();
+    // ---- MFMAs: k-pairs of this chunk
+    const float* af = as + wave * 32 + l31;
+    const float* bf = bs + l31;
+    const int npairs = (kc + 1) >> 1;
+#pragma unroll 2
+    for (int kk = 0; kk < npairs; ++kk) {
+      const int k = 2 * kk + lhi;
+      const float a = af[k * TK_LDA];
+      float b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = bf[k * TK_LDB + j * 32];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: accumulators -> LDS (row-major, per wave, 16 rows at a time) -> float4 rows -> HBM
+  float* stg = smem + wave * 16 * TK_LDS;
+  const int mw = m0 + wave * 32;
+  int q0 = 0, rem0 = 0;
+  if (p.bias2) {  // image index of the wave's first row; later rows carry at most once when rpg >= 32
+    q0 = mw / p.rpg;
+    rem0 = mw - q0 * p.rpg;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();  // operand buffers (h = 0) / the previous half's staging rows are no longer read
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = 8 * h + rr;
+        const int lr = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;
+        stg[lr * TK_LDS + j * 32 + l31] = acc[j][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int lr = it * 2 + lhi;
+      const int c4 = l31 * 4;
+      const int d = 16 * h + lr;
+      const int m = mw + d, n = n0 + c4;
+      if (m < p.M && n < p.N) {
+        float4 v = *(const float4*)(stg + lr * TK_LDS + c4);
+        if (p.bias) {
+          const float4 b = *(const float4*)(p.bias + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (p.bias2) {
+          const int img = (p.rpg >= 32) ? q0 + (rem0 + d >= p.rpg ? 1 : 0) : m / p.rpg;
+          const float4 b = *(const float4*)(p.bias2 + (long)img * p.N + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+        if (p.R) {
+          const float4 rv = *(const float4*)(p.R + (long)m * p.ldr + n);
+          v.x += p.beta * rv.x; v.y += p.beta * rv.y; v.z += p.beta * rv.z; v.w += p.beta * rv.w;
+        }
+        *(float4*)(p.C + (long)m * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin-K, flat form (lda == K <= 32), persistent: a block keeps ONE 128-column B tile in LDS and walks down the rows.
+// Every wave of this kernel has the same timing, so the waves of the chip run in lock-step and phases that wait for
+// memory do NOT overlap across waves (measured on the first version: MFMA 31 us + stores 39 us + loads/LDS 20 us
+// simply added up to 89 us).  The overlap therefore has to happen inside each wave:
+//   * the next A tile (one contiguous run of 128*K floats) is requested right before the MFMA loop with inline-asm
+//     global_load_dwordx4 (hipcc sinks a C++ load below the loop and then waits for it with vmcnt(0)) and is awaited
+//     only after the loop, where it is written to LDS for the next iteration;
+//   * the stores of a tile are issued last and nothing waits for them until the next tile's MFMAs are done
+//     (vmcnt counts in order: waiting for the next loads is the first point that needs them retired);
+//     weaving the previous tile's store passes INTO the MFMA loop (second accumulator set, 2 waves/SIMD) measured
+//     the same 71 us and was dropped;
+//   * the accumulators leave through per-wave staging rows (8 rows x 512 B per pass): no block barrier in the epilogue.
+constexpr int TF_LDS = TK_TN + 8;
+constexpr int TF_AS = TK_KC * TK_LDA, TF_BS = TK_KC * TK_LDB, TF_STG = 4 * 8 * TF_LDS;
+
+__device__ __forceinline__ void async_load4(f32x4& dst, const float* src) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+
+__global__ __launch_bounds__(256, 3) void igemm_thin_kflat_kernel(ThinGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[TF_AS + TF_BS + TF_STG];
+  float* as = smem;
+  float* bs = smem + TF_AS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* stg = smem + TF_AS + TF_BS + wave * 8 * TF_LDS;
+  const int tiles_n = (p.N + TK_TN - 1) / TK_TN, tiles_m = (p.M + TK_TM - 1) / TK_TM;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);  // the tiles_n blocks that share A tiles sit on one XCD
+  const int tn = lb % tiles_n, mstep = gridDim.x / tiles_n;
+  const int n0 = tn * TK_TN;
+  const int K = p.K;
+  const int tile_elems = TK_TM * K;
+
+  // (row, k) and the clamped source offset of this thread's four float4 groups inside an A tile (same for every tile;
+  // groups past the tile re-read its last float4 and are never stored)
+  int grow[4], gk[4], goff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = (tid + j * 256) * 4;
+    grow[j] = e0 / K;
+    gk[j] = e0 - grow[j] * K;
+    goff[j] = min(e0, tile_elems - 4);
+  }
+  f32x4 ra[4];
+  // A tile -> LDS [k][row]; `total` = valid elements of the tile (ragged last tile: the rest stays stale, never stored)
+  auto sstore_a = [&](int total) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = (tid + j * 256) * 4;
+      if (e0 < total) {
+        int row = grow[j], k = gk[j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (e0 + t < total) as[k * TK_LDA + row] = ra[j][t];
+          if (++k == K) { k = 0; ++row; }
+        }
+      }
+    }
+  };
+  // the last tile may be ragged (fewer than 128 rows): its loads are clamped element-wise in C++ (cold path)
+  auto load_tile_sync = [&](int tm) {
+    const int m0 = tm * TK_TM;
+    const int total = min(TK_TM, p.M - m0) * K;
+    const float* src = p.A + (long)m0 * K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e0 = (tid + j * 256) * 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ra[j][t] = e0 + t < total ? src[e0 + t] : 0.f;
+    }
+    return total;
+  };
+
+  int tm = lb / tiles_n;
+  // B tile: [K x 128] once (zero beyond K / N)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int g = tid + j * 256;
+    const int k = g >> 5, c4 = (g & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K && n0 + c4 < p.N) v = *(const float4*)(p.B + (long)k * p.ldb + n0 + c4);
+    *(float4*)(bs + k * TK_LDB + c4) = v;
+  }
+  if ((K & 1) && tid < TK_TM) as[K * TK_LDA + tid] = 0.f;  // odd K: second half of the last k-pair
+  if (tm < tiles_m) sstore_a(load_tile_sync(tm));
+  const int npairs = (K + 1) >> 1;
+  const int c4 = l31 * 4, n = n0 + c4;  // this lane's four output columns: the same for every row it stores
+  const bool nok = n < p.N;
+  float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias && nok) bn = *(const float4*)(p.bias + n);
+  const float* af = as + wave * 32 + l31;
+  const float* bf = bs + l31;
+
+  // one epilogue pass: rows [8q, 8q+8) of the wave's 32 (accumulator registers 4q .. 4q+3) of tile `tme`
+  auto epilogue_pass = [&](const f32x16 (&src)[4], int q, int tme) {
+    const int mw = tme * TK_TM + wave * 32;
+    const bool full = (tme + 1) * TK_TM <= p.M && n0 + TK_TN <= p.N;  // block-uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) stg[(rr + 4 * lhi) * TF_LDS + j * 32 + l31] = src[j][4 * q + rr];
+    __builtin_amdgcn_wave_barrier();
+    float4 bq = bn;  // bias[n] + bias2[image of these 8 rows][n]: one load per pass (rpg % 8 == 0, host-checked)
+    if (p.bias2 && nok) {
+      const int img = (mw + 8 * q) / p.rpg;
+      const float4 b = *(const float4*)(p.bias2 + (long)img * p.N + n);
+      bq.x += b.x; bq.y += b.y; bq.z += b.z; bq.w += b.w;
+    }
+    float4 v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      v[it] = *(const float4*)(stg + (it * 2 + lhi) * TF_LDS + c4);
+      v[it].x = (v[it].x + bq.x) * p.alpha; v[it].y = (v[it].y + bq.y) * p.alpha;
+      v[it].z = (v[it].z + bq.z) * p.alpha; v[it].w = (v[it].w + bq.w) * p.alpha;
+    }
+    if (p.R) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = mw + 8 * q + it * 2 + lhi;
+        if (m < p.M && nok) {
+          const float4 rv = *(const float4*)(p.R + (long)m * p.ldr + n);
+          v[it].x += p.beta * rv.x; v[it].y += p.beta * rv.y; v[it].z += p.beta * rv.z; v[it].w += p.beta * rv.w;
+        }
+      }
+    }
+    float* crow = p.C + (long)(mw + 8 * q + lhi) * p.ldc + n;
+    if (full) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) *(float4*)(crow + (long)(2 * it) * p.ldc) = v[it];
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (mw + 8 * q + it * 2 + lhi < p.M && nok) *(float4*)(crow + (long)(2 * it) * p.ldc) = v[it];
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  for (; tm < tiles_m; tm += mstep) {
+    __syncthreads();  // this tile's A (written at the end of the previous iteration) is visible
+    const int tnext = tm + mstep;
+    const bool next_full = (tnext + 1) * TK_TM <= p.M;  // block-uniform
+    if (next_full) {
+      const float* src = p.A + (long)tnext * TK_TM * K;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) async_load4(ra[j], src + goff[j]);
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // fragments of k-pair kk+1 are requested before the MFMAs of kk
+    float a0 = af[lhi * TK_LDA], b0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = bf[lhi * TK_LDB + j * 32];
+    for (int kk = 0; kk < npairs; ++kk) {
+      const int k = 2 * min(kk + 1, npairs - 1) + lhi;
+      const float a1 = af[k * TK_LDA];
+      float b1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1[j] = bf[k * TK_LDB + j * 32];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[j], acc[j], 0, 0, 0);
+      a0 = a1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = b1[j];
+    }
+
+    __syncthreads();  // every wave is done with this tile's A fragments
+    if (next_full) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3])::"memory");
+      sstore_a(tile_elems);
+    } else if (tnext < tiles_m) {
+      sstore_a(load_tile_sync(tnext));
+    }
+    // stores last: nothing waits for them until the next tile's MFMAs are done
+#pragma unroll
+    for (int q = 0; q < 4; ++q) epilogue_pass(acc, q, tm);
+  }
+}
+
+int launch_thin_k(const ThinGemmArgs& a, hipStream_t st) {
+  const bool flat = a.lda == a.K && a.K <= TK_KC;
+  if (!flat && ((a.lda & 3) || (a.K & 3))) return THIN_NA;
+  const int tiles = cdiv(a.M, TK_TM) * cdiv(a.N, TK_TN);
+  if (flat && (!a.bias2 || !(a.rpg & 7))) {
+    // persistent: three blocks per CU, each with its own B tile; a multiple of tiles_n (and of 8 for the XCD remap)
+    const int tiles_n = cdiv(a.N, TK_TN), tiles_m = cdiv(a.M, TK_TM);
+    const int target = 768;
+    int groups = target / tiles_n;
+    if (groups > tiles_m) groups = tiles_m;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(igemm_thin_kflat_kernel, dim3(groups * tiles_n), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+  }
+  if (flat) hipLaunchKernelGGL(igemm_thin_k_kernel<true>, dim3(tiles), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(igemm_thin_k_kernel<false>, dim3(tiles), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
+}  // namespace
+
+int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st) {
+  if (a.batch != 1) return THIN_NA;
+  if (!a.transA && !a.transB && !a.G && a.K >= 1 && a.K <= 128 && a.N >= 128 && !(a.N & 3) && a.M >= 1024 &&
+      !(a.ldb & 3) && !(a.ldc & 3) && al16(a.A) && al16(a.B) && al16(a.C) && al16(a.bias) && al16(a.bias2) &&
+      al16(a.R) && !(a.ldr & 3))
+    return launch_thin_k(a, st);
+  return THIN_NA;
+}

@@ -381,6 +381,8 @@ __global__ __launch_bounds__(1024) void colreduce_final_kernel(const float* __re
   __shared__ float sh[16][64];
   const int t = threadIdx.x & 63, l = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + t;
+  part += (long)blockIdx.y * P * C;  // segmented form (indm_segreduce_f32): one output row per blockIdx.y
+  out += (long)blockIdx.y * C;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < C) {
     int p = l;
@@ -565,6 +567,32 @@ INDM_API int indm_colreduce_f32(const float* x, const float* y, float* out, long
   hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C4, 64), (int)P), dim3(256), 0, st, x, y, ws, R, C, mode, rpb);
   INDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, ws, out, C, (int)P, alpha, beta);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+// Segmented column sums: out[s][c] = alpha * sum_{r < rps} x[(s*rps + r)*C + c]  -- the per-image bias gradients
+// (bias2 of the GEMM / conv epilogues: losses w.r.t. the flow's conditioning bias and the score net's temb bias).
+// Each segment is cut into S row blocks (S | rps) so that ~2048 workgroups stream the tensor; deterministic.
+static long segreduce_split(long nseg, long rps, int C) {
+  const int cb = ((C + 3) / 4 + 63) / 64;
+  long S = 1;
+  while (S < 64 && nseg * S * cb < 2048 && rps % (2 * S) == 0 && rps / (2 * S) >= 16) S *= 2;
+  return S;
+}
+INDM_API long indm_segreduce_ws_floats(long nseg, long rps, int C) { return nseg * segreduce_split(nseg, rps, C) * C; }
+INDM_API int indm_segreduce_f32(const float* x, float* out, long nseg, long rps, int C, float alpha, float* ws,
+                                void* stream) {
+  if (C <= 0 || nseg <= 0) return INDM_OK;
+  if (rps <= 0) return INDM_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const long S = segreduce_split(nseg, rps, C);
+  if (nseg * S > 65535) return INDM_E_SHAPE;
+  const int C4 = (C + 3) / 4;
+  hipLaunchKernelGGL(colreduce_part_kernel, dim3(cdiv(C4, 64), (int)(nseg * S)), dim3(256), 0, st, x, (const float*)nullptr,
+                     ws, nseg * rps, C, 0, rps / S);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64), (int)nseg), dim3(1024), 0, st, ws, out, C, (int)S, alpha, 0.f);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

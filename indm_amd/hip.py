@@ -50,6 +50,9 @@ _SIGS = {
     "indm_softmax_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_f, c_p],
     "indm_colreduce_ws_floats": [c_l, c_i],
     "indm_colreduce_f32": [c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_f, c_p, c_p],
+    "indm_segreduce_ws_floats": [c_l, c_l, c_i],
+    "indm_segreduce_f32": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
+    "indm_igemm_last_variant": [],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
@@ -90,7 +93,7 @@ _SIGS = {
                            c_p],
     "indm_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
 }
-_LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_rowreduce_ws_floats",
+_LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_segreduce_ws_floats", "indm_rowreduce_ws_floats",
              "indm_dsm_ws_floats", "indm_sqnorm_ws_floats"}
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
@@ -108,7 +111,7 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = c_l if name in _LONG_RET else c_i
+            fn.restype = c_l if name in _LONG_RET else (ctypes.c_char_p if name == "indm_igemm_last_variant" else c_i)
         _lib = L
     return _lib
 
@@ -163,6 +166,7 @@ class _Profile:
     enabled = False
     only = None
     rec = {}
+    shapes = bool(os.environ.get("INDM_PROFILE_SHAPES"))
 
 
 def profile_start(only=None):
@@ -180,68 +184,16 @@ def profile_stop():
     return out
 
 
-def _big_tile_n(M, N, K, batch):
-    """mirror of big_tile_n() in csrc/igemm.hip (only used to LABEL launches for the live profile)"""
-    if N < 64 or M < 1024 or K % 16:
-        return 0
-    tn = 256 if -(-N // 256) * 256 <= -(-N // 128) * 128 else 128
-    if tn == 256 and K < 1024:
-        tn = 128
-    if -(-M // 256) * -(-N // tn) * batch >= 224:
-        return tn
-    if tn == 256 and -(-M // 256) * -(-N // 128) * batch >= 224:
-        return 128
-    return 0
-
-
-def _tile(M, N, K, amode="", bmode="", batch=1, splitk=False, gated=False):
-    if _MFMA["dtype"] == "bf16":  # the big-tile kernels are fp32-only
-        return _tile_8wave(M, N, amode, batch, splitk) + ",bf16"
-    if amode == "A_COL" and bmode == "B_ROW" and M >= 256 and N >= 256 and M % 4 == 0 and N % 4 == 0 and \
-            K % 16 == 0 and K >= 8192 and -(-M // 256) * -(-N // 256) * batch <= 64 and \
-            K // max(1, 256 // (-(-M // 256) * -(-N // 256) * batch)) >= 512:
-        return "big256x256"  # weight-grad GEMM on the big-tile split-K path
-    if amode == "A_WGRAD" and M >= 256 and N >= 128 and N % 4 == 0 and K % 16 == 0 and K >= 16384:
-        tn = 256 if N % 256 == 0 else 128
-        tiles = -(-M // 256) * -(-N // tn)
-        if tiles <= 128 and K // max(1, (256 if tn == 256 else 512) // tiles) >= 512:
-            return f"big256x{tn}"  # convolution weight grad on the big-tile split-K path
-    if amode == "A_ROW" and bmode in ("B_ROW", "B_COL") and not splitk and K % 16 == 0 and M >= 1024 and N >= 64 and \
-            (bmode == "B_COL" or N % 4 == 0) and -(-M // 256) * -(-N // 128) * batch >= 224 and \
-            not (not gated and K >= 1024 and _big_tile_n(M, N, K, batch) == 256):
-        return "glds256x128"  # direct-to-LDS staging kernel (gated or not)
-    if amode == "A_CONV" and bmode in ("B_ROW", "B_DGRAD") and not gated and not splitk and K % 16 == 0 and \
-            M >= 1024 and N >= 64 and N % 4 == 0 and -(-M // 256) * -(-N // 128) * batch >= 224 and \
-            not (bmode == "B_DGRAD" and _big_tile_n(M, N, K, batch) == 256):
-        return "glds256x128"  # implicit-GEMM convolution on the direct-to-LDS kernel (needs Cin % 16 == 0: K % 144)
-    if not gated and not splitk and (amode == "A_ROW" or (amode == "A_CONV" and bmode == "B_DGRAD")) and \
-            (bmode != "B_ROW" or N % 4 == 0):
-        tn = _big_tile_n(M, N, K, batch)
-        if tn and (amode == "A_ROW" or tn == 256):
-            return f"big256x{tn}"
-    return _tile_8wave(M, N, amode, batch, splitk)
-
-
-def _tile_8wave(M, N, amode, batch, splitk):
-    if N <= 32 and M > 32:
-        return "128x32"
-    if M <= 128 and -(-M // 32) * -(-N // 128) * batch <= 512:
-        return "32x128"
-    if amode in ("A_ROW", "A_CONV") and not splitk and N >= 128 and -(-M // 256) * -(-N // 128) * batch >= 256:
-        return "256x128"
-    return "128x128"
-
-
 class _timed:
+    """HIP-event bracket around one dense launch.  The class key names the kernel variant the C side actually
+    dispatched to (indm_igemm_last_variant) -- no Python mirror of the dispatch rules."""
+
     def __init__(self, amode, bmode, M, N, K, batch=1, splitk=False, nbytes=None, gated=False):
-        tile = _tile(M, N, K, amode, bmode, batch, splitk, gated)
-        if gated and tile.startswith("glds"):
-            tile += ",gated"      # its own template instantiation (igemm_glds_kernel<..., true, 8>): its own class
-        self.key = f"igemm<{amode},{bmode},{tile}>"
+        self.amode, self.bmode, self.shape = amode, bmode, (M, N, K, batch)
         self.flops = 2.0 * M * N * K * batch
         # algorithmic bytes: every operand read once, the result written once (conv callers pass the image size)
         self.bytes = float(nbytes) if nbytes is not None else 4.0 * batch * (M * K + K * N + M * N)
-        self.on = _Profile.enabled and (_Profile.only is None or _Profile.only == self.key)
+        self.on = _Profile.enabled
 
     def __enter__(self):
         if self.on:
@@ -253,10 +205,14 @@ class _timed:
     def __exit__(self, *a):
         if self.on:
             self.e1.record()
-            r = _Profile.rec.setdefault(self.key, [[0.0, 0.0], []])
-            r[0][0] += self.flops
-            r[0][1] += self.bytes
-            r[1].append((self.e0, self.e1))
+            key = f"igemm<{self.amode},{self.bmode},{lib().indm_igemm_last_variant().decode()}>"
+            if _Profile.shapes:  # INDM_PROFILE_SHAPES=1: one class per problem shape (tools / bench stderr table only)
+                key += " M=%d N=%d K=%d b=%d" % self.shape
+            if _Profile.only is None or _Profile.only == key:
+                r = _Profile.rec.setdefault(key, [[0.0, 0.0], []])
+                r[0][0] += self.flops
+                r[0][1] += self.bytes
+                r[1].append((self.e0, self.e1))
         return False
 
 
@@ -507,6 +463,20 @@ def colreduce(x, y=None, mode=0, alpha=1.0):
     ws = _ws(lib().indm_colreduce_ws_floats(R, C), x.device)
     _chk(lib().indm_colreduce_f32(_ptr(x), _ptr(y), _ptr(out), R, C, mode, alpha, 0.0, _ptr(ws), _stream()),
          "indm_colreduce_f32")
+    return out
+
+
+def segreduce(x, rows_per_seg, alpha=1.0):
+    """out[s, c] = alpha * sum of the s-th run of rows_per_seg rows of x (viewed as [rows, C]): per-image bias grads."""
+    C = x.shape[-1]
+    R = x.numel() // C
+    if R % rows_per_seg:
+        raise RuntimeError("segreduce: rows do not divide into segments")
+    nseg = R // rows_per_seg
+    out = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().indm_segreduce_ws_floats(nseg, rows_per_seg, C), x.device)
+    _chk(lib().indm_segreduce_f32(_ptr(x), _ptr(out), nseg, rows_per_seg, C, alpha, _ptr(ws), _stream()),
+         "indm_segreduce_f32")
     return out
 
 

@@ -53,13 +53,11 @@ class _Gemm(Function):
                 db = hip.gemm(dc, a, True, ta, alpha, splitk=sk)                   # dC^T op(A)  (stored [N,K])
             else:  # the gate rides on the A-operand loader: form op(A.*G)^T dC = dB^T and transpose the small result
                 db = hip.gemm(a, dc, not ta, False, alpha, splitk=sk, gate=gate).transpose(-1, -2).contiguous()
-        if has_bias and ctx.needs_input_grad[2]:
-            dbias = hip.colreduce(dc, None, 0, alpha)
         if has_bias2 and ctx.needs_input_grad[3]:
-            n = dc.shape[-1]
-            g = dc.reshape(-1, rpg, n)
-            ones = torch.ones((1, rpg), dtype=torch.float32, device=dc.device)
-            dbias2 = hip.gemm(ones, g, False, False, alpha).reshape(-1, n)
+            dbias2 = hip.segreduce(dc, rpg, alpha)           # per-image sums: one pass over dc
+        if has_bias and ctx.needs_input_grad[2]:
+            # the per-image sums already hold the whole reduction: no second pass over dc
+            dbias = dbias2.sum(0) if dbias2 is not None else hip.colreduce(dc, None, 0, alpha)
         if has_res and ctx.needs_input_grad[4]:
             dres = hip.axpby(dc, None, beta, 0.0)
         return da, db, dbias, dbias2, dres, None, None, None, None, None, None, dgate
@@ -112,12 +110,10 @@ class _Conv2d(Function):
             dx = hip.conv2d_dgrad(dy, w, (x.shape[1], x.shape[2]), stride, pad, alpha)
         if ctx.needs_input_grad[1]:
             dw = hip.conv2d_wgrad(x, dy, w.shape[0], w.shape[1], stride, pad, alpha)
-        if has_bias and ctx.needs_input_grad[2]:
-            dbias = hip.colreduce(dy, None, 0, alpha)
         if has_bias2 and ctx.needs_input_grad[3]:
-            N, OH, OW, Co = dy.shape
-            ones = torch.ones((1, OH * OW), dtype=torch.float32, device=dy.device)
-            dbias2 = hip.gemm(ones, dy.reshape(N, OH * OW, Co), False, False, alpha).reshape(N, Co)
+            dbias2 = hip.segreduce(dy, dy.shape[1] * dy.shape[2], alpha)   # per-image sums: one pass over dy
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = dbias2.sum(0) if dbias2 is not None else hip.colreduce(dy, None, 0, alpha)
         if has_res and ctx.needs_input_grad[4]:
             dres = hip.axpby(dy, None, beta, 0.0)
         return dx, dw, dbias, dbias2, dres, None, None, None, None

@@ -183,6 +183,11 @@ def colreduce(x, y=None, mode=0, alpha=1.0):
     return alpha * v.reshape(-1, x.shape[-1]).sum(0)
 
 
+def segreduce(x, rows_per_seg, alpha=1.0):
+    C = x.shape[-1]
+    return alpha * x.reshape(-1, rows_per_seg, C).sum(1)
+
+
 def sincos_fwd(p, want_d=True):
     a = torch.sin(2 * math.pi * p) / (2 * math.pi)
     return a, (torch.cos(2 * math.pi * p) if want_d else None)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     text = open(os.path.join(ROOT, "include", "indm_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|long)\s+(indm_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|long|const char\*)\s+(indm_\w+)\s*\(", text)))
 
 
 def test_header_matches_binding():

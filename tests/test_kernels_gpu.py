@@ -100,6 +100,22 @@ def test_gemm_big_tile(M, N, K, tb):
     close(out, ref, rtol=1e-5, atol=1e-4, name="big gemm gated + epilogue")
 
 
+# ---- thin kernels (igemm_thin.hip): HBM-streaming GEMMs with one dimension <= 128 ---------------------------------
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 27), (2048 + 77, 512, 27), (1500, 132, 5), (3000, 256, 32),
+                                   (4096 + 3, 512, 108), (1024, 128, 128), (2000, 640, 36), (1111, 512, 1)])
+def test_gemm_thin_k(M, N, K):
+    """thin-K form (3x3 conv with a skinny input after tap_spread): flat A tiles (lda == K <= 32) and chunked K"""
+    a, b = rnd(M, K), rnd(K, N, seed=1)
+    out, ref = run_both("gemm", a, b)
+    close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), name="thin-K gemm")
+    for rpg in (M, 7, 100, 8, 1024):
+        if M % rpg:
+            continue
+        bias, bias2, res = rnd(N, seed=2), rnd(M // rpg, N, seed=3), rnd(M, N, seed=4)
+        out, ref = run_both("gemm", a, b, alpha=0.5, bias=bias, bias2=bias2, rows_per_group=rpg, res=res, beta=-1.5)
+        close(out, ref, rtol=1e-5, atol=1e-4, name=f"thin-K gemm + epilogue rpg={rpg}")
+
+
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", [(64, 32, 32, 16, 128, 3, 1, 1), (32, 32, 32, 32, 512, 3, 1, 1),
                                                (57, 32, 32, 16, 256, 1, 1, 0), (64, 32, 32, 32, 128, 3, 2, 1)])
 def test_conv_big_tile(N, H, W, Ci, Co, k, s, p):
@@ -341,6 +357,13 @@ def test_reductions_elementwise():
     close(o, r, name="mul")
     o, r = run_both("scale_rows", da, rnd(3, seed=9))
     close(o, r, name="scale_rows")
+
+
+@pytest.mark.parametrize("nseg,rps,C", [(128, 1024, 512), (8, 256, 512), (5, 17, 130), (3, 64, 3), (1, 1000, 256)])
+def test_segreduce(nseg, rps, C):
+    x = rnd(nseg * rps, C)
+    out, ref = run_both("segreduce", x, rps, alpha=0.5)
+    close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(rps), name="segreduce")
 
 
 def test_resample_permutes():
