@@ -1282,9 +1282,10 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip
     const ThinGemmArgs t = {p.A, p.G, p.B, p.C, p.M, p.N, p.K, am == A_COL, bm == B_COL, p.lda, p.ldb, p.ldc, p.batch,
                             p.alpha, p.beta, p.bias, p.bias2, p.rpg, p.R, p.ldr, ws, ws_floats};
-    const int r = indm_thin_gemm(t, st);
+    const char* name = "";
+    const int r = indm_thin_gemm(t, st, &name);
     if (r != THIN_NA) {
-      last_variant = "thin128x128";
+      last_variant = name;
       return r;
     }
   }

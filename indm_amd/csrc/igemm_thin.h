@@ -25,4 +25,5 @@ struct ThinGemmArgs {
 
 enum { THIN_NA = 1 };
 
-int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st);
+// *variant names the kernel that ran ("thin_k128x128" | "thin_wgrad32x128" | "thin_wgrad128x128")
+int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st, const char** variant);

@@ -368,13 +368,205 @@ int launch_thin_k(const ThinGemmArgs& a, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// thin weight grads:  D[t, c] = sum_p thin[p, t] * (wide[p, c] * gate[p, c]),   t < T <= 128,  c < N (512),  p < P.
+// (3x3 convs with a skinny side: T = 27 / 108 taps x channels, P = pixels.)  One pass over the wide tensor (+ gate):
+// HBM-bound for T = 27, MFMA-bound for T = 108.  Both operands are stored [pixel][column] = the [k][row] LDS layout,
+// so slabs of 32 pixels are copied with float4 loads / ds_write_b128 (the thin one is a contiguous run of 32*T floats).
+// grid = (N / 128 column tiles) x (S pixel chunks); block tile TP x 128 (TP = 32: one 32x32 MFMA tile per wave;
+// TP = 128: 2x2 waves of 64x64); partial sums -> ws[s][t][c]; thin_wgrad_reduce adds them in a fixed order
+// (deterministic) and writes D or its transpose (the form whose OUTPUT is [wide column][t]).
+constexpr int TW_BK = 32, TW_TN = 128, TW_LDB = TW_TN + 4;
+
+template <int TP, bool HAS_G>
+__global__ __launch_bounds__(256, (TP == 32 ? 3 : 2)) void thin_wgrad_kernel(const float* __restrict__ thin,
+                                                                             const float* __restrict__ wide,
+                                                                             const float* __restrict__ gate, float* __restrict__ ws,
+                                                                             int T, int N, long ldw, int chunk, int P) {
+  constexpr int LDA = TP + 4;
+  constexpr int RM = TP == 32 ? 1 : 2, RN = TP == 32 ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) float smem[2 * TW_BK * (LDA + TW_LDB)];
+  float* As = smem;
+  float* Bs = smem + 2 * TW_BK * LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n0 = blockIdx.x * TW_TN;
+  const int p_beg = blockIdx.y * chunk, p_end = min(P, p_beg + chunk);
+  const int nslab = (p_end - p_beg) / TW_BK;
+  const int mw = TP == 32 ? 0 : (wave >> 1) * 64, nw = TP == 32 ? wave * 32 : (wave & 1) * 64;
+
+  // zero the pad columns [T, TP) of both A buffers once (slabs only write t < T)
+  for (int i = tid; i < 2 * TW_BK * LDA; i += 256) As[i] = 0.f;
+  __syncthreads();
+
+  // thin slab = 32*T contiguous floats; this thread's float4 groups and their (pixel, t) inside the slab
+  const int tgroups = (TW_BK * T) >> 2;
+  int tpx[4], tt[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e0 = (tid + j * 256) * 4;
+    tpx[j] = e0 / T;
+    tt[j] = e0 - tpx[j] * T;
+  }
+  float4 rt[4], rw[4], rg[4];
+  auto gload = [&](int sl) {
+    const long p0 = p_beg + (long)sl * TW_BK;
+    const float* tsrc = thin + p0 * T;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tid + j * 256 < tgroups) rt[j] = *(const float4*)(tsrc + (tid + j * 256) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid + j * 256;
+      const int px = g >> 5, c4 = (g & 31) * 4;
+      rw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + c4 < N) {
+        rw[j] = *(const float4*)(wide + (p0 + px) * ldw + n0 + c4);
+        if constexpr (HAS_G) rg[j] = *(const float4*)(gate + (p0 + px) * ldw + n0 + c4);
+      } else if constexpr (HAS_G) {
+        rg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* as = As + buf * TW_BK * LDA;
+    float* bs = Bs + buf * TW_BK * TW_LDB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (tid + j * 256 < tgroups) {
+        int px = tpx[j], t = tt[j];
+        const float v[4] = {rt[j].x, rt[j].y, rt[j].z, rt[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          as[px * LDA + t] = v[q];
+          if (++t == T) { t = 0; ++px; }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid + j * 256;
+      const int px = g >> 5, c4 = (g & 31) * 4;
+      float4 v = rw[j];
+      if constexpr (HAS_G) { v.x *= rg[j].x; v.y *= rg[j].y; v.z *= rg[j].z; v.w *= rg[j].w; }
+      *(float4*)(bs + px * TW_LDB + c4) = v;
+    }
+  };
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nslab > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int buf = sl & 1;
+    if (sl + 1 < nslab) gload(sl + 1);
+    const float* af = As + buf * TW_BK * LDA + mw + l31;
+    const float* bf = Bs + buf * TW_BK * TW_LDB + nw + l31;
+#pragma unroll
+    for (int kk = 0; kk < TW_BK / 2; ++kk) {
+      const int k = 2 * kk + lhi;
+      float a[RM], b[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) a[i] = af[k * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < RN; ++j) b[j] = bf[k * TW_LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (sl + 1 < nslab) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = ws + (long)blockIdx.y * T * N;
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int c = n0 + nw + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (t < T && c < N) out[(long)t * N + c] = acc[i][j][r];
+      }
+    }
+}
+
+// out = alpha * sum_s ws[s][t][c]  (+ beta * R, same layout as out), written as D[t][c] (ldo) or transposed [c][t] (ldo)
+__global__ void thin_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ out, int S, int T, int N, float alpha,
+                                  int transpose, long ldo) {
+  const int total = T * N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int t = i / N, c = i - t * N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 3 < S; s += 4) {
+    s0 += ws[(long)s * total + i];
+    s1 += ws[(long)(s + 1) * total + i];
+    s2 += ws[(long)(s + 2) * total + i];
+    s3 += ws[(long)(s + 3) * total + i];
+  }
+  for (; s < S; ++s) s0 += ws[(long)s * total + i];
+  const float v = alpha * ((s0 + s1) + (s2 + s3));
+  if (transpose) out[(long)c * ldo + t] = v;
+  else out[(long)t * ldo + c] = v;
+}
+
+// thin: [P, T] contiguous; wide (+gate): [P, N] with row stride ldw; out: [T, N] (ldo) or, transposed, [N, T] (ldo)
+int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, float* out, int T, int N, long P, long ldw,
+                      float alpha, int transpose, long ldo, float* ws, long ws_floats, hipStream_t st) {
+  if (T < 1 || T > 128 || (N & 3) || (ldw & 3) || (P % TW_BK) || P < 4096 || P > (1L << 30)) return THIN_NA;
+  if (!al16(thin) || !al16(wide) || !al16(gate) || !ws) return THIN_NA;
+  const int tiles_n = cdiv(N, TW_TN);
+  long S = (T <= 32 ? 768 : 512) / tiles_n;  // ~3 (TP = 32) / 2 (TP = 128) blocks per CU
+  if (S < 1) S = 1;
+  int chunk = cdiv(cdiv(P, S), TW_BK) * TW_BK;
+  S = cdiv(P, chunk);
+  if (S * T * N > ws_floats || S > 65535) return THIN_NA;
+  dim3 grid(tiles_n, (unsigned)S);
+  if (T <= 32) {
+    if (gate) hipLaunchKernelGGL((thin_wgrad_kernel<32, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+    else hipLaunchKernelGGL((thin_wgrad_kernel<32, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+  } else {
+    if (gate) hipLaunchKernelGGL((thin_wgrad_kernel<128, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+    else hipLaunchKernelGGL((thin_wgrad_kernel<128, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+  }
+  if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+  hipLaunchKernelGGL(thin_wgrad_reduce, dim3(cdiv((long)T * N, 256)), dim3(256), 0, st, ws, out, (int)S, T, N, alpha, transpose, ldo);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
 }  // namespace
 
-int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st) {
+int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st, const char** variant) {
   if (a.batch != 1) return THIN_NA;
   if (!a.transA && !a.transB && !a.G && a.K >= 1 && a.K <= 128 && a.N >= 128 && !(a.N & 3) && a.M >= 1024 &&
       !(a.ldb & 3) && !(a.ldc & 3) && al16(a.A) && al16(a.B) && al16(a.C) && al16(a.bias) && al16(a.bias2) &&
-      al16(a.R) && !(a.ldr & 3))
+      al16(a.R) && !(a.ldr & 3)) {
+    *variant = "thin_k128x128";
     return launch_thin_k(a, st);
+  }
+  // weight-grad forms: reduction over pixels (K), A stored [K, M]
+  if (a.transA && !a.transB && !a.bias && !a.bias2 && !a.R && a.K >= 4096) {
+    // thin^T x wide -> [T, N]  (A = thin, contiguous [K, M]; B = wide)
+    *variant = (a.M <= 128 ? a.M : a.N) <= 32 ? "thin_wgrad32x128" : "thin_wgrad128x128";
+    if (a.M <= 128 && a.N >= 256 && !a.G && a.lda == a.M)
+      return launch_thin_wgrad(a.A, a.B, nullptr, a.C, a.M, a.N, a.K, a.ldb, a.alpha, 0, a.ldc, a.ws, a.ws_floats, st);
+    // (wide .* gate)^T x thin -> [N_wide, T]  (A = wide (+ gate), B = thin contiguous [K, N])
+    if (a.N <= 128 && a.M >= 256 && a.ldb == a.N)
+      return launch_thin_wgrad(a.B, a.A, a.G, a.C, a.N, a.M, a.K, a.lda, a.alpha, 1, a.ldc, a.ws, a.ws_floats, st);
+  }
   return THIN_NA;
 }

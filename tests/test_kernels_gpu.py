@@ -116,6 +116,18 @@ def test_gemm_thin_k(M, N, K):
         close(out, ref, rtol=1e-5, atol=1e-4, name=f"thin-K gemm + epilogue rpg={rpg}")
 
 
+@pytest.mark.parametrize("T,N,P", [(27, 512, 8192), (108, 512, 4096), (5, 256, 4096 + 32), (128, 640, 6400), (12, 260, 4128)])
+def test_gemm_thin_wgrad(T, N, P):
+    """weight-grad forms with a skinny side: thin^T wide -> [T, N] and (wide .* gate)^T thin -> [N, T]"""
+    thin, wide, gate = rnd(P, T), rnd(P, N, seed=1), rnd(P, N, seed=2)
+    out, ref = run_both("gemm", thin, wide, trans_a=True, splitk=True, alpha=0.5)
+    close(out, ref, rtol=1e-5, atol=3e-3, name="thin^T wide")
+    out, ref = run_both("gemm", wide, thin, trans_a=True, splitk=True)
+    close(out, ref, rtol=1e-5, atol=3e-3, name="wide^T thin")
+    out, ref = run_both("gemm", wide, thin, trans_a=True, splitk=True, gate=gate, alpha=2.0)
+    close(out, ref, rtol=1e-5, atol=3e-3, name="(wide.gate)^T thin")
+
+
 @pytest.mark.parametrize("N,H,W,Ci,Co,k,s,p", [(64, 32, 32, 16, 128, 3, 1, 1), (32, 32, 32, 32, 512, 3, 1, 1),
                                                (57, 32, 32, 16, 256, 1, 1, 0), (64, 32, 32, 32, 128, 3, 2, 1)])
 def test_conv_big_tile(N, H, W, Ci, Co, k, s, p):
