@@ -150,6 +150,8 @@ int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);
 int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);
 int indm_axpby_f32(const float* x, const float* y, float* out, float a, float b, float c, long n, void* stream);
 int indm_mul_f32(const float* x, const float* y, float* out, float alpha, long n, void* stream);
+/* out1 = x*y1, out2 = x*y2 in one pass: the backward of a gated contraction (d(v.*g) -> dv = d.*g, dg = d.*v). */
+int indm_mul2_f32(const float* x, const float* y1, const float* y2, float* out1, float* out2, long n, void* stream);
 int indm_scale_rows_f32(const float* x, const float* s, float* out, long B, long D, void* stream);
 /* naive_upsample_2d / naive_downsample_2d, models/up_or_down_sampling.py:59-69 (NHWC) */
 int indm_upsample2x_f32(const float* x, float* y, int N, int H, int W, int C, float alpha, void* stream);

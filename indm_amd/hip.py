@@ -59,6 +59,7 @@ _SIGS = {
     "indm_act_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
     "indm_axpby_f32": [c_p, c_p, c_p, c_f, c_f, c_f, c_l, c_p],
     "indm_mul_f32": [c_p, c_p, c_p, c_f, c_l, c_p],
+    "indm_mul2_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_scale_rows_f32": [c_p, c_p, c_p, c_l, c_l, c_p],
     "indm_rowreduce_ws_floats": [c_l, c_l],
     "indm_rowreduce_f32": [c_p, c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
@@ -555,6 +556,13 @@ def mul(x, y, alpha=1.0):
     out = torch.empty_like(x)
     _chk(lib().indm_mul_f32(_ptr(x), _ptr(y), _ptr(out), alpha, x.numel(), _stream()), "indm_mul_f32")
     return out
+
+
+def mul2(x, y1, y2):
+    """(x*y1, x*y2) in one pass over x."""
+    o1, o2 = torch.empty_like(x), torch.empty_like(x)
+    _chk(lib().indm_mul2_f32(_ptr(x), _ptr(y1), _ptr(y2), _ptr(o1), _ptr(o2), x.numel(), _stream()), "indm_mul2_f32")
+    return o1, o2
 
 
 def scale_rows(x, s):

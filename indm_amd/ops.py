@@ -43,6 +43,8 @@ class _Gemm(Function):
                 dag = hip.gemm(b, dc, tb, True, alpha)                 # op(B) dC^T  (stored [K,M])
             if gate is None:
                 da = dag
+            elif ctx.needs_input_grad[0] and ctx.needs_input_grad[11]:
+                da, dgate = hip.mul2(dag, gate, a)      # both products in one pass over dag
             else:
                 da = hip.mul(dag, gate) if ctx.needs_input_grad[0] else None
                 dgate = hip.mul(dag, a) if ctx.needs_input_grad[11] else None
@@ -144,6 +146,8 @@ class _Conv2dT(Function):
             dvg = hip.conv2d(dt, w, stride, pad)
             if gate is None:
                 dv = dvg
+            elif ctx.needs_input_grad[0] and ctx.needs_input_grad[5]:
+                dv, dgate = hip.mul2(dvg, gate, v)
             else:
                 dv = hip.mul(dvg, gate) if ctx.needs_input_grad[0] else None
                 dgate = hip.mul(dvg, v) if ctx.needs_input_grad[5] else None

@@ -183,6 +183,10 @@ def colreduce(x, y=None, mode=0, alpha=1.0):
     return alpha * v.reshape(-1, x.shape[-1]).sum(0)
 
 
+def mul2(x, y1, y2):
+    return x * y1, x * y2
+
+
 def segreduce(x, rows_per_seg, alpha=1.0):
     C = x.shape[-1]
     return alpha * x.reshape(-1, rows_per_seg, C).sum(1)

@@ -378,6 +378,16 @@ def test_segreduce(nseg, rps, C):
     close(out, ref, rtol=1e-5, atol=1e-5 * math.sqrt(rps), name="segreduce")
 
 
+@pytest.mark.parametrize("n", [4096, 1000003, 7])
+def test_mul_mul2(n):
+    x, y1, y2 = rnd(n), rnd(n, seed=1), rnd(n, seed=2)
+    out, ref = run_both("mul", x, y1, alpha=0.5)
+    close(out, ref, name="mul")
+    (o1, o2), (r1, r2) = run_both("mul2", x, y1, y2)
+    close(o1, r1, name="mul2[0]")
+    close(o2, r2, name="mul2[1]")
+
+
 def test_resample_permutes():
     x = rnd(2, 8, 8, 12)
     for fn in ("upsample2x", "downsample2x", "squeeze2x"):

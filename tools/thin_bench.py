@@ -48,3 +48,8 @@ timeit(lambda: hip.colreduce(x, None, 0), 4.0 * x.numel(), 1, "colreduce [131072
 for (M, N, K) in [(128, 512, 256), (128, 256, 512), (128, 512, 128)]:
     a, b = r(M, K), r(K, N)
     timeit(lambda: hip.gemm(a, b), 4.0 * (M * K + K * N + M * N), 2.0 * M * N * K, f"small   [{M},{K}]x[{K},{N}]")
+x, y1, y2 = r(131072, 512), r(131072, 512), r(131072, 512)
+timeit(lambda: hip.mul(x, y1), 12.0 * x.numel(), 1, "mul (2 reads 1 write)")
+timeit(lambda: hip.mul2(x, y1, y2), 20.0 * x.numel(), 1, "mul2 (3 reads 2 writes)")
+timeit(lambda: hip.sincos_fwd(x), 12.0 * x.numel(), 1, "sincos fwd (1 read 2 writes)")
+timeit(lambda: hip.axpby(x, y1, 1.0, 1.0), 12.0 * x.numel(), 1, "axpby (2 reads 1 write)")
