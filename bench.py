@@ -215,7 +215,7 @@ def main():
     score.train(); flow.train()
     batches = [synthetic_batch(args.batch, cfg.data.image_size, 1234 + rank + 1000 * i, dev)
                for i in range(args.steps + args.warmup)]
-    rng = DeviceRng(dev, seed=1234 + rank)
+    rng = DeviceRng(dev, seed=1234 + rank, poisson_seed=4321)   # same series lengths on every rank: balanced steps
 
     def barrier():
         if dist_on:

@@ -142,6 +142,11 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
     def _zero(state):
         state["optimizer"].zero_grad()
 
+    def _step_rng(device, step):
+        """default noise source of a step: per-rank noise, rank-independent series lengths (see DeviceRng)"""
+        rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+        return DeviceRng(device, seed=step + 1 + 7919 * rank, poisson_seed=step + 3)
+
     class _HostLosses:
         """The per-image loss vectors the step returns on the CPU (reference API: losses.py:281-284,320).  Their
         device->host copy is enqueued right after the FORWARD pass (pinned buffer, non-blocking) and only that copy's
@@ -201,7 +206,7 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
 
     def flow_step_fn_nll(state, flow_state, batch, rng=None):
         """losses.py:258-320"""
-        rng = rng or DeviceRng(batch.device, seed=state["step"] + 1)
+        rng = rng or _step_rng(batch.device, state["step"])
         B = batch.shape[0]
         nmb = config.optim.num_micro_batch
         outs = _HostLosses(4)
@@ -223,7 +228,7 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         """losses.py:322-406 (training.st=False)"""
         if config.training.st:
             raise NotImplementedError("training.st=True is not used by any shipped config")
-        rng = rng or DeviceRng(batch.device, seed=state["step"] + 1)
+        rng = rng or _step_rng(batch.device, state["step"])
         B = batch.shape[0]
         nmb = config.optim.num_micro_batch
         outs = _HostLosses(4)

@@ -12,12 +12,16 @@ import torch
 
 
 class DeviceRng:
-    def __init__(self, device, seed=0):
+    def __init__(self, device, seed=0, poisson_seed=None):
+        """seed: noise streams (per rank in data-parallel runs).  poisson_seed: stream of the residual-flow series
+        lengths n ~ Poisson(2) (iresblock.py:110-113); data-parallel ranks pass the SAME value so that every rank
+        unrolls the same number of vector-Jacobian products per block -- the single-device reference draws one n per
+        block for its whole batch, and equal work per rank removes the wait-for-the-slowest at the all-reduce."""
         self.device = torch.device(device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         self.cpu_gen = torch.Generator().manual_seed(seed + 1)
-        self.np = np.random.RandomState(seed + 2)
+        self.np = np.random.RandomState((seed + 2 if poisson_seed is None else poisson_seed) % (1 << 32))
         self._drop = seed * 1000003 + 12345
 
     def randn_image(self, n, c, h, w):
