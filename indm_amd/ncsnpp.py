@@ -182,7 +182,9 @@ class ResnetBlockBigGANpp(nn.Module):
                 h, x = self.firop.downsample(h), self.firop.downsample(x)
             else:
                 h, x = ops.downsample2x(h), ops.downsample2x(x)
-        tb = self.Dense_0(temb_act) if temb_act is not None else None
+        tb = self.__dict__.pop("tb_next", None)     # precomputed by NCSNpp.forward for all blocks at once
+        if tb is None and temb_act is not None:
+            tb = self.Dense_0(temb_act)
         h = self.Conv_0(h, bias2=tb)
         drop = self.dropout if self.training else 0.0
         seed = rng.dropout_seed() if (drop > 0 and rng is not None) else 0
@@ -346,6 +348,14 @@ class NCSNpp(nn.Module):
         temb = mods[i](temb); i += 1
         temb = mods[i](ops.silu(temb)); i += 1
         temb_act = ops.silu(temb)
+        # Dense_0(act(temb)) of ALL residual blocks (layerspp.py:262-263) as ONE [B,512] x [512, sum C] GEMM instead of
+        # 44 short-M launches forward and 3 x 44 backward; every block takes its (contiguous) column slice as bias2
+        blocks = [m for m in mods if isinstance(m, ResnetBlockBigGANpp) and hasattr(m, "Dense_0")]
+        if blocks:
+            tb_all = ops.linear(temb_act, torch.cat([b.Dense_0.weight for b in blocks], dim=0),
+                                torch.cat([b.Dense_0.bias for b in blocks], dim=0))
+            for b, t in zip(blocks, tb_all.split([b.out_ch for b in blocks], dim=1)):
+                b.tb_next = t.contiguous()
         h0 = x if nhwc else ops.to_nhwc(x)
         if not self.config.data.centered:
             h0 = ops.axpby(h0, None, 2.0, 0.0, -1.0)  # 2x-1 (ncsnpp.py:278-280)
