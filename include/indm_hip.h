@@ -75,6 +75,13 @@ int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, 
                           int KH, int KW, int stride, int pad, int OH, int OW, float alpha, const float* R,
                           float beta, float* ws, long ws_floats, void* stream);
 
+/* 3x3 / pad 1 / stride 1 convolution whose INPUT has C <= 3 (or C <= 12, C % 4 == 0) channels -- LopConv2d at the
+ * flow's image side, lipschitz.py:321-369 -- with the im2col gather inside the thin-K GEMM's operand loader:
+ * y = alpha*(conv_sign(x, w[9C, Cout]) + bias[co] + bias2[n][co]) + beta*R; sign = -1 forward, +1 transposed conv.
+ * Returns 1 (not an error) when the geometry is not covered; the caller then uses indm_tap_spread_f32 + indm_gemm_f32. */
+int indm_conv3x3_thin_f32(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout, int sign,
+                          float alpha, const float* bias, const float* bias2, const float* R, float beta, void* stream);
+
 /* Name of the kernel variant this thread's last dense launch (gemm / conv2d_*) was dispatched to, e.g.
  * "glds256x128,gated", "big256x256", "thin128x128", "128x32": bench.py labels its live per-kernel timings with it. */
 const char* indm_igemm_last_variant(void);

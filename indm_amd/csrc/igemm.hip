@@ -1391,6 +1391,26 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
 // Kernel variant chosen by this thread's last dense launch ("glds256x128,gated", "big256x256", "thin128x128", ...).
 INDM_API const char* indm_igemm_last_variant(void) { return last_variant; }
 
+// 3x3 / pad 1 / stride 1 convolution with a SKINNY input (the flow's 3-/12-channel edges) as a thin-K GEMM whose operand
+// loader gathers the 9 taps itself (no [pixels, 9C] panel in HBM):
+//   y[p, co] = alpha*(sum_{tap,c} x[n, h - sign*(kh-1), w - sign*(kw-1), c] * w[tap*C + c, co] + bias[co] + bias2[n][co]) + beta*R
+// sign = -1: cross-correlation (conv forward); sign = +1: the transposed convolution (w pre-packed by the caller).
+// Returns 1 when the geometry is not covered (the caller then takes the tap_spread + GEMM route).
+INDM_API int indm_conv3x3_thin_f32(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout,
+                                   int sign, float alpha, const float* bias, const float* bias2, const float* R,
+                                   float beta, void* stream) {
+  if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return INDM_E_SHAPE;
+  if (Nimg == 0) return INDM_OK;
+  ThinGemmArgs t = {};
+  t.B = w; t.C = y; t.M = Nimg * H * W; t.N = Cout; t.K = 9 * C;
+  t.ldb = Cout; t.ldc = Cout; t.batch = 1; t.alpha = alpha; t.beta = beta; t.bias = bias; t.bias2 = bias2; t.rpg = H * W;
+  t.R = R; t.ldr = Cout; t.X = x; t.cH = H; t.cW = W; t.cC = C; t.csign = sign;
+  const int r = indm_thin_conv3x3(t, (hipStream_t)stream);
+  if (r == THIN_NA) return 1;
+  last_variant = C <= 3 ? "thin_conv3x3_flat" : "thin_conv3x3_k128";
+  return r;
+}
+
 // C[b] = alpha * (opA(A[b] .* gateA[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]   (gateA optional)
 //   transA == 0: A is [M,K] row-major (lda);  transA == 1: A is stored [K,M] (lda)
 //   transB == 0: B is [K,N] row-major (ldb);  transB == 1: B is stored [N,K] (ldb)

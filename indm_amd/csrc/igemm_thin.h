@@ -21,9 +21,16 @@ struct ThinGemmArgs {
   long ldr;
   float* ws;  // split-K workspace (weight-grad forms)
   long ws_floats;
+  // implicit im2col (X != NULL): A[p, tap*cC + c] = X[n, h - csign*(kh-1), w - csign*(kw-1), c] of an NHWC image with
+  // cC channels (3x3 taps, zero padding), p = (n, h, w); A / lda are ignored, K = 9*cC, M = images*cH*cW
+  const float* X;
+  int cH, cW, cC, csign;
 };
 
 enum { THIN_NA = 1 };
 
 // *variant names the kernel that ran ("thin_k128x128" | "thin_wgrad32x128" | "thin_wgrad128x128")
 int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st, const char** variant);
+// 3x3 / pad 1 / stride 1 convolution whose INPUT is skinny (C <= 3, or C <= 12 with C % 4 == 0), as a thin-K GEMM with
+// the im2col gather inside the operand loader (THIN_NA when the geometry is not covered)
+int indm_thin_conv3x3(const ThinGemmArgs& a, hipStream_t st);

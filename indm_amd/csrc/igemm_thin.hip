@@ -31,8 +31,11 @@ constexpr int TK_OPER = TK_KC * (TK_LDA + TK_LDB);
 constexpr int TK_STAGE = 4 * 16 * TK_LDS;
 constexpr int TK_SMEM = TK_OPER > TK_STAGE ? TK_OPER : TK_STAGE;
 
-template <bool FLAT>
+enum { TK_STRIDED = 0, TK_FLAT = 1, TK_IM2COL = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
+  constexpr bool FLAT = MODE == TK_FLAT;
   __shared__ __attribute__((aligned(16))) float smem[TK_SMEM];
   float* as = smem;
   float* bs = smem + TK_KC * TK_LDA;
@@ -87,6 +90,31 @@ __global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
         }
       }
       if ((p.K & 1) && tid < TK_TM) as[p.K * TK_LDA + tid] = 0.f;  // odd K: the last k-pair's second half
+    } else if constexpr (MODE == TK_IM2COL) {
+      // A[p, tap*C + c] gathered from the NHWC image: four consecutive k stay inside one tap (C % 4 == 0)
+      const int C = p.cC, W = p.cW, H = p.cH;
+      const float rC = 1.0f / (float)C;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int g = tid + j * 256;
+        const int row = g >> 3, k4 = (g & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int pix = m0 + row, kk = k0 + k4;
+        if (pix < p.M && k4 < kc) {
+          const int tap = (int)(((float)kk + 0.5f) * rC);  // exact for kk < 128
+          const int c = kk - tap * C;
+          const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;  // tap / 3 for tap < 9
+          const int hw = H * W;
+          const int n = pix / hw, r = pix - n * hw;
+          const int h = r / W, w = r - h * W;
+          const int hh = h - p.csign * (kh - 1), ww = w - p.csign * (kw - 1);
+          if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = *(const float4*)(p.X + (((long)n * H + hh) * W + ww) * C + c);
+        }
+        as[(k4 + 0) * TK_LDA + row] = v.x;
+        as[(k4 + 1) * TK_LDA + row] = v.y;
+        as[(k4 + 2) * TK_LDA + row] = v.z;
+        as[(k4 + 3) * TK_LDA + row] = v.w;
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -186,7 +214,17 @@ __device__ __forceinline__ void async_load4(f32x4& dst, const float* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
 }
 
-__global__ __launch_bounds__(256, 3) void igemm_thin_kflat_kernel(ThinGemmArgs p) {
+__device__ float thin_zero_word[4];  // padded taps of the implicit im2col load from here (zero-initialised)
+
+__device__ __forceinline__ void async_load1(float& dst, const float* src) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+
+// IM2COL: the A tile is gathered from a 3-channel NHWC image (K = 27) instead of being read as a flat run: 128
+// consecutive pixels are whole image rows (128 % W == 0, H*W % 128 == 0, host-checked), so the (row, tap) -> source
+// offset table of a thread's 16 elements is the same for every tile and only the row bound depends on the tile.
+template <bool IM2COL>
+__global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel(ThinGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[TF_AS + TF_BS + TF_STG];
   float* as = smem;
   float* bs = smem + TF_AS;
@@ -251,7 +289,9 @@ __global__ __launch_bounds__(256, 3) void igemm_thin_kflat_kernel(ThinGemmArgs p
     *(float4*)(bs + k * TK_LDB + c4) = v;
   }
   if ((K & 1) && tid < TK_TM) as[K * TK_LDA + tid] = 0.f;  // odd K: second half of the last k-pair
-  if (tm < tiles_m) sstore_a(load_tile_sync(tm));
+  if constexpr (!IM2COL) {
+    if (tm < tiles_m) sstore_a(load_tile_sync(tm));
+  }
   const int npairs = (K + 1) >> 1;
   const int c4 = l31 * 4, n = n0 + c4;  // this lane's four output columns: the same for every row it stores
   const bool nok = n < p.N;
@@ -259,6 +299,53 @@ __global__ __launch_bounds__(256, 3) void igemm_thin_kflat_kernel(ThinGemmArgs p
   if (p.bias && nok) bn = *(const float4*)(p.bias + n);
   const float* af = as + wave * 32 + l31;
   const float* bf = bs + l31;
+
+  // ---- implicit im2col: per-thread element table (tile-invariant) and the gather / store helpers
+  int eoff[IM2COL ? 16 : 1], emeta[IM2COL ? 16 : 1];
+  float rv[IM2COL ? 16 : 1];
+  if constexpr (IM2COL) {
+    const int C = p.cC, W = p.cW;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = tid + j * 256;
+      eoff[j] = 0;
+      emeta[j] = 0;
+      if (e < tile_elems) {
+        const int row = e / K, k = e - row * K;
+        const int tap = k / C, c = k - tap * C;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int rh = row / W, rw = row - rh * W;
+        const int hoff = rh - p.csign * (kh - 1), ww = rw - p.csign * (kw - 1);
+        eoff[j] = (hoff * W + ww) * C + c;
+        // bits 0-15: LDS slot, 16-23: row offset + 64, 24: column in range, 25: element exists
+        emeta[j] = (k * TK_LDA + row) | ((hoff + 64) << 16) | ((ww >= 0 && ww < W) ? (1 << 24) : 0) | (1 << 25);
+      }
+    }
+  }
+  auto gather = [&](int tmg) {   // requests tile tmg's elements (asynchronous: see wait_gather)
+    if constexpr (IM2COL) {
+      const int m0 = tmg * TK_TM, hw = p.cH * p.cW;
+      const int img = m0 / hw, h0 = (m0 - img * hw) / p.cW;
+      const float* base = p.X + ((long)img * p.cH + h0) * p.cW * p.cC;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int hh = h0 + ((emeta[j] >> 16) & 0xff) - 64;
+        const bool ok = ((emeta[j] >> 24) & 1) && hh >= 0 && hh < p.cH;
+        async_load1(rv[j], ok ? base + eoff[j] : thin_zero_word);
+      }
+    }
+  };
+  auto scatter = [&]() {         // awaits the gather and writes the tile into LDS [k][row]
+    if constexpr (IM2COL) {
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),
+                     "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]),
+                     "+v"(rv[15])::"memory");
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if ((emeta[j] >> 25) & 1) as[emeta[j] & 0xffff] = rv[j];
+    }
+  };
 
   // one epilogue pass: rows [8q, 8q+8) of the wave's 32 (accumulator registers 4q .. 4q+3) of tile `tme`
   auto epilogue_pass = [&](const f32x16 (&src)[4], int q, int tme) {
@@ -304,11 +391,19 @@ __global__ __launch_bounds__(256, 3) void igemm_thin_kflat_kernel(ThinGemmArgs p
     __builtin_amdgcn_wave_barrier();
   };
 
+  if constexpr (IM2COL) {
+    if (tm < tiles_m) {
+      gather(tm);
+      scatter();
+    }
+  }
   for (; tm < tiles_m; tm += mstep) {
     __syncthreads();  // this tile's A (written at the end of the previous iteration) is visible
     const int tnext = tm + mstep;
     const bool next_full = (tnext + 1) * TK_TM <= p.M;  // block-uniform
-    if (next_full) {
+    if constexpr (IM2COL) {
+      if (next_full) gather(tnext);
+    } else if (next_full) {
       const float* src = p.A + (long)tnext * TK_TM * K;
 #pragma unroll
       for (int j = 0; j < 4; ++j) async_load4(ra[j], src + goff[j]);
@@ -337,7 +432,9 @@ __global__ __launch_bounds__(256, 3) void igemm_thin_kflat_kernel(ThinGemmArgs p
     }
 
     __syncthreads();  // every wave is done with this tile's A fragments
-    if (next_full) {
+    if constexpr (IM2COL) {
+      if (next_full) scatter();
+    } else if (next_full) {
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3])::"memory");
       sstore_a(tile_elems);
     } else if (tnext < tiles_m) {
@@ -360,11 +457,11 @@ int launch_thin_k(const ThinGemmArgs& a, hipStream_t st) {
     int groups = target / tiles_n;
     if (groups > tiles_m) groups = tiles_m;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(igemm_thin_kflat_kernel, dim3(groups * tiles_n), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(igemm_thin_kflat_kernel<false>, dim3(groups * tiles_n), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
   }
-  if (flat) hipLaunchKernelGGL(igemm_thin_k_kernel<true>, dim3(tiles), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(igemm_thin_k_kernel<false>, dim3(tiles), dim3(256), 0, st, a);
+  if (flat) hipLaunchKernelGGL(igemm_thin_k_kernel<TK_FLAT>, dim3(tiles), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(igemm_thin_k_kernel<TK_STRIDED>, dim3(tiles), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
@@ -549,6 +646,27 @@ int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, f
 }
 
 }  // namespace
+
+int indm_thin_conv3x3(const ThinGemmArgs& a, hipStream_t st) {
+  const int C = a.cC, H = a.cH, W = a.cW;
+  if (!a.X || C < 1 || a.K != 9 * C || a.batch != 1 || a.G || a.M < 1024 || a.N < 128 || (a.N & 3) || (a.ldb & 3) ||
+      (a.ldc & 3) || (a.R && (a.ldr & 3)) || !al16(a.X) || !al16(a.B) || !al16(a.C) || !al16(a.bias) || !al16(a.bias2) ||
+      !al16(a.R) || (long)a.M * 9 * C >= (1L << 31))
+    return THIN_NA;
+  const int tiles_n = cdiv(a.N, TK_TN), tiles_m = cdiv(a.M, TK_TM);
+  if (C <= 3 && W <= 128 && (128 % W) == 0 && ((H * W) % 128) == 0 && (a.M % 128) == 0 && (!a.bias2 || !(a.rpg & 7))) {
+    int groups = 512 / tiles_n;  // two blocks per CU (the element tables cost registers)
+    if (groups > tiles_m) groups = tiles_m;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(igemm_thin_kflat_kernel<true>, dim3(groups * tiles_n), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+  }
+  if (!(C & 3) && 9 * C <= 128) {
+    hipLaunchKernelGGL(igemm_thin_k_kernel<TK_IM2COL>, dim3(tiles_m * tiles_n), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+  }
+  return THIN_NA;
+}
 
 int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st, const char** variant) {
   if (a.batch != 1) return THIN_NA;

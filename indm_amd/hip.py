@@ -53,6 +53,7 @@ _SIGS = {
     "indm_segreduce_ws_floats": [c_l, c_l, c_i],
     "indm_segreduce_f32": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
     "indm_igemm_last_variant": [],
+    "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
@@ -317,6 +318,25 @@ def tap_spread(y, sign, alpha=1.0):
     return P
 
 
+def conv3x3_thin(x, w2d, sign, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
+    """3x3 / pad 1 / stride 1 conv of a skinny NHWC input x [N,H,W,C] with w2d [9C, Co] (rows (tap, c)); the 9-tap gather
+    happens inside the thin-K GEMM's operand loader.  sign -1: conv forward, +1: transposed conv (w2d pre-packed).
+    Returns None when the kernel does not cover the geometry (or in bf16 mode): the caller falls back."""
+    if _MFMA["dtype"] != "f32":
+        return None
+    N, H, W, C = x.shape
+    Co = w2d.shape[1]
+    y = torch.empty((N, H, W, Co), dtype=torch.float32, device=x.device)
+    nbytes = 4 * (x.numel() + w2d.numel() + y.numel() + (res.numel() if res is not None else 0))
+    with _timed("A_CONV3", "B_ROW", N * H * W, Co, 9 * C, nbytes=nbytes):
+        st = lib().indm_conv3x3_thin_f32(_ptr(x), _ptr(w2d), _ptr(y), N, H, W, C, Co, sign, alpha, _ptr(bias),
+                                         _ptr(bias2), _ptr(res), beta, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_conv3x3_thin_f32")
+    return y
+
+
 def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
@@ -334,6 +354,9 @@ def conv2d(x, w, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, be
     if _skinny(KH, KW, stride, pad, Ci, Co):
         # skinny INPUT (flow edges 3 / 12 -> 512): spread x over the 9 taps (a [pixels, 9*Ci] panel, a few MB) and
         # run one plain MFMA GEMM; keeps every epilogue fusion of the GEMM
+        y = conv3x3_thin(x, w.reshape(9 * Ci, Co), -1, alpha, bias, bias2, res, beta)
+        if y is not None:
+            return y
         xcol = tap_spread(x, -1)
         r = res.reshape(-1, Co) if res is not None else None
         y2 = gemm(xcol.reshape(-1, 9 * Ci), w.reshape(9 * Ci, Co), alpha=alpha, bias=bias, bias2=bias2,
@@ -367,6 +390,9 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
         return tap_gather(P.view(N, H, W, 9 * Ci), None, -1, alpha)
     if _skinny(KH, KW, stride, pad, Co, Ci):
         # transposed conv with a skinny INPUT dy: spread dy (+1), then [pixels, 9*Co] x [(tap,co), ci]
+        dx = conv3x3_thin(dy, _packed_weight(w, "tapco_ci"), 1, alpha, None, None, res, beta)
+        if dx is not None:
+            return dx
         dycol = tap_spread(dy, 1)
         r = res.reshape(-1, Ci) if res is not None else None
         return gemm(dycol.reshape(-1, 9 * Co), _packed_weight(w, "tapco_ci"), alpha=alpha, res=r,

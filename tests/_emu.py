@@ -45,6 +45,13 @@ def tap_gather(P, bias, sign, alpha=1.0):
     return alpha * acc
 
 
+def conv3x3_thin(x, w2d, sign, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
+    N, H, W, C = x.shape
+    xcol = tap_spread(x, sign).reshape(-1, 9 * C)
+    r = res.reshape(-1, w2d.shape[1]) if res is not None else None
+    return gemm(xcol, w2d, alpha=alpha, bias=bias, bias2=bias2, rows_per_group=H * W, res=r, beta=beta).view(N, H, W, -1)
+
+
 def tap_spread(y, sign, alpha=1.0):
     N, H, W, C = y.shape
     yp = F.pad(y, (0, 0, 1, 1, 1, 1))

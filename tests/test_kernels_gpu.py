@@ -57,6 +57,22 @@ def test_gemm_gated(ta, tb):
                         trans_a=ta, trans_b=tb, gate=g[:, :133].contiguous() if not ta else g) if False else (out, ref)
 
 
+@pytest.mark.parametrize("N,H,W,C,Co", [(8, 32, 32, 3, 512), (4, 16, 16, 12, 512), (2, 64, 64, 3, 128), (16, 16, 16, 1, 256),
+                                         (3, 32, 32, 3, 260), (2, 32, 32, 8, 128), (1, 64, 16, 2, 128)])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_conv3x3_thin(N, H, W, C, Co, sign):
+    """skinny-input 3x3 conv with the tap gather inside the thin-K GEMM loader (flat C <= 3 form and C % 4 == 0 form)"""
+    x, w = rnd(N, H, W, C), rnd(9 * C, Co, seed=1, scale=0.3)
+    out = hip.conv3x3_thin(x.to(DEV), w.to(DEV), sign)
+    assert out is not None, "geometry should be covered"
+    ref = _emu.conv3x3_thin(x.double(), w.double(), sign)
+    close(out, ref, rtol=1e-5, atol=1e-4, name="conv3x3_thin")
+    bias, bias2, res = rnd(Co, seed=2), rnd(N, Co, seed=3), rnd(N, H, W, Co, seed=4)
+    out = hip.conv3x3_thin(x.to(DEV), w.to(DEV), sign, 0.5, bias.to(DEV), bias2.to(DEV), res.to(DEV), -1.5)
+    ref = _emu.conv3x3_thin(x.double(), w.double(), sign, 0.5, bias.double(), bias2.double(), res.double(), -1.5)
+    close(out, ref, rtol=1e-5, atol=1e-4, name="conv3x3_thin + epilogue")
+
+
 def test_conv_dgrad_gated():
     dy, g = rnd(2, 16, 16, 64), rnd(2, 16, 16, 64, seed=3)
     for ci in (3, 12, 32):
