@@ -190,6 +190,10 @@ int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const float* l1
  * taps (sign +1 forward conv, -1 transposed conv); tap_spread is its adjoint (used for the weight gradient). */
 int indm_tap_gather_f32(const float* P, const float* bias, float* y, int N, int H, int W, int C, int sign,
                         float alpha, void* stream);
+/* the same gather with the series bookkeeping of neumann_logdet_estimator (iresblock.py:264-273) in the same pass:
+ * y = alpha*(gather + bias) .* mulp (the block's input gate cos(2 pi x), optional); acc_out = acc_in + coeff*y (optional). */
+int indm_tap_gather_acc_f32(const float* P, const float* bias, const float* mulp, float* y, const float* acc_in,
+                            float* acc_out, float coeff, int N, int H, int W, int C, int sign, float alpha, void* stream);
 int indm_tap_spread_f32(const float* y, float* P, int N, int H, int W, int C, int sign, float alpha, void* stream);
 /* stop test of the fixed-point inverse: count of elements with (x-xp)^2/(atol+|y|rtol) >= 1, iresblock.py:81-82 */
 int indm_fixed_point_check_f32(const float* x, const float* xp, const float* y, long n, float atol, float rtol,

@@ -110,9 +110,13 @@ __global__ __launch_bounds__(256) void fp_check_kernel(const float* __restrict__
 //   y[n,h,w,c] = alpha * ( sum_{kh,kw} P[n, h + s*(kh-1), w + s*(kw-1), (kh*3+kw)*C + c] + bias[c] )
 // P is the [pixels, 9*C] product of the wide side with the tap-major weight (an MFMA GEMM with N = 9C instead
 // of nine N = C ones).  s = +1: forward conv; s = -1: data-grad / transposed conv.
+// optional tail (the per-iteration bookkeeping of the residual flow's series, iresblock.py:264-273, in the same pass):
+//   y = alpha*(gather + bias) * mulp   and   acc_out = acc_in + coeff * y
 __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ P, const float* __restrict__ bias,
                                                          float* __restrict__ y, int N, int H, int W, int C, int s,
-                                                         float alpha) {
+                                                         float alpha, const float* __restrict__ mulp,
+                                                         const float* __restrict__ acc_in, float* __restrict__ acc_out,
+                                                         float coeff) {
   const long total = (long)N * H * W * C;
   const int C9 = 9 * C;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
@@ -134,7 +138,10 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
         acc += P[(((long)n * H + hh) * W + ww) * C9 + (kh * 3 + kw) * C + c];
       }
     }
-    y[i] = alpha * acc;
+    float v = alpha * acc;
+    if (mulp) v *= mulp[i];
+    y[i] = v;
+    if (acc_out) acc_out[i] = acc_in[i] + coeff * v;
   }
 }
 // adjoint of the gather: Pout[n,h',w',(tap,c)] = alpha * y[n, h' - s*(kh-1), w' - s*(kw-1), c]  (0 outside)
@@ -401,7 +408,21 @@ INDM_API int indm_tap_gather_f32(const float* P, const float* bias, float* y, in
   if (total <= 0) return INDM_OK;
   if (total >= (1L << 31)) return INDM_E_SHAPE;
   hipLaunchKernelGGL(tap_gather_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, P, bias, y, N, H,
-                     W, C, sign, alpha);
+                     W, C, sign, alpha, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, 0.f);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+// tap gather with the series bookkeeping fused: y = alpha*(gather + bias) .* mulp (mulp optional);
+// acc_out = acc_in + coeff*y (acc_in / acc_out optional, together)
+INDM_API int indm_tap_gather_acc_f32(const float* P, const float* bias, const float* mulp, float* y, const float* acc_in,
+                                     float* acc_out, float coeff, int N, int H, int W, int C, int sign, float alpha,
+                                     void* stream) {
+  const long total = (long)N * H * W * C;
+  if (total <= 0) return INDM_OK;
+  if (total >= (1L << 31)) return INDM_E_SHAPE;
+  if ((acc_in == nullptr) != (acc_out == nullptr)) return INDM_E_ARG;
+  hipLaunchKernelGGL(tap_gather_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, P, bias, y, N, H,
+                     W, C, sign, alpha, mulp, acc_in, acc_out, coeff);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

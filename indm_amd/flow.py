@@ -126,6 +126,24 @@ class IResBlock(nn.Module):
             t = ops.mul(t, d0)
         return t
 
+    def vjp_acc(self, v, W, gates, hw, acc, coeff):
+        """One series iteration without a graph: (v^T dg/dx, acc + coeff * v^T dg/dx).  Same contractions as vjp(); the
+        skinny tail (9-tap gather, input gate, accumulation into the Neumann sum) is ONE launch instead of three."""
+        W1, W2, W3 = (w if w.is_contiguous() else w.contiguous() for w in W)
+        d0, d1, d2 = gates
+        N, H, Wd, _ = v.shape
+        t = hip.conv2d_dgrad(v, W3, hw)
+        C = t.shape[-1]
+        t = hip.gemm(t.view(-1, C), W2, trans_b=True, gate=d2.view(-1, C))
+        Ci = W1.shape[2]
+        if not hip._skinny(3, 3, 1, 1, Ci, W1.shape[3]):
+            t = hip.conv2d_dgrad(t.view(N, H, Wd, -1), W1, hw, gate=d1)
+            if d0 is not None:
+                t = hip.mul(t, d0)
+            return t, hip.axpby(acc, t, 1.0, coeff)
+        P = hip.gemm(t, W1.reshape(9 * Ci, W1.shape[3]), trans_b=True, gate=d1.view(-1, d1.shape[-1]))
+        return hip.tap_gather_acc(P.view(N, H, Wd, 9 * Ci), -1, d0, acc, coeff)
+
     def forward_logdet(self, x, cb, W, rng, stats):
         """_logdetgrad iresblock.py:90-174 (poisson, n_samples=1, neumann_grad in training)."""
         lamb = self.lamb_value
@@ -145,8 +163,7 @@ class IResBlock(nn.Module):
             with torch.no_grad():
                 vjp, nvjp = eps, eps
                 for k in range(1, K + 1):
-                    vjp = self.vjp(vjp, W, gates, hw)
-                    nvjp = ops.axpby(nvjp, vjp, 1.0, (-1) ** k * coeff(k))
+                    vjp, nvjp = self.vjp_acc(vjp, W, gates, hw, nvjp, (-1) ** k * coeff(k))
             vj = self.vjp(nvjp, W, gates, hw)
             logdet = ops.rowdot(vj, eps)
         else:  # basic_logdet_estimator :253-261 (create_graph=False)

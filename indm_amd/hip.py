@@ -85,6 +85,7 @@ _SIGS = {
     "indm_adamw_ema_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p, c_f, c_f, c_p],
     "indm_tap_gather_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "indm_tap_spread_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
+    "indm_tap_gather_acc_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_p],
     "indm_fixed_point_check_f32": [c_p, c_p, c_p, c_l, c_f, c_f, c_p, c_p],
     "indm_ema_update_f32": [c_p, c_p, c_l, c_f, c_p],
     "indm_slogdet_inv_f32": [c_p, c_i, c_p, c_p, c_p],
@@ -308,6 +309,18 @@ def tap_gather(P, bias, sign, alpha=1.0):
     _chk(lib().indm_tap_gather_f32(_ptr(P), _ptr(bias), _ptr(y), N, H, W, C, sign, alpha, _stream()),
          "indm_tap_gather_f32")
     return y
+
+
+def tap_gather_acc(P, sign, mulp=None, acc_in=None, coeff=0.0, alpha=1.0):
+    """tap_gather with the series bookkeeping fused: y = alpha*gather(P) * mulp; acc = acc_in + coeff*y.
+    Returns (y, acc) (acc None without acc_in)."""
+    N, H, W, C9 = P.shape
+    C = C9 // 9
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=P.device)
+    acc = torch.empty_like(y) if acc_in is not None else None
+    _chk(lib().indm_tap_gather_acc_f32(_ptr(P), None, _ptr(mulp), _ptr(y), _ptr(acc_in), _ptr(acc), coeff, N, H, W, C,
+                                       sign, alpha, _stream()), "indm_tap_gather_acc_f32")
+    return y, acc
 
 
 def tap_spread(y, sign, alpha=1.0):

@@ -45,6 +45,13 @@ def tap_gather(P, bias, sign, alpha=1.0):
     return alpha * acc
 
 
+def tap_gather_acc(P, sign, mulp=None, acc_in=None, coeff=0.0, alpha=1.0):
+    y = tap_gather(P, None, sign, alpha)
+    if mulp is not None:
+        y = y * mulp
+    return y, (acc_in + coeff * y if acc_in is not None else None)
+
+
 def conv3x3_thin(x, w2d, sign, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
     N, H, W, C = x.shape
     xcol = tap_spread(x, sign).reshape(-1, 9 * C)

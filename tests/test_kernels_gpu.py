@@ -293,6 +293,17 @@ def test_tap_gather_spread():
         assert abs(float(a - b)) < 1e-9
 
 
+def test_tap_gather_acc():
+    P, m, a = rnd(2, 16, 16, 27), rnd(2, 16, 16, 3, seed=1), rnd(2, 16, 16, 3, seed=2)
+    for sign in (-1, 1):
+        (y, acc), (ry, racc) = run_both("tap_gather_acc", P, sign, mulp=m, acc_in=a, coeff=-0.75, alpha=1.0)
+        close(y, ry, name="gather*mul")
+        close(acc, racc, name="acc")
+        (y, acc), (ry, racc) = run_both("tap_gather_acc", P, sign)
+        close(y, ry, name="gather")
+        assert acc is None and racc is None
+
+
 def test_conv2d_big_wgrad_splitk():
     x, dy = rnd(16, 32, 32, 16), rnd(16, 32, 32, 32, seed=1)
     out, ref = run_both("conv2d_wgrad", x, dy, 3, 3, stride=1, pad=1)
