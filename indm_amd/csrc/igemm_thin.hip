@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
       for (int rr = 0; rr < 4; ++rr) stg[(rr + 4 * lhi) * TF_LDS + j * 32 + l31] = src[j][4 * q + rr];
     __builtin_amdgcn_wave_barrier();
     float4 bq = bn;  // bias[n] + bias2[image of these 8 rows][n]: one load per pass (rpg % 8 == 0, host-checked)
-    if (p.bias2 && nok) {
+    if (p.bias2 && nok && mw + 8 * q < p.M) {  // (rows of a ragged last tile past M have no image: M % 8 == 0 here)
       const int img = (mw + 8 * q) / p.rpg;
       const float4 b = *(const float4*)(p.bias2 + (long)img * p.N + n);
       bq.x += b.x; bq.y += b.y; bq.z += b.z; bq.w += b.w;
