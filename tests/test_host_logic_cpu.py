@@ -62,3 +62,28 @@ def test_sampling_lib_cache(emulate_hip, tmp_path):
     assert __import__("os").path.exists(sd + "/samples_0_before_flow_denoise_0.0.npz")
     assert np.load(tsd + "/samples_0_denoise_0.0.npz")["samples"].dtype == np.uint8
     assert b3.shape == a3.shape == shape
+
+
+@pytest.mark.parametrize("fx", ["mini_vp_nll", "mini_vp_fid"])
+def test_micro_batches_and_loss_readback(fx, emulate_hip):
+    """optim.num_micro_batch = 2 (losses.py:287-309): every micro-batch's loss vectors are read back (enqueued before its
+    backward pass) and concatenated in order; total = score + flow + logp; steps advance once."""
+    import torch
+    import golden_utils as gu
+    from indm_amd import losses, sde_lib, utils
+    from indm_amd.rng import DeviceRng
+    if fx not in pc.FIXTURES:
+        pytest.skip("fixture not present")
+    d, cfg, score, fl = pc.build(fx, "cpu")
+    cfg.optim.num_micro_batch = 2
+    state, flow_state, _ = utils.build_states(cfg, score, fl, "cpu")
+    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+    score.train(); fl.train()
+    x = torch.from_numpy(d["step0/x"])
+    out = step_fn(state, flow_state, x, rng=DeviceRng("cpu", seed=7))
+    assert len(out) == 4
+    for v in out:
+        assert v.shape == (x.shape[0],) and not v.is_cuda and torch.isfinite(v).all()
+    if cfg.training.likelihood_weighting:
+        assert torch.allclose(out[0], out[1] + out[2] + out[3], rtol=1e-5, atol=1e-5)
+    assert state["step"] == 1 and flow_state["step"] == 1
