@@ -916,6 +916,10 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
 //   * LDS images: A / gate / k-contiguous B as [row][16 k] with the XOR chunk swizzle applied on the SOURCE address
 //     (the DMA writes lane-linear: LDS slot = lane), row-contiguous B as plain [16 k][128 n]
 //   * 256 x 128 block tile, 4 waves of 128 x 64, two blocks per CU; 80 KB of LDS per block when gated
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (an inline-asm v_pk_mul_f32 here is unsafe: the hazard recogniser does not see its VGPR writes next to in-flight MFMAs)
+__device__ __forceinline__ f32x2 pk_mul_f32(f32x2 a, f32x2 b) { return a * b; }
+
 // 16 bytes of zeros in device memory: the source of a padded tap's DMA copy
 __device__ __attribute__((aligned(16))) float indm_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -929,7 +933,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   constexpr int A_SZ = TM * BK, G_SZ = HAS_G ? TM * BK : 0, B_SZ = TN * BK, BUF = A_SZ + G_SZ + B_SZ;
   extern __shared__ __attribute__((aligned(16))) float glds_smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS destinations of the DMA stay in SGPRs
   const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
   const int lt = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
@@ -961,7 +966,36 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     for (int q = 0; q < 16 / NW; ++q)
       pix[q] = decode_pix(min(m0 + wave * (256 / NW) + q * 16 + (lane >> 2), p.M - 1), p.OH, p.OW);
   }
-  // this wave's share of slab kt -> LDS buffer buf
+  // A_ROW / B_COL / B_ROW: every DMA of this lane reads the same row (or k-row) in every slab -> per-lane source
+  // pointers advanced by one slab per stage() call (one v_lshl_add_u64 each) instead of re-deriving 64-bit offsets
+  // from k0 (the non-MFMA VALU work of the loop does not overlap with the MFMAs: PMC SQ_VALU_MFMA_COEXEC_CYCLES = 0)
+  const float* pa[16 / NW];
+  const float* pg[16 / NW];
+  const float* pb[8 / NW];
+  if constexpr (AM == A_ROW) {
+#pragma unroll
+    for (int q = 0; q < 16 / NW; ++q) {
+      const int row = wave * (256 / NW) + q * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      const long off = (long)min(m0 + row, p.M - 1) * p.lda + kbeg + 4 * c;
+      pa[q] = A + off;
+      pg[q] = HAS_G ? G + off : nullptr;
+    }
+  }
+  if constexpr (BMODE == B_COL) {
+#pragma unroll
+    for (int q = 0; q < 8 / NW; ++q) {
+      const int row = wave * (128 / NW) + q * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      pb[q] = B + (long)min(n0 + row, p.N - 1) * p.ldb + kbeg + 4 * c;
+    }
+  } else if constexpr (BMODE == B_ROW) {
+#pragma unroll
+    for (int q = 0; q < 8 / NW; ++q)
+      pb[q] = B + (long)(kbeg + wave * (16 / NW) + q * 2 + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4);
+  }
+  const long b_step = BMODE == B_ROW ? (long)BK * p.ldb : BK;
+  // this wave's share of slab kt -> LDS buffer buf (called for kt = 0, 1, 2, ... in order)
   auto stage = [&](int buf, int kt) {
     float* base = glds_smem + buf * BUF;
     const int k0 = kbeg + kt * BK;
@@ -978,9 +1012,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       const int row = r0 + (lane >> 2);
       const int c = (lane & 3) ^ ((row >> 2) & 3);  // the k-chunk that belongs in LDS slot (row, lane&3)
       if constexpr (AM == A_ROW) {
-        const long off = (long)min(m0 + row, p.M - 1) * p.lda + k0 + 4 * c;
-        dma(A + off, base + r0 * BK);
-        if constexpr (HAS_G) dma(G + off, base + A_SZ + r0 * BK);
+        dma(pa[q], base + r0 * BK);
+        pa[q] += BK;
+        if constexpr (HAS_G) {
+          dma(pg[q], base + A_SZ + r0 * BK);
+          pg[q] += BK;
+        }
       } else {
         int ih = pix[q].oh * p.stride + kh - p.pad, iw = pix[q].ow * p.stride + kw - p.pad;
         bool ok = ih >= 0 && iw >= 0;
@@ -1002,14 +1039,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         const int row = r0 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         if constexpr (BMODE == B_COL) {
-          dma(B + (long)min(n0 + row, p.N - 1) * p.ldb + k0 + 4 * c, bb + r0 * BK);
+          dma(pb[q], bb + r0 * BK);
+          pb[q] += b_step;
         } else {  // B_DGRAD: packed weight [T][N][Cout], taps flipped; one tap per slab
           const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
           dma(B + ((long)(p.KH * p.KW - 1 - tap) * p.N + min(n0 + row, p.N - 1)) * p.Cout + co0 + 4 * c, bb + r0 * BK);
         }
       } else {              // [16 k][128 n]: two k-rows per instruction, 16 / NW k-rows per wave
         const int kr0 = wave * (16 / NW) + q * 2;
-        dma(B + (long)(k0 + kr0 + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4), bb + kr0 * TN);
+        dma(pb[q], bb + kr0 * TN);
+        pb[q] += b_step;
       }
     }
   };
@@ -1026,10 +1065,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
       const int o = (mw + i * 32 + l31) * BK + ch;
-      fa[i] = *(const float4*)(as + o);
-      if constexpr (HAS_G) {
-        const float4 g = *(const float4*)(as + A_SZ + o);
-        fa[i].x *= g.x; fa[i].y *= g.y; fa[i].z *= g.z; fa[i].w *= g.w;
+      if constexpr (HAS_G) {  // gate multiplied as two packed pairs (v_pk_mul_f32: half the VALU issue slots)
+        const f32x4 av = *(const f32x4*)(as + o), gv = *(const f32x4*)(as + A_SZ + o);
+        const f32x2 lo = pk_mul_f32(av.lo, gv.lo), hi = pk_mul_f32(av.hi, gv.hi);
+        fa[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+      } else {
+        fa[i] = *(const float4*)(as + o);
       }
     }
 #pragma unroll
