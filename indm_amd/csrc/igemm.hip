@@ -961,10 +961,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   };
   // implicit-GEMM A operand: the output pixel of each of this lane's LDS rows (fixed over the K loop)
   PixDec pix[16 / NW];
+  // undilated input (everything but the data-grad of a strided conv): top-left input coordinate and element offset of
+  // each of this lane's rows, fixed over the K loop -> per slab only the (uniform) tap offset is added and two
+  // unsigned compares test the padding (no integer multiplies in the loop: v_mul_lo_u32 is quarter rate and the
+  // loop's VALU work does not overlap with the MFMAs)
+  int ih0[16 / NW], iw0[16 / NW];
+  long pbase[16 / NW];
   if constexpr (AM == A_CONV) {
 #pragma unroll
-    for (int q = 0; q < 16 / NW; ++q)
-      pix[q] = decode_pix(min(m0 + wave * (256 / NW) + q * 16 + (lane >> 2), p.M - 1), p.OH, p.OW);
+    for (int q = 0; q < 16 / NW; ++q) {
+      const int row = wave * (256 / NW) + q * 16 + (lane >> 2);
+      pix[q] = decode_pix(min(m0 + row, p.M - 1), p.OH, p.OW);
+      ih0[q] = pix[q].oh * p.stride - p.pad;
+      iw0[q] = pix[q].ow * p.stride - p.pad;
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      pbase[q] = (((long)pix[q].img * p.H + ih0[q]) * p.W + iw0[q]) * p.Cin + 4 * c;
+    }
   }
   // A_ROW / B_COL / B_ROW: every DMA of this lane reads the same row (or k-row) in every slab -> per-lane source
   // pointers advanced by one slab per stage() call (one v_lshl_add_u64 each) instead of re-deriving 64-bit offsets
@@ -995,16 +1007,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       pb[q] = B + (long)(kbeg + wave * (16 / NW) + q * 2 + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4);
   }
   const long b_step = BMODE == B_ROW ? (long)BK * p.ldb : BK;
+  long bdg[8 / NW];  // B_DGRAD: this lane's row of the packed weight (fixed over the K loop)
+  if constexpr (BMODE == B_DGRAD) {
+#pragma unroll
+    for (int q = 0; q < 8 / NW; ++q) {
+      const int row = wave * (128 / NW) + q * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      bdg[q] = (long)min(n0 + row, p.N - 1) * p.Cout + 4 * c;
+    }
+  }
   // this wave's share of slab kt -> LDS buffer buf (called for kt = 0, 1, 2, ... in order)
   auto stage = [&](int buf, int kt) {
     float* base = glds_smem + buf * BUF;
     const int k0 = kbeg + kt * BK;
     int kh = 0, kw = 0, ci0 = 0;
+    long tap_off = 0;
     if constexpr (AM == A_CONV) {  // one tap per slab (host checks Cin % 16 == 0)
       const int tap = k0 / p.Cin;
       ci0 = k0 - tap * p.Cin;
       kh = tap / p.KW;
       kw = tap - kh * p.KW;
+      tap_off = ((long)kh * p.W + kw) * p.Cin + ci0;  // uniform
     }
 #pragma unroll
     for (int q = 0; q < 16 / NW; ++q) {  // A (+ gate): 16 rows per instruction, 256 / NW rows per wave
@@ -1018,17 +1041,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
           dma(pg[q], base + A_SZ + r0 * BK);
           pg[q] += BK;
         }
+      } else if (p.dil == 1) {  // block-uniform branch
+        const bool ok = (unsigned)(ih0[q] + kh) < (unsigned)p.H && (unsigned)(iw0[q] + kw) < (unsigned)p.W;
+        const float* src = A + pbase[q] + tap_off;
+        dma(ok ? src : indm_zero16, base + r0 * BK);  // zero padding: the DMA copies from a 16-byte zero page
       } else {
         int ih = pix[q].oh * p.stride + kh - p.pad, iw = pix[q].ow * p.stride + kw - p.pad;
         bool ok = ih >= 0 && iw >= 0;
-        if (p.dil > 1) {
-          ok = ok && ((ih % p.dil) | (iw % p.dil)) == 0;
-          ih /= p.dil;
-          iw /= p.dil;
-        }
+        ok = ok && ((ih % p.dil) | (iw % p.dil)) == 0;
+        ih /= p.dil;
+        iw /= p.dil;
         ok = ok && ih < p.H && iw < p.W;
         const float* src = A + (((long)pix[q].img * p.H + ih) * p.W + iw) * p.Cin + ci0 + 4 * c;
-        dma(ok ? src : indm_zero16, base + r0 * BK);  // zero padding: the DMA copies from a 16-byte zero page
+        dma(ok ? src : indm_zero16, base + r0 * BK);
       }
     }
     float* bb = base + A_SZ + G_SZ;
@@ -1043,7 +1068,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
           pb[q] += b_step;
         } else {  // B_DGRAD: packed weight [T][N][Cout], taps flipped; one tap per slab
           const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
-          dma(B + ((long)(p.KH * p.KW - 1 - tap) * p.N + min(n0 + row, p.N - 1)) * p.Cout + co0 + 4 * c, bb + r0 * BK);
+          const long toff = (long)(p.KH * p.KW - 1 - tap) * p.N * p.Cout + co0;  // uniform
+          dma(B + toff + bdg[q], bb + r0 * BK);
         }
       } else {              // [16 k][128 n]: two k-rows per instruction, 16 / NW k-rows per wave
         const int kr0 = wave * (16 / NW) + q * 2;
