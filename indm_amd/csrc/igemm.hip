@@ -56,6 +56,7 @@ struct IgemmParams {
   int a_vec, b_vec;
   int a_tap_uniform, b_tap_uniform;  // reduction slab of BK never straddles a tap (Cin % BK == 0)
   int wg_inc;                        // A_WGRAD: pixel decode advanced incrementally (needs OH*OW >= BK)
+  int ow_sh, ohw_sh;                 // log2(OW), log2(OH*OW) when both are powers of two, else -1
   int bf16;                          // MFMA inputs rounded to bf16 (RNE), fp32 accumulate (BASELINE configs #3-#5)
 };
 
@@ -567,7 +568,15 @@ __device__ __forceinline__ long a_off(const IgemmParams& p, int row, int k, cons
     ok = ok && ih < p.H && iw < p.W;
     return (((long)rd.img * p.H + ih) * p.W + iw) * p.Cin + tapdec.z + (k - kbase);
   } else {
-    const PixDec d = decode_pix(k, p.OH, p.OW);
+    PixDec d;
+    if (p.ow_sh >= 0) {  // OW and OH*OW powers of two (every map of the INDM nets): shifts instead of two divisions
+      d.img = k >> p.ohw_sh;
+      const int r = k & ((1 << p.ohw_sh) - 1);
+      d.oh = r >> p.ow_sh;
+      d.ow = r & ((1 << p.ow_sh) - 1);
+    } else {
+      d = decode_pix(k, p.OH, p.OW);
+    }
     const int ih = d.oh * p.stride + rd.img - p.pad, iw = d.ow * p.stride + rd.oh - p.pad;
     ok = ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
     return (((long)d.img * p.H + ih) * p.W + iw) * p.Cin + rd.ow;
@@ -1615,6 +1624,11 @@ static int conv2d_wgrad_f32_impl(int bf16, const float* x, const float* dy, floa
   p.a_vec = al16(x) && (Cin % 4 == 0);
   p.b_vec = al16(dy) && (Cout % 4 == 0);
   p.wg_inc = (OH * OW >= BK);
+  p.ow_sh = p.ohw_sh = -1;
+  if (!(OW & (OW - 1)) && !((OH * OW) & (OH * OW - 1))) {
+    p.ow_sh = __builtin_ctz((unsigned)OW);
+    p.ohw_sh = __builtin_ctz((unsigned)(OH * OW));
+  }
   return run(p, A_WGRAD, B_ROW, ws, ws_floats, (hipStream_t)stream);
 }
 INDM_API int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, int H, int W,
