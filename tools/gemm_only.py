@@ -1,5 +1,5 @@
 """Run a few launches of one contraction shape (for rocprofv3 --pmc).  usage: gemm_only.py MODE [M N K]
-MODE: nn | nt (igemm), vnn | vnt (vendor torch.matmul, reference point only), conv"""
+MODE: nn | nt | ntg | nng (igemm; g = gated), vnn | vnt (vendor torch.matmul, reference point only), conv"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,6 +17,8 @@ for _ in range(5):
         hip.gemm(a, wt, trans_b=True)
     elif mode == "ntg":
         hip.gemm(a, wt, trans_b=True, gate=g_)
+    elif mode == "nng":
+        hip.gemm(a, w, gate=g_)
     elif mode == "vnn":
         torch.matmul(a, w)
     elif mode == "vnt":
