@@ -1160,6 +1160,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   float* C = partial ? p.ws + ((long)z * p.M) * p.N : p.C + (long)bz * p.sC;
   const long ldc = partial ? p.N : p.ldc;
   const float* R = (!partial && p.R) ? p.R + (long)bz * p.sR : nullptr;
+  if (m0 + TM <= p.M && n0 + TN <= p.N && !R && (partial || !p.bias2)) {
+    // full tile, no per-element reads: no bounds tests, one running row pointer per 32 x 32 block (the epilogue's
+    // integer work is ~40 % of the kernel's non-MFMA VALU instructions, none of which overlap with the MFMAs)
+    const float alpha = partial ? 1.f : p.alpha;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        const int n = n0 + nw + j * 32 + l31;
+        const float bn = (!partial && p.bias) ? p.bias[n] : 0.f;
+        float* cp = C + (long)(m0 + mw + i * 32 + 4 * lhi) * ldc + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cp[(long)((r & 3) + 8 * (r >> 2)) * ldc] = (acc[i][j][r] + bn) * alpha;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < RM; ++i) {
 #pragma unroll
