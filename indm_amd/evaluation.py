@@ -18,7 +18,7 @@ import logging
 import numpy as np
 import torch
 
-from .rng import DeviceRng
+from .rng import default_rng
 
 
 def _to_batch(config, item):
@@ -50,7 +50,7 @@ def get_bpd(config, eval_ds, scaler, nelbo_fn, nll_fn, score_model, flow_model=N
         if config.flow.model != "identity":
             flow_model.eval()
         num_data = config.eval.num_test_data if eval else 10000
-        rng = rng or DeviceRng(config.device)
+        rng = rng or default_rng(config.device)
         kw = dict(rng=rng)
 
         def batches(n):

@@ -588,8 +588,8 @@ class WolfCore(nn.Module):
     def forward(self, data, y=None, n_bits=8, nsamples=1, reverse=False, eval_logdet=True, rng=None, stats=None,
                 iters=None):
         if rng is None:
-            from .rng import DeviceRng
-            rng = DeviceRng(data.device)
+            from .rng import default_rng
+            rng = default_rng(data.device)
         if reverse:
             h = self.discriminator.prior.sample(data.shape[0], self.discriminator.dim, rng)
             return self.generator.flow.bwdpass(data, h.contiguous(), iters)

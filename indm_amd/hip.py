@@ -696,8 +696,27 @@ def multi_copy(srcs, dsts):
          "indm_multi_copy_f32")
 
 
+_tables = {}  # (device, rows) -> (pinned host staging tensor, device table): both stay alive with the entry
+
+
 def _lop_table(rows, device):
-    return torch.tensor(rows, dtype=torch.int64).to(device, non_blocking=True)
+    """Device-side pointer table of a multi-tensor launch.  Staged through a PINNED host tensor that outlives the
+    asynchronous copy (a dropped pageable temporary would rely on the runtime staging it before returning) and cached
+    by content: the flow's weights / flat-buffer slices keep their addresses from step to step, and the caching
+    allocator hands autograd the same gradient blocks again, so most steps re-use the resident table."""
+    flat = tuple(r if isinstance(r, int) else tuple(r) for r in rows)
+    key = (device.type, device.index, flat)
+    hit = _tables.get(key)
+    if hit is not None:
+        return hit[1]
+    host = torch.tensor(rows, dtype=torch.int64)
+    if device.type == "cuda":
+        host = host.pin_memory()
+    dev = host.to(device, non_blocking=True)
+    if len(_tables) >= 256:
+        _tables.pop(next(iter(_tables)))
+    _tables[key] = (host, dev)
+    return dev
 
 
 def lop_normalize_multi_fwd(ws, coeff):

@@ -11,7 +11,7 @@ import torch
 
 from . import hip, ops, sde_lib
 from .flow import flow_forward
-from .rng import DeviceRng
+from .rng import default_rng
 from .sampling import _Stepper, _d, _unwrap
 from .sde_lib import VPSDE
 
@@ -59,7 +59,7 @@ def get_elbo_fn(config, sde, inverse_scaler=None, hutchinson_type="Rademacher"):
     """likelihood.py:142-238 -> (nelbo_bpd [B], nelbo_residual_bpd [B]) on the CPU."""
 
     def loss_fn(model, flow_model, batch, logdet=None, rng=None, stats=None):
-        rng = rng or DeviceRng(batch.device)
+        rng = rng or default_rng(batch.device)
         dev = batch.device
         B = batch.shape[0]
         if config.flow.model != "identity":
@@ -135,7 +135,7 @@ def get_likelihood_fn(config, sde, inverse_scaler, hutchinson_type="Rademacher",
     from scipy import integrate
 
     def likelihood_fn(model, flow_model, data, logdet=None, residual=True, eps_bpd=1e-5, rng=None, stats=None):
-        rng = rng or DeviceRng(data.device)
+        rng = rng or default_rng(data.device)
         dev = data.device
         shape = data.shape
         B = shape[0]

@@ -12,7 +12,7 @@ import torch
 from . import ops, sde_lib
 from .flow import flow_forward
 from .optim import FusedAdamW
-from .rng import DeviceRng
+from .rng import DeviceRng, default_rng, mix64
 from .sde_lib import VESDE, VPSDE
 
 
@@ -96,7 +96,7 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
             raise NotImplementedError("reconstruction_loss is off in every shipped config")
         if importance_sampling is None:
             importance_sampling = config.training.importance_sampling
-        rng = rng or DeviceRng(batch.device)
+        rng = rng or default_rng(batch.device)
         dev = batch.device
         B, C, H, W = batch.shape
         t_min = sde.get_t_min(config, st)
@@ -145,7 +145,7 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
     def _step_rng(device, step):
         """default noise source of a step: per-rank noise, rank-independent series lengths (see DeviceRng)"""
         rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-        return DeviceRng(device, seed=step + 1 + 7919 * rank, poisson_seed=step + 3)
+        return DeviceRng(device, seed=mix64(config.get("seed", 0), step, rank), poisson_seed=mix64(config.get("seed", 0), step) % (1 << 32))
 
     class _HostLosses:
         """The per-image loss vectors the step returns on the CPU (reference API: losses.py:281-284,320).  Their
@@ -180,14 +180,22 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
             return tuple(torch.cat(o) if o else torch.zeros(B) for o in outs)
 
     def _reduce_and_step(states):
+        """gather -> (data-parallel) all-reduce of exactly the slices being stepped -> fused clip+AdamW+EMA.
+        The reference ramps BOTH optimisers from the constant config.optim.lr (optimize_fn's default lr,
+        losses.py:51-57 -- the flow's own lr is overwritten as soon as optim.warmup > 0); with warmup = 0 (every
+        shipped config) each optimiser keeps the lr it was built with."""
         for s in states:
             s["optimizer"].flat.gather_grads()   # autograd's per-parameter grads -> the flat buffer (one launch)
         if allreduce is not None:
-            allreduce()
+            allreduce([s["optimizer"].flat for s in states])
         for s in states:
-            optimize_fn(s["optimizer"], None, step=s["step"],
-                        lr=s["optimizer"].param_groups[0].get("base_lr", s["optimizer"].param_groups[0]["lr"]),
-                        ema=s["ema"], grad_scale=1.0 / world_size)
+            optimize_fn(s["optimizer"], None, step=s["step"], ema=s["ema"], grad_scale=1.0 / world_size)
+
+    def _eval_ema(state, flow_state):
+        """train=False in flow_step_fn_nll: the reference still runs ema.update on both networks (losses.py:314-318);
+        in a training step that update is part of the fused optimiser kernel."""
+        state["ema"].update()
+        flow_state["ema"].update()
 
     def _nll_losses(state, flow_state, mini_batch, rng, importance_sampling=None):
         flow_model = flow_state["model"]
@@ -218,8 +226,14 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
                 ls, lf, lp = _nll_losses(state, flow_state, mb, rng)
                 losses = ls + lf + lp
                 outs.push({0: losses, 1: ls, 2: lf, 3: lp})   # D2H enqueued before the backward pass
+                if k == nmb - 1 and hasattr(allreduce, "arm"):
+                    # data parallel: the score slice's all-reduce starts inside this backward pass, as soon as the
+                    # score network's last gradient exists, and overlaps the flow's backward (parallel.GradReducer)
+                    allreduce.arm(state["optimizer"].flat)
                 torch.mean(losses).backward()
             _reduce_and_step([state, flow_state])
+        else:
+            _eval_ema(state, flow_state)
         state["step"] += 1
         flow_state["step"] += 1
         return outs.result(B)
@@ -253,7 +267,7 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
             _reduce_and_step([state])
             state["step"] += 1
             flow_state["step"] += 1
-        return outs.result(B)
+        return outs.result(B)   # train=False: the reference's fid step does nothing at all (losses.py:353,406)
 
     if config.flow.model == "identity":
         raise NotImplementedError("flow.model='identity' (score-only training) is outside the INDM hot path")

@@ -187,7 +187,15 @@ class ResnetBlockBigGANpp(nn.Module):
             tb = self.Dense_0(temb_act)
         h = self.Conv_0(h, bias2=tb)
         drop = self.dropout if self.training else 0.0
-        seed = rng.dropout_seed() if (drop > 0 and rng is not None) else 0
+        seed = 0
+        if drop > 0:    # never a constant mask: a missing noise source falls back to the process-wide advancing one
+            if rng is None:
+                from .rng import default_rng
+                rng = default_rng(h.device)
+            seed = rng.dropout_seed()
+            if seed is None:
+                raise RuntimeError("training with dropout > 0 on a replayed noise source: the parity fixtures are "
+                                   "recorded with model.dropout = 0")
         h = self.GroupNorm_1(h, silu=True, drop_p=drop, seed=seed)
         if self.in_ch != self.out_ch or self.up or self.down:
             x = self.Conv_2(x)

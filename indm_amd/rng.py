@@ -11,6 +11,47 @@ import numpy as np
 import torch
 
 
+def mix64(*vals):
+    """splitmix64-style mix of integers -> one 63-bit seed.  Streams keyed by (step, rank) must not collide the way a
+    linear combination does (step + 7919*rank reuses rank 0's stream of step s+7919 for rank 1 at step s)."""
+    m = (1 << 64) - 1
+    x = 0x9E3779B97F4A7C15
+    for v in vals:
+        x = (x ^ (int(v) & m)) & m
+        x = (x + 0x9E3779B97F4A7C15) & m
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+        x = x ^ (x >> 31)
+    return x >> 1
+
+
+_default = {}      # device key -> the process-wide advancing DeviceRng
+_default_seed = [None]
+
+
+def manual_seed(seed):
+    """Re-seed the process-wide default noise source (the analogue of torch.manual_seed for the global generator the
+    reference draws from)."""
+    _default_seed[0] = int(seed)
+    _default.clear()
+
+
+def default_rng(device):
+    """The noise source used whenever a caller passes no rng=: ONE advancing DeviceRng per (process, device), like the
+    reference's global torch / numpy generators -- two consecutive sampling_fn / nelbo_fn / loss_fn calls therefore
+    draw DIFFERENT noise.  Seeded from manual_seed() (else torch.initial_seed()) mixed with the data-parallel rank."""
+    device = torch.device(device)
+    key = (device.type, device.index)
+    r = _default.get(key)
+    if r is None:
+        base = _default_seed[0] if _default_seed[0] is not None else torch.initial_seed()
+        rank = 0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank = torch.distributed.get_rank()
+        r = _default[key] = DeviceRng(device, seed=mix64(base, rank, 0x1D))
+    return r
+
+
 class DeviceRng:
     def __init__(self, device, seed=0, poisson_seed=None):
         """seed: noise streams (per rank in data-parallel runs).  poisson_seed: stream of the residual-flow series
@@ -19,10 +60,11 @@ class DeviceRng:
         block for its whole batch, and equal work per rank removes the wait-for-the-slowest at the all-reduce."""
         self.device = torch.device(device)
         self.gen = torch.Generator(device=self.device)
+        seed = int(seed) % (1 << 63)
         self.gen.manual_seed(seed)
-        self.cpu_gen = torch.Generator().manual_seed(seed + 1)
+        self.cpu_gen = torch.Generator().manual_seed((seed + 1) % (1 << 63))
         self.np = np.random.RandomState((seed + 2 if poisson_seed is None else poisson_seed) % (1 << 32))
-        self._drop = seed * 1000003 + 12345
+        self._drop = (seed * 1000003 + 12345) % (1 << 63)
 
     def randn_image(self, n, c, h, w):
         return torch.randn((n, h, w, c), device=self.device, generator=self.gen)
@@ -89,7 +131,9 @@ class ReplayRng:
         return int(self._next("poisson"))
 
     def dropout_seed(self):
-        return 0
+        """The parity fixtures are recorded with model.dropout = 0 (masks cannot be replayed by seed): the value is
+        never consumed.  NCSNpp raises if a replay is asked to train with dropout > 0."""
+        return None
 
     def done(self):
         return self.i == len(self.events)

@@ -15,7 +15,7 @@ import torch
 
 from . import hip, ops
 from .flow import flow_forward
-from .rng import DeviceRng
+from .rng import default_rng
 from .sde_lib import VESDE, VPSDE
 
 
@@ -144,7 +144,7 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
     def pc_sampler(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
                    sample_dir=None, r=None, rng=None, iters=None):
         """sampling.py:410-456"""
-        rng = rng or DeviceRng(device)
+        rng = rng or default_rng(device)
         with torch.no_grad():
             num_scales = config.sampling.num_scales if config.sampling.num_scales != sde.N else sde.N
             x = prior(rng, data_mean)
@@ -176,7 +176,7 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
     def pc_sampler_search(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
                           sample_dir=None, r=None, rng=None, iters=None):
         """sampling.py:458-495"""
-        rng = rng or DeviceRng(device)
+        rng = rng or default_rng(device)
         with torch.no_grad():
             st = _Stepper(config, sde, model, rng)
             if before_data is None:
@@ -197,7 +197,7 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
     def pc_sampler_more_step(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
                              sample_dir=None, r=None, rng=None, iters=None):
         """sampling.py:497-535"""
-        rng = rng or DeviceRng(device)
+        rng = rng or default_rng(device)
         with torch.no_grad():
             st = _Stepper(config, sde, model, rng)
             if before_data is None:
@@ -227,7 +227,7 @@ def get_ode_sampler(config, sde, shape, inverse_scaler, denoise=False, rtol=1e-5
 
     def ode_sampler(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
                     sample_dir=None, r=None, rng=None, iters=None):
-        rng = rng or DeviceRng(device)
+        rng = rng or default_rng(device)
         with torch.no_grad():
             B, C, H, W = shape
             st = _Stepper(config, sde, model, rng)

@@ -832,66 +832,70 @@ class OracleState:
                 s.sub_((1.0 - d) * (s - self.P[k]))
 
 
-def flow_step_fn_nll(cfg, sde, state, flow_state, batch, rng, stats=None):
-    """losses.py:258-320 (train=True, num_micro_batch=1)"""
-    state.zero_grad()
-    flow_state.zero_grad()
+def _micro_batches(cfg, batch):
+    """losses.py:287-288 / :355-356: batch[B//n*k : B//n*(k+1)] for k < n = optim.num_micro_batch"""
+    n = int(cfg.optim.num_micro_batch)
+    B = batch.shape[0]
+    return [batch[B // n * k: B // n * (k + 1)] for k in range(n)]
+
+
+def _nll_losses(cfg, sde, state, flow_state, mb, rng, stats, importance_sampling=None):
     bn = {}
-    z, losses_flow = flow_forward(flow_state.P, cfg, batch, training=True, rng=rng, stats=stats, bn_updates=bn)
-    losses_score = sde_loss(state.P, cfg, sde, z, True, rng)
+    z, losses_flow = flow_forward(flow_state.P, cfg, mb, training=True, rng=rng, stats=stats, bn_updates=bn)
+    losses_score = sde_loss(state.P, cfg, sde, z, True, rng, importance_sampling=importance_sampling)
     losses_logp = calculate_logp(sde, z, rng)
-    D = np.prod(batch.shape[1:])
+    D = np.prod(mb.shape[1:])
     if cfg.training.reduce_mean:
         losses_flow, losses_logp = -losses_flow / D, -losses_logp / D
     else:
         losses_flow, losses_logp = -losses_flow, -losses_logp
     losses = losses_score + losses_flow + losses_logp
-    torch.mean(losses).backward()
+    torch.mean(losses).backward()      # gradients ACCUMULATE over the micro-batches (sum of per-micro-batch means)
     with torch.no_grad():
         for k, v in bn.items():
             flow_state.P[k] = v
+    return losses.detach(), losses_score.detach(), losses_flow.detach(), losses_logp.detach()
+
+
+def flow_step_fn_nll(cfg, sde, state, flow_state, batch, rng, stats=None):
+    """losses.py:258-320 (train=True)"""
+    state.zero_grad()
+    flow_state.zero_grad()
+    parts = [_nll_losses(cfg, sde, state, flow_state, mb, rng, stats) for mb in _micro_batches(cfg, batch)]
     state.optimize()
     flow_state.optimize()
     state.step += 1
     state.ema_update()
     flow_state.step += 1
     flow_state.ema_update()
-    return losses.detach(), losses_score.detach(), losses_flow.detach(), losses_logp.detach()
+    return tuple(torch.cat([p[i] for p in parts]) for i in range(4))
 
 
 def flow_step_fn_fid(cfg, sde, state, flow_state, batch, rng, stats=None):
     """losses.py:322-406 (training.st=False)"""
     state.zero_grad()
     flow_state.zero_grad()
-    bn = {}
-    z, losses_flow = flow_forward(flow_state.P, cfg, batch, training=True, rng=rng, stats=stats, bn_updates=bn)
-    losses_score = sde_loss(state.P, cfg, sde, z, True, rng, importance_sampling=True)
-    losses_logp = calculate_logp(sde, z, rng)
-    D = np.prod(batch.shape[1:])
-    if cfg.training.reduce_mean:
-        losses_flow, losses_logp = -losses_flow / D, -losses_logp / D
-    else:
-        losses_flow, losses_logp = -losses_flow, -losses_logp
-    losses = losses_score + losses_flow + losses_logp
-    torch.mean(losses).backward()
-    with torch.no_grad():
-        for k, v in bn.items():
-            flow_state.P[k] = v
+    parts = [_nll_losses(cfg, sde, state, flow_state, mb, rng, stats, importance_sampling=True)
+             for mb in _micro_batches(cfg, batch)]
     flow_state.optimize()
     flow_state.ema_update()
     state.zero_grad()
-    bn = {}
-    with torch.no_grad():
-        z2, _ = flow_forward(flow_state.P, cfg, batch, log_det=None, training=True, rng=rng, bn_updates=bn)
-        for k, v in bn.items():
-            flow_state.P[k] = v
-    losses_add = sde_loss(state.P, cfg, sde, z2.detach(), True, rng, recon_loss=False)
-    torch.mean(losses_add).backward()
+    adds = []
+    for mb in _micro_batches(cfg, batch):
+        bn = {}
+        with torch.no_grad():
+            z2, _ = flow_forward(flow_state.P, cfg, mb, log_det=None, training=True, rng=rng, bn_updates=bn)
+            for k, v in bn.items():
+                flow_state.P[k] = v
+        la = sde_loss(state.P, cfg, sde, z2.detach(), True, rng, recon_loss=False)
+        torch.mean(la).backward()
+        adds.append(la.detach())
     state.optimize()
     state.ema_update()
     state.step += 1
     flow_state.step += 1
-    return losses.detach(), losses_add.detach(), losses_flow.detach(), losses_logp.detach()
+    return (torch.cat([p[0] for p in parts]), torch.cat(adds), torch.cat([p[2] for p in parts]),
+            torch.cat([p[3] for p in parts]))
 
 
 # ----------------------------------------------------------------------------- NELBO / NLL

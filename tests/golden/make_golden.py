@@ -186,6 +186,17 @@ def golden_sde(out_dir):
         finally:
             torch.rand = orig
         out[f"{name}/is_t"] = tt.numpy()
+        # reverse-time SDE / probability-flow ODE (sde_lib.py:74-120) around a closed-form stand-in score
+        score_fn = lambda xx, tt_: torch.sin(3.0 * xx) * (1.0 + tt_)[:, None, None, None]  # noqa: E731
+        for pf in (False, True):
+            rsde = sde.reverse(score_fn, probability_flow=pf)
+            tag = f"{name}/rsde_pf{int(pf)}"
+            drift, diff = rsde.sde(x, t)
+            out[f"{tag}/drift"] = drift.numpy()
+            out[f"{tag}/diffusion"] = np.asarray(diff.numpy() if torch.is_tensor(diff) else diff, dtype=np.float32)
+            for nm, nxt in (("disc", None), ("disc2", nt), ("disc0", torch.zeros_like(t))):
+                f, G = rsde.discretize(x, t, nxt)
+                out[f"{tag}/{nm}_f"], out[f"{tag}/{nm}_G"] = f.numpy(), G.numpy()
     out["timestep_embedding"] = ref_layers.get_timestep_embedding(t * 999, 128).numpy()
     torch.manual_seed(3)
     gfp = ref_layerspp.GaussianFourierProjection(embedding_size=8, scale=16.0)
@@ -581,6 +592,119 @@ def golden_celeba(out_dir):
     print("mini_celeba done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
 
 
+# ----------------------------------------------------------------------------- round-2 fixtures
+def golden_round2(out_dir):
+    """mini_r2.npz + mini_r2_ckpt_{score,flow}.pth:
+      * optim.num_micro_batch = 2 training steps (losses.py:280-309), nll and fid step functions, batch 4;
+      * VE likelihood_fn / ODE sampler (likelihood.py:41-140, sampling.py:547-621);
+      * checkpoints written by the REFERENCE's utils.save_checkpoint (utils.py:36-48) after one optimisation step and
+        the step that follows a restore (losses, parameter statistics);
+      * moments of the reference's initialisers (layers.py:54-91 default_init / variance_scaling)."""
+    out = {}
+    # ---- micro-batched steps ----
+    for tag, fixture, cfg_name, patch in (("mb2_nll", "mini_vp_nll", "configs.vp.CIFAR10.indm_nll", patch_vp_nll),
+                                          ("mb2_fid", "mini_vp_fid", "configs.vp.CIFAR10.indm_fid", patch_vp_fid)):
+        cfg = mini(ref_import.get_config(cfg_name), batch=4)
+        patch(cfg)
+        cfg.optim.num_micro_batch = 2
+        score, flow = build(cfg, seed=1234)
+        _load_fixture_weights(fixture, score, flow)
+        sde = sde_lib.get_sde(cfg)
+        scaler = ref_datasets.get_data_scaler(cfg)
+        step_fn = losses.get_step_fn(cfg, sde, train=True, optimize_fn=losses.optimization_manager(cfg), scaler=scaler)
+        state, fstate = make_states(cfg, score, flow)
+        score.train(); flow.train()
+        xb = data_batch(cfg, 4, seed=300)
+        out[f"{tag}/x"] = xb.numpy()
+        rec = Recorder()
+        with rec.on():
+            l, ls, lf, lp = step_fn(state, fstate, xb)
+        for nm, v in (("loss", l), ("loss_score", ls), ("loss_flow", lf), ("loss_logp", lp)):
+            out[f"{tag}/{nm}"] = v.numpy()
+        pack_events(tag, rec.events, out)
+        for pre, mod in (("score", score), ("flow", flow)):
+            named = [(n[len("module."):], p.detach()) for n, p in mod.named_parameters()]
+            for k, v in tensor_stats(named).items():
+                out[f"{tag}/after/{pre}/stat/{k}"] = v
+        out[f"{tag}/steps"] = np.asarray([state["step"], fstate["step"], state["ema"].num_updates])
+
+    # ---- VE: RK45 likelihood + ODE sampler ----
+    cfg = mini(ref_import.get_config("configs.ve.CIFAR10.indm"))
+    score, flow = build(cfg, seed=1234)
+    d = _load_fixture_weights("mini_ve", score, flow)
+    score.eval(); flow.eval()
+    sde = sde_lib.get_sde(cfg)
+    inverse_scaler = ref_datasets.get_data_inverse_scaler(cfg)
+    x = torch.from_numpy(d["x"])
+    lik = likelihood.get_likelihood_fn(cfg, sde, inverse_scaler, rtol=1e-3, atol=1e-3)
+    rec = Recorder()
+    with rec.on():
+        bpd, zlat, nfe = lik(score, flow, x.clone())
+    out["ve_nll/bpd"], out["ve_nll/z"], out["ve_nll/nfe"] = bpd.numpy(), zlat.numpy(), np.asarray(nfe)
+    pack_events("ve_nll", rec.events, out)
+    cfg.sampling.method = "ode"
+    cfg.eval.rtol, cfg.eval.atol = 1e-3, 1e-3
+    osamp = sampling.get_sampling_fn(cfg, sde, tuple(x.shape), inverse_scaler, cfg.sampling.truncation_time)
+    rec = Recorder()
+    with rec.on():
+        before, after, nfe = osamp(score, flow)
+    out["ve_ode/before"], out["ve_ode/after"], out["ve_ode/nfe"] = before.numpy(), after.numpy(), np.asarray(nfe)
+    pack_events("ve_ode", rec.events, out)
+
+    # ---- checkpoints written by the reference ----
+    cfg = mini(ref_import.get_config("configs.vp.CIFAR10.indm_nll"))
+    score, flow = build(cfg, seed=1234)
+    _load_fixture_weights("mini_vp_nll", score, flow)
+    sde = sde_lib.get_sde(cfg)
+    scaler = ref_datasets.get_data_scaler(cfg)
+    step_fn = losses.get_step_fn(cfg, sde, train=True, optimize_fn=losses.optimization_manager(cfg), scaler=scaler)
+    state, fstate = make_states(cfg, score, flow)
+    score.train(); flow.train()
+    step_fn(state, fstate, data_batch(cfg, 2, seed=400))
+    ref_utils.save_checkpoint(cfg, os.path.join(out_dir, "mini_r2_ckpt_score.pth"), state)
+    ref_utils.save_checkpoint(cfg, os.path.join(out_dir, "mini_r2_ckpt_flow.pth"), fstate)
+    xb = data_batch(cfg, 2, seed=401)
+    out["ckpt/x"] = xb.numpy()
+    rec = Recorder()
+    with rec.on():
+        l, ls, lf, lp = step_fn(state, fstate, xb)
+    for nm, v in (("loss", l), ("loss_score", ls), ("loss_flow", lf), ("loss_logp", lp)):
+        out[f"ckpt/{nm}"] = v.numpy()
+    pack_events("ckpt", rec.events, out)
+    for pre, mod, st in (("score", score, state), ("flow", flow, fstate)):
+        named = [(n[len("module."):], p.detach()) for n, p in mod.named_parameters()]
+        for k, v in tensor_stats(named).items():
+            out[f"ckpt/after/{pre}/stat/{k}"] = v
+        tr = [n for n, p in named if dict(mod.named_parameters())["module." + n].requires_grad]
+        for n, s_ in zip(tr, st["ema"].shadow_params):
+            out[f"ckpt/after/{pre}/emastat/{n}"] = np.asarray([float(s_.double().sum()), float(s_.double().pow(2).sum())])
+    out["ckpt/steps"] = np.asarray([state["step"], fstate["step"], state["ema"].num_updates])
+
+    # ---- initialiser moments (D5): default_init(scale) = variance_scaling(scale, 'fan_avg', 'uniform') ----
+    torch.manual_seed(99)
+    shapes = [(128, 3, 3, 3), (256, 128, 3, 3), (256, 256, 1, 1), (512, 128), (128, 256)]
+    out["init/shapes"] = np.asarray([list(s_) + [0] * (4 - len(s_)) for s_ in shapes])
+    for i, shp in enumerate(shapes):
+        for scale in (1.0, 0.1, 0.0):
+            w = ref_layers.default_init(scale)(shp)
+            out[f"init/{i}/scale{scale}"] = np.asarray([float(w.double().mean()), float(w.double().var(unbiased=False)),
+                                                        float(w.min()), float(w.max())])
+    # whole-network initialisation from a seed (mutils.create_model / create_flow_model constructors)
+    cfg = mini(ref_import.get_config("configs.vp.CIFAR10.indm_nll"))
+    torch.manual_seed(7)
+    np.random.seed(7)
+    score = mutils.create_model(cfg)
+    torch.manual_seed(8)
+    flow = create_flow_model(cfg)
+    for pre, mod in (("score", score), ("flow", flow)):
+        for k, v in mod.state_dict().items():
+            v = v.detach().double()
+            out[f"init_net/{pre}/{k[len('module.'):]}"] = np.asarray([float(v.sum()), float(v.pow(2).sum()),
+                                                                      float(v.min()), float(v.max())])
+    np.savez_compressed(os.path.join(out_dir, "mini_r2.npz"), **out)
+    print("mini_r2 done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
+
+
 def patch_vp_nll(cfg):
     pass
 
@@ -610,3 +734,5 @@ if __name__ == "__main__":
         golden_extra(HERE)
     if "celeba" in which:
         golden_celeba(HERE)
+    if "r2" in which:
+        golden_round2(HERE)

@@ -335,3 +335,101 @@ def case_celeba_squeeze(device, tol=1.0):
 
 EXTRA_CASES = [case_pc_sampler_search, case_pc_sampler_more_step, case_get_bpd, case_deeper_score_net,
                case_celeba_squeeze]
+
+
+# ----------------------------------------------------------------------------- round-2 fixtures (mini_r2.npz)
+def _check_param_stats(d, prefix, pairs, tol, slack=0.0):
+    """slack: absolute allowance on a tensor's sum -- AdamW's first update is lr*g/(|g|+eps), so an element whose
+    gradient sits at rounding-noise level may move by a few per cent of lr differently (cf. case_two_training_steps)."""
+    for pre, model in pairs:
+        for n, p in model.named_parameters():
+            ref = torch.from_numpy(d[f"{prefix}/{pre}/stat/{n}"]).double()
+            got = gu.stat(p)
+            scale = (ref[1].item() * p.numel()) ** 0.5 + 1e-12
+            assert abs(got[0] - ref[0]).item() <= 1e-4 * tol * scale + 2e-6 + slack, ("param sum " + n, got, ref)
+            assert abs(got[1] - ref[1]).item() <= 1e-4 * tol * ref[1].item() + 1e-9 + 2 * slack * p.detach().abs().max().item(), \
+                ("param sumsq " + n, got, ref)
+
+
+def case_micro_batch_step(tag, device, tol=1.0):
+    """optim.num_micro_batch = 2 against the reference's own micro-batched step (losses.py:280-309 / :355-399):
+    the 4 loss vectors in batch order and every parameter after the fused optimiser (gradients are the SUM of the
+    per-micro-batch means)."""
+    d = gu.load("mini_r2")
+    fx = {"mb2_nll": "mini_vp_nll", "mb2_fid": "mini_vp_fid"}[tag]
+    _, cfg, score, fl = build(fx, device)
+    cfg.optim.num_micro_batch = 2
+    sde = sde_lib.get_sde(cfg)
+    state, flow_state, _ = utils.build_states(cfg, score, fl, device)
+    step_fn = losses.get_step_fn(cfg, sde, train=True)
+    score.train(); fl.train()
+    rng = ReplayRng(gu.events(d, tag), device)
+    out = step_fn(state, flow_state, torch.from_numpy(d[f"{tag}/x"]).to(device), rng=rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+        gu.assert_close(v, d[f"{tag}/{nm}"], 5e-4 * tol, 2e-5 * tol, f"{tag} {nm}")
+    _check_param_stats(d, f"{tag}/after", (("score", score), ("flow", fl)), tol, slack=0.02 * cfg.flow.lr)
+    assert [state["step"], flow_state["step"], state["ema"].num_updates] == list(d[f"{tag}/steps"])
+
+
+def case_ve_ode(device, tol=1.0):
+    """VE probability-flow ODE: RK45 likelihood (likelihood.py:41-140) and ODE sampler (sampling.py:547-621)."""
+    d = gu.load("mini_r2")
+    dv, cfg, score, fl = build("mini_ve", device)
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    inv = utils.get_data_inverse_scaler(cfg)
+    x = torch.from_numpy(dv["x"]).to(device)
+    fn = likelihood.get_likelihood_fn(cfg, sde, inv, rtol=1e-3, atol=1e-3)
+    rng = ReplayRng(gu.events(d, "ve_nll"), device)
+    bpd, z, nfe = fn(score, fl, x, rng=rng)
+    assert rng.done()
+    assert abs(nfe - int(d["ve_nll/nfe"])) <= 12, (nfe, int(d["ve_nll/nfe"]))
+    gu.assert_close(bpd, d["ve_nll/bpd"], 1e-3 * tol, 3e-3 * tol, "ve nll bpd")
+    cfg.sampling.method = "ode"
+    cfg.eval.rtol, cfg.eval.atol = 1e-3, 1e-3
+    fn = sampling.get_sampling_fn(cfg, sde, tuple(x.shape), inv, cfg.sampling.truncation_time, device=device)
+    rng = ReplayRng(gu.events(d, "ve_ode"), device)
+    before, after, nfe = fn(score, fl, rng=rng)
+    assert rng.done()
+    gu.assert_close(before, d["ve_ode/before"], 5e-3 * tol, 5e-3 * tol, "ve ode before")
+    gu.assert_close(after, d["ve_ode/after"], 5e-3 * tol, 5e-3 * tol, "ve ode after")
+
+
+def case_reference_checkpoint(device, tol=1.0):
+    """Restore checkpoints WRITTEN BY THE REFERENCE's utils.save_checkpoint (utils.py:36-48; tests/golden/
+    mini_r2_ckpt_*.pth, taken after one optimisation step) into freshly initialised product networks and reproduce the
+    reference's next step: losses, parameters (=> AdamW moments + step count restored) and EMA (=> shadow + num_updates)."""
+    import os
+    d = gu.load("mini_r2")
+    cfg = gu.mini_config("mini_vp_nll")
+    cfg.device = torch.device(device)
+    torch.manual_seed(123)                       # weights the checkpoint must overwrite
+    score = ncsnpp.NCSNpp(cfg).to(device)
+    fl = iflow.create_flow_model(cfg).to(device)
+    state, flow_state, _ = utils.build_states(cfg, score, fl, device)
+    utils.restore_checkpoint(cfg, os.path.join(gu.GOLDEN, "mini_r2_ckpt_score.pth"), state, device)
+    utils.restore_checkpoint(cfg, os.path.join(gu.GOLDEN, "mini_r2_ckpt_flow.pth"), flow_state, device)
+    assert state["step"] == 1 and flow_state["step"] == 1 and state["ema"].num_updates == 1
+    assert state["optimizer"].t == 1 and flow_state["optimizer"].t == 1
+    sde = sde_lib.get_sde(cfg)
+    step_fn = losses.get_step_fn(cfg, sde, train=True)
+    score.train(); fl.train()
+    rng = ReplayRng(gu.events(d, "ckpt"), device)
+    out = step_fn(state, flow_state, torch.from_numpy(d["ckpt/x"]).to(device), rng=rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+        gu.assert_close(v, d[f"ckpt/{nm}"], 5e-4 * tol, 2e-5 * tol, f"ckpt step {nm}")
+    _check_param_stats(d, "ckpt/after", (("score", score), ("flow", fl)), tol, slack=0.02 * cfg.flow.lr)
+    for pre, model, st in (("score", score, state), ("flow", fl, flow_state)):
+        ema = dict(zip([n for n, p in model.named_parameters() if p.requires_grad], st["ema"].shadow_params()))
+        for n, s_ in ema.items():
+            ref = torch.from_numpy(d[f"ckpt/after/{pre}/emastat/{n}"]).double()
+            got = gu.stat(s_)
+            scale = (ref[1].item() * s_.numel()) ** 0.5 + 1e-12
+            assert abs(got[0] - ref[0]).item() <= 1e-4 * tol * scale + 2e-6, ("ema sum " + n, got, ref)
+            assert abs(got[1] - ref[1]).item() <= 1e-4 * tol * ref[1].item() + 1e-9, ("ema sumsq " + n, got, ref)
+    assert [state["step"], flow_state["step"], state["ema"].num_updates] == list(d["ckpt/steps"])
+
+
+R2_CASES = [case_ve_ode, case_reference_checkpoint]

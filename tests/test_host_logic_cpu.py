@@ -22,6 +22,16 @@ def test_extra_case(case, emulate_hip):
     case("cpu")
 
 
+@pytest.mark.parametrize("case", pc.R2_CASES, ids=lambda f: f.__name__)
+def test_r2_case(case, emulate_hip):
+    case("cpu")
+
+
+@pytest.mark.parametrize("tag", ["mb2_nll", "mb2_fid"])
+def test_micro_batch_golden(tag, emulate_hip):
+    pc.case_micro_batch_step(tag, "cpu")
+
+
 def test_sampling_lib_cache(emulate_hip, tmp_path):
     """sampling_lib.get_samples: first call samples and writes the reference's npz files, second call resumes from
     them (flow inverse in chunks of 16), pc_denoise resumes from the for-search snapshot."""
@@ -49,8 +59,11 @@ def test_sampling_lib_cache(emulate_hip, tmp_path):
     # second call: cached latents -> flow inverse in chunks of 16 -> same images (up to the fixed-point tolerance)
     os_remove = __import__("os").remove
     os_remove(tsd + "/samples_0.npz")
+    from indm_amd import rng as irng
+    irng.manual_seed(5)     # the flow inverse draws h from the prior with the process-wide (advancing) noise source
     b2, a2 = sampling_lib.get_samples(cfg, score, fl, fn, 3, 0, sd, 1.0, inv, tsd, scaler)
     from indm_amd.flow import flow_forward
+    irng.manual_seed(5)
     with torch.no_grad():
         want = inv(flow_forward(cfg, fl, scaler(b2), log_det=None, reverse=True)[0])
     assert torch.allclose(b2, b1, rtol=1e-6, atol=1e-6 * float(b1.abs().max())) and torch.equal(a2, want)
@@ -87,3 +100,109 @@ def test_micro_batches_and_loss_readback(fx, emulate_hip):
     if cfg.training.likelihood_weighting:
         assert torch.allclose(out[0], out[1] + out[2] + out[3], rtol=1e-5, atol=1e-5)
     assert state["step"] == 1 and flow_state["step"] == 1
+
+
+def test_default_noise_source_advances(emulate_hip):
+    """callers that pass no rng= must not replay a constant seed -- two consecutive sampling_fn /
+    nelbo_fn / loss_fn calls draw different noise (the reference uses the advancing global torch generator), and
+    rng.manual_seed() makes a run reproducible."""
+    import torch
+    from indm_amd import likelihood, losses, rng, sampling, sde_lib, utils
+    d, cfg, score, fl = pc.build("mini_vp_nll", "cpu")
+    cfg.sampling.method, cfg.sampling.num_scales = "pc", 2
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    inv = utils.get_data_inverse_scaler(cfg)
+    fn = sampling.get_sampling_fn(cfg, sde, (2, 3, 32, 32), inv, cfg.sampling.truncation_time, device="cpu")
+    rng.manual_seed(11)
+    b1, _, _ = fn(score, fl)
+    b2, _, _ = fn(score, fl)
+    assert not torch.equal(b1, b2)
+    rng.manual_seed(11)
+    b3, _, _ = fn(score, fl)
+    assert torch.equal(b1, b3)
+    x = torch.from_numpy(d["x"])
+    nelbo = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=inv)
+    n1, n2 = nelbo(score, fl, x)[0], nelbo(score, fl, x)[0]
+    assert not torch.equal(n1, n2)
+    loss_fn = losses.get_sde_loss_fn(cfg, sde, train=False)
+    with torch.no_grad():
+        l1, l2 = loss_fn(score, x), loss_fn(score, x)
+    assert not torch.equal(l1, l2)
+    # per-(step, rank) streams of the training step do not collide the way step + 7919*rank did
+    assert rng.mix64(42, 0, 1) != rng.mix64(42, 7919, 0) and rng.mix64(1, 2) != rng.mix64(2, 1)
+
+
+def test_warmup_ramps_from_the_configured_lr(emulate_hip):
+    """optim.warmup > 0 -- lr_k = config.optim.lr * min(k / warmup, 1) for BOTH optimisers
+    (losses.py:51-57: the default lr of optimize_fn is config.optim.lr), not stuck at the 0 written at step 0."""
+    import torch
+    from indm_amd import losses, sde_lib, utils
+    from indm_amd.rng import DeviceRng
+    d, cfg, score, fl = pc.build("mini_vp_nll", "cpu")
+    cfg.optim.warmup = 2
+    state, flow_state, _ = utils.build_states(cfg, score, fl, "cpu")
+    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+    score.train(); fl.train()
+    x = torch.from_numpy(d["step0/x"])
+    seen = []
+    for k in range(3):
+        before = state["optimizer"].flat.p.clone()
+        step_fn(state, flow_state, x, rng=DeviceRng("cpu", seed=k))
+        seen.append((state["optimizer"].param_groups[0]["lr"], flow_state["optimizer"].param_groups[0]["lr"],
+                     float((state["optimizer"].flat.p - before).abs().max())))
+    want = [cfg.optim.lr * min(k / 2, 1.0) for k in range(3)]
+    for (ls, lf, moved), w in zip(seen, want):
+        assert abs(ls - w) < 1e-12 and abs(lf - w) < 1e-12, (seen, want)
+    assert seen[0][2] == 0.0 and seen[1][2] > 0.0 and seen[2][2] > 0.0
+
+
+def test_eval_step_still_updates_ema(emulate_hip):
+    """train=False: flow_step_fn_nll still advances step and EMA (losses.py:314-318); flow_step_fn_fid does nothing."""
+    import torch
+    from indm_amd import losses, sde_lib, utils
+    for fx, moved in (("mini_vp_nll", True), ("mini_vp_fid", False)):
+        d, cfg, score, fl = pc.build(fx, "cpu")
+        state, flow_state, _ = utils.build_states(cfg, score, fl, "cpu")
+        step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=False)
+        out = step_fn(state, flow_state, torch.from_numpy(d["step0/x"]))
+        assert all(float(v.abs().sum()) == 0.0 for v in out)
+        assert (state["step"], flow_state["step"]) == ((1, 1) if moved else (0, 0))
+        assert state["ema"].num_updates == (1 if moved else 0) and flow_state["ema"].num_updates == (1 if moved else 0)
+
+
+def test_initialisers_match_the_reference():
+    """D5: default_init / variance_scaling (models/layers.py:54-91).  The product's constructors consume the torch
+    generator exactly like the reference's, so a seeded NCSN++ is BIT-identical; the flow (different draw order) must
+    match in distribution: per-tensor second moment and range of every parameter."""
+    import numpy as np
+    import torch
+    import golden_utils as gu
+    from indm_amd import flow as iflow
+    from indm_amd import ncsnpp
+    d = gu.load("mini_r2")
+    torch.manual_seed(99)
+    for i, shp in enumerate(d["init/shapes"]):
+        shp = tuple(int(v) for v in shp if v > 0)
+        for scale in (1.0, 0.1, 0.0):
+            w = ncsnpp.default_init_(shp, scale).double()
+            got = np.asarray([float(w.mean()), float(w.var(unbiased=False)), float(w.min()), float(w.max())])
+            assert np.allclose(got, d[f"init/{i}/scale{scale}"], rtol=1e-12, atol=0), (shp, scale, got)
+    cfg = gu.mini_config("mini_vp_nll")
+    torch.manual_seed(7)
+    score = ncsnpp.NCSNpp(cfg)
+    torch.manual_seed(8)
+    fl = iflow.create_flow_model(cfg)
+    for k, v in score.reference_state_dict(prefix="").items():
+        v = v.double()
+        got = np.asarray([float(v.sum()), float(v.pow(2).sum()), float(v.min()), float(v.max())])
+        assert np.array_equal(got, d[f"init_net/score/{k}"]), k
+    for k, v in fl.reference_state_dict(prefix="").items():
+        ref = d[f"init_net/flow/{k}"]
+        v = v.double()
+        n = v.numel()
+        if n < 64 or not v.is_floating_point():
+            assert abs(float(v.sum()) - ref[0]) <= 1e-6 + 6.0 * (ref[1] + 1e-12) ** 0.5, k    # |sum| <~ 6 sigma sqrt(n)
+            continue
+        assert abs(float(v.pow(2).sum()) - ref[1]) <= (8.0 / n ** 0.5) * ref[1] + 1e-9, (k, float(v.pow(2).sum()), ref[1])
+        assert float(v.min()) >= 2.5 * min(ref[2], 0.0) - 1e-6 and float(v.max()) <= 2.5 * max(ref[3], 0.0) + 1e-6, k

@@ -329,3 +329,71 @@ def test_celeba_squeeze_config():
         for k in st.trainable:
             gu.assert_close(gu.stat(st.P[k]), d[f"after1/{pre}/stat/{k}"], 1e-5, 1e-6, "param " + k)
     assert [state.step, fstate.step, state.num_updates] == list(d["after1/steps"])
+
+
+# ----------------------------------------------------------------------------- round-2 fixtures (mini_r2.npz)
+@pytest.mark.parametrize("tag", ["mb2_nll", "mb2_fid"])
+def test_micro_batched_step(tag):
+    """optim.num_micro_batch = 2 (losses.py:280-309, :355-399)"""
+    d = gu.load("mini_r2")
+    fx = {"mb2_nll": "mini_vp_nll", "mb2_fid": "mini_vp_fid"}[tag]
+    dw, cfg = gu.load(fx), gu.mini_config(fx)
+    cfg.optim.num_micro_batch = 2
+    sde = O.get_sde(cfg)
+    state = O.OracleState(gu.state_dict(dw, "score"), cfg.optim.lr, cfg.model.ema_rate, cfg)
+    fstate = O.OracleState(gu.state_dict(dw, "flow"), cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    step = O.flow_step_fn_nll if cfg.training.likelihood_weighting else O.flow_step_fn_fid
+    rng = O.ReplayRng(gu.events(d, tag))
+    out = step(cfg, sde, state, fstate, torch.from_numpy(d[f"{tag}/x"]), rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+        gu.assert_close(v, d[f"{tag}/{nm}"], 2e-4, 1e-5, f"{tag} {nm}")
+    for pre, st in (("score", state), ("flow", fstate)):
+        for k in st.trainable:
+            gu.assert_close(gu.stat(st.P[k]), d[f"{tag}/after/{pre}/stat/{k}"], 1e-5, 1e-6, "param " + k)
+    assert [state.step, fstate.step, state.num_updates] == list(d[f"{tag}/steps"])
+
+
+def test_ve_pf_ode_likelihood_and_sampler():
+    d, dv, cfg = gu.load("mini_r2"), gu.load("mini_ve"), gu.mini_config("mini_ve")
+    Ps, Pf = gu.state_dict(dv, "score"), gu.state_dict(dv, "flow")
+    sde = O.get_sde(cfg)
+    x = torch.from_numpy(dv["x"])
+    rng = O.ReplayRng(gu.events(d, "ve_nll"))
+    bpd, z, nfe = O.likelihood_fn(Ps, Pf, cfg, sde, x, rng, rtol=1e-3, atol=1e-3)
+    assert rng.done() and nfe == int(d["ve_nll/nfe"])
+    gu.assert_close(bpd, d["ve_nll/bpd"], 1e-4, 1e-3, "ve nll bpd")
+    gu.assert_close(z, d["ve_nll/z"], 1e-3, 1e-3, "ve nll z")
+    rng = O.ReplayRng(gu.events(d, "ve_ode"))
+    before, after, nfe = O.ode_sampler(Ps, Pf, cfg, sde, tuple(x.shape), rng, cfg.sampling.truncation_time, 1e-3, 1e-3)
+    assert rng.done() and nfe == int(d["ve_ode/nfe"])
+    gu.assert_close(before, d["ve_ode/before"], 1e-3, 1e-3, "ve ode before")
+    gu.assert_close(after, d["ve_ode/after"], 1e-3, 1e-3, "ve ode after")
+
+
+def test_step_after_reference_checkpoint():
+    """the oracle restarts from the checkpoint files the reference's save_checkpoint wrote (utils.py:36-48)"""
+    import os
+    d, cfg = gu.load("mini_r2"), gu.mini_config("mini_vp_nll")
+    sde = O.get_sde(cfg)
+    states = []
+    for name, lr, rate in (("score", cfg.optim.lr, cfg.model.ema_rate), ("flow", cfg.flow.lr, cfg.flow.ema_rate)):
+        ck = torch.load(os.path.join(gu.GOLDEN, f"mini_r2_ckpt_{name}.pth"), map_location="cpu", weights_only=False)
+        st = O.OracleState({k[len("module."):]: v for k, v in ck["model"].items()}, lr, rate, cfg)
+        st.opt.load_state_dict(ck["optimizer"])
+        st.ema = [s.clone() for s in ck["ema"]["shadow_params"]]
+        st.num_updates, st.step = ck["ema"]["num_updates"], ck["step"]
+        assert len(st.ema) == len(st.trainable)
+        states.append(st)
+    state, fstate = states
+    rng = O.ReplayRng(gu.events(d, "ckpt"))
+    out = O.flow_step_fn_nll(cfg, sde, state, fstate, torch.from_numpy(d["ckpt/x"]), rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+        gu.assert_close(v, d[f"ckpt/{nm}"], 2e-4, 1e-5, f"ckpt {nm}")
+    for pre, st in (("score", state), ("flow", fstate)):
+        for k in st.trainable:
+            gu.assert_close(gu.stat(st.P[k]), d[f"ckpt/after/{pre}/stat/{k}"], 1e-5, 1e-6, "param " + k)
+        for k, s_ in zip(st.trainable, st.ema):
+            gu.assert_close(gu.stat(s_), d[f"ckpt/after/{pre}/emastat/{k}"], 1e-5, 1e-6, "ema " + k)
+    assert [state.step, fstate.step, state.num_updates] == list(d["ckpt/steps"])

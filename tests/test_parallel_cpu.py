@@ -20,7 +20,7 @@ def _patch_emu():
             setattr(hip, name, getattr(_emu, name))
 
 
-def _run_steps(rank, world, port, out_path):
+def _run_steps(rank, world, port, out_path, fx="mini_vp_nll"):
     _patch_emu()
     import golden_utils as gu
     from indm_amd import flow as iflow
@@ -29,12 +29,12 @@ def _run_steps(rank, world, port, out_path):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     parallel.init_distributed(backend="gloo")
-    d, cfg = gu.load("mini_vp_nll"), gu.mini_config("mini_vp_nll")
+    d, cfg = gu.load(fx), gu.mini_config(fx)
     score = ncsnpp.NCSNpp(cfg); score.load_reference_state_dict(gu.state_dict(d, "score"))
     fl = iflow.create_flow_model(cfg); fl.load_reference_state_dict(gu.state_dict(d, "flow"))
     state, fstate, flat_g = utils.build_states(cfg, score, fl, "cpu")
-    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True, world_size=world,
-                                 allreduce=parallel.make_allreduce(flat_g, world))
+    reducer = parallel.make_allreduce(flat_g, world)
+    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True, world_size=world, allreduce=reducer)
     score.train(); fl.train()
     # each rank trains on ONE image of the golden batch with that image's slice of the recorded noise
     ev = []
@@ -63,7 +63,9 @@ def _run_steps(rank, world, port, out_path):
         parallel.make_allreduce(g2, world)()
     opt2.step(grad_clip=cfg.optim.grad_clip, grad_scale=1.0 / world)
     torch.save({"loss": out[0], "p": state["optimizer"].flat.p.clone(), "pf": fstate["optimizer"].flat.p.clone(),
-                "p2": f2.p.clone(), "g2": g2.clone() / world}, out_path.format(rank=rank))
+                "p2": f2.p.clone(), "g2": g2.clone() / world, "calls": list(reducer.calls) if reducer else [],
+                "sizes": (state["optimizer"].flat.g.numel(), fstate["optimizer"].flat.g.numel())},
+               out_path.format(rank=rank))
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -75,6 +77,10 @@ def test_two_rank_step_matches_single_rank(tmp_path):
     mp.spawn(_run_steps, args=(2, port, path), nprocs=2, join=True)
     a, b = torch.load(path.format(rank=0)), torch.load(path.format(rank=1))
     assert torch.equal(a["p"], b["p"]) and torch.equal(a["pf"], b["pf"])  # replicas stay in lock-step
+    # flow_step_fn_nll: the score slice is reduced from INSIDE the backward pass (overlapping the flow's backward), the
+    # flow slice after it -- each gradient element crosses the wire exactly once
+    ns, nf = a["sizes"]
+    assert a["calls"] == [ns, nf] == b["calls"], (a["calls"], ns, nf)
     # single-process reference on the full batch (BatchNorm statistics are per-rank by design, so compare the
     # score network, whose loss has no cross-image coupling given the same z; the flow differs through BN only)
     single = str(tmp_path / "s{rank}.pt")
@@ -86,3 +92,17 @@ def test_two_rank_step_matches_single_rank(tmp_path):
     assert gerr < 1e-5, gerr
     perr = (a["p2"] - s["p2"]).abs().max().item()
     assert perr < 1e-6, perr
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_fid_step_reduces_only_the_stepped_slice(tmp_path):
+    """flow_step_fn_fid on 2 ranks: phase 1 all-reduces the flow slice only, phase 2 the score slice only (SURVEY 8e:
+    52.7 MB then 247 MB at full size -- not the joint 300 MB buffer twice); replicas end bit-identical."""
+    port = 29500 + (os.getpid() + 7) % 1000
+    path = str(tmp_path / "f{rank}.pt")
+    mp.spawn(_run_steps, args=(2, port, path, "mini_vp_fid"), nprocs=2, join=True)
+    a, b = torch.load(path.format(rank=0)), torch.load(path.format(rank=1))
+    assert torch.equal(a["p"], b["p"]) and torch.equal(a["pf"], b["pf"])
+    ns, nf = a["sizes"]
+    assert a["calls"] == [nf, ns] == b["calls"], (a["calls"], ns, nf)
+    assert torch.isfinite(a["loss"]).all()

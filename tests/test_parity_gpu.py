@@ -27,6 +27,18 @@ def test_extra_case(case):
     case("cuda")
 
 
+@pytest.mark.parametrize("case", pc.R2_CASES, ids=lambda f: f.__name__)
+def test_r2_case(case):
+    """VE RK45 likelihood / ODE sampler goldens; checkpoints written by the reference's own save_checkpoint."""
+    case("cuda")
+
+
+@pytest.mark.parametrize("tag", ["mb2_nll", "mb2_fid"])
+def test_micro_batch_golden(tag):
+    """optim.num_micro_batch = 2 against the reference's micro-batched step (golden, not self-comparison)."""
+    pc.case_micro_batch_step(tag, "cuda")
+
+
 @pytest.mark.parametrize("fx", ["mini_vp_nll", "mini_vp_fid"])
 def test_micro_batches_and_async_loss_readback(fx):
     """num_micro_batch = 2 on the GPU: the loss vectors come back through the pinned, event-synchronised copy that is
