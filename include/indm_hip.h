@@ -152,6 +152,13 @@ int indm_rowreduce_f32(const float* x, const float* y, float* out, long B, long 
 int indm_sincos_act_fwd_f32(const float* p, float* a, float* d, long n, void* stream);
 int indm_sincos_act_bwd_f32(const float* da, const float* dd, const float* a, const float* d, float* dp, long n,
                             void* stream);
+/* One Sin level of the hand-written backward of an iResBlock (replaces autograd over iresblock.py:253-273's double
+ * backward): with u = t .* d a link of the explicit VJP chain and a = Sin(p) the activation of g,
+ *   dp = da*d - 4 pi^2 * a * (du*t);  dt_out = du*d (optional);  seg_out[s][c] = per-segment column sums of dp (optional:
+ * the per-image conditioning-bias gradient; rows_per_seg % 64 == 0).  All tensors [R, C]; ws: indm_ires_bwd_act_ws_floats. */
+long indm_ires_bwd_act_ws_floats(long R, int C);
+int indm_ires_bwd_act_f32(const float* da, const float* du, const float* d, const float* a, const float* t, float* dp,
+                          float* dt_out, float* seg_out, long R, int C, long rows_per_seg, float* ws, void* stream);
 /* act 1 SiLU (models/layers.py:38-39), 2 ELU (resnet_batchnorm.py:27) */
 int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);
 int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);

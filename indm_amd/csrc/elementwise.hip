@@ -191,6 +191,84 @@ INDM_API int indm_sincos_act_bwd_f32(const float* da, const float* dd, const flo
   });
 }
 
+// ---- hand-written backward of the residual-flow block (flow.py::_IResTrain) --------------------------------------
+// One pass replaces autograd's mul2 + sincos_act_bwd (+ the segmented bias reduction) at one Sin level of the block:
+//   u = t .* d  is a link of the explicit VJP chain (d = cos(2 pi p) the gate, t the incoming vector) and
+//   a = sin(2 pi p)/(2 pi) the activation of g itself, so with  da = dL/da (through g)  and  du = dL/du (through the
+//   chain):   dp = da*d - 4 pi^2 * a * (du*t)          (dd = du*t is never written)
+//             dt = du*d                                  (optional second output: the chain's next cotangent)
+//             seg[s][c] = sum over the rows of segment s of dp[., c]   (optional: per-image bias gradient)
+// Rows are [R, C] with C contiguous; a workgroup owns 64 consecutive rows (all columns), so the column sums of dp come
+// for free in registers: partial sums per (64-row chunk, column) go to `ws`, a second tiny kernel folds the chunks of
+// each segment.  Reads 5 tensors, writes 1 (2): 6 (7) passes instead of the 10 of mul2 + sincos_act_bwd.
+namespace {
+constexpr int IRES_CH = 64;
+template <bool HAS_DT, bool HAS_SEG>
+__global__ __launch_bounds__(256) void ires_bwd_act_kernel(const float* __restrict__ da, const float* __restrict__ du,
+                                                           const float* __restrict__ d, const float* __restrict__ a,
+                                                           const float* __restrict__ t, float* __restrict__ dp,
+                                                           float* __restrict__ dt, float* __restrict__ part, long R,
+                                                           int C) {
+  const float K = TWO_PI * TWO_PI;
+  for (long chunk = blockIdx.x; chunk * IRES_CH < R; chunk += gridDim.x) {
+    const long r0 = chunk * IRES_CH;
+    const int nr = (int)min((long)IRES_CH, R - r0);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float s = 0.f;
+      long i = r0 * C + c;
+#pragma unroll 4
+      for (int r = 0; r < nr; ++r, i += C) {
+        const float uu = du[i], dd = d[i];
+        const float g = da[i] * dd - K * a[i] * (uu * t[i]);
+        dp[i] = g;
+        if (HAS_DT) dt[i] = uu * dd;
+        if (HAS_SEG) s += g;
+      }
+      if (HAS_SEG) part[chunk * C + c] = s;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ires_seg_fold_kernel(const float* __restrict__ part, float* __restrict__ seg,
+                                                            long nseg, int cps, int C) {
+  const long total = nseg * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long sgm = i / C;
+    const int c = (int)(i - sgm * C);
+    const float* q = part + (sgm * cps) * C + c;
+    float s = 0.f;
+    for (int k = 0; k < cps; ++k) s += q[(long)k * C];
+    seg[i] = s;
+  }
+}
+}  // namespace
+
+INDM_API long indm_ires_bwd_act_ws_floats(long R, int C) { return ((R + IRES_CH - 1) / IRES_CH) * (long)C; }
+
+// da, du, d, a, t, dp (and dt_out if non-null): [R, C]; seg_out (if non-null): [R / rows_per_seg, C], which needs
+// rows_per_seg % 64 == 0 and ws of indm_ires_bwd_act_ws_floats(R, C) floats.
+INDM_API int indm_ires_bwd_act_f32(const float* da, const float* du, const float* d, const float* a, const float* t,
+                                   float* dp, float* dt_out, float* seg_out, long R, int C, long rows_per_seg,
+                                   float* ws, void* stream) {
+  if (R < 0 || C <= 0) return INDM_E_SHAPE;
+  if (R == 0) return INDM_OK;
+  if (seg_out && (rows_per_seg <= 0 || rows_per_seg % IRES_CH || R % rows_per_seg || !ws)) return INDM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long chunks = (R + IRES_CH - 1) / IRES_CH;
+  dim3 grid((unsigned)(chunks > 4096 ? 4096 : chunks)), block(256);
+  if (dt_out && seg_out) hipLaunchKernelGGL((ires_bwd_act_kernel<true, true>), grid, block, 0, st, da, du, d, a, t, dp, dt_out, ws, R, C);
+  else if (dt_out) hipLaunchKernelGGL((ires_bwd_act_kernel<true, false>), grid, block, 0, st, da, du, d, a, t, dp, dt_out, ws, R, C);
+  else if (seg_out) hipLaunchKernelGGL((ires_bwd_act_kernel<false, true>), grid, block, 0, st, da, du, d, a, t, dp, dt_out, ws, R, C);
+  else hipLaunchKernelGGL((ires_bwd_act_kernel<false, false>), grid, block, 0, st, da, du, d, a, t, dp, dt_out, ws, R, C);
+  INDM_CHECK_LAUNCH();
+  if (seg_out) {
+    const long nseg = R / rows_per_seg;
+    hipLaunchKernelGGL(ires_seg_fold_kernel, dim3(ew_grid(nseg * C, 256)), block, 0, st, ws, seg_out, nseg,
+                       (int)(rows_per_seg / IRES_CH), C);
+    INDM_CHECK_LAUNCH();
+  }
+  return INDM_OK;
+}
+
 // act: 1 = SiLU, 2 = ELU(alpha=1)
 INDM_API int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream) {
   return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) {

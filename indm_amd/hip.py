@@ -56,6 +56,8 @@ _SIGS = {
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "indm_ires_bwd_act_ws_floats": [c_l, c_i],
+    "indm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p],
     "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
     "indm_act_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_p],
     "indm_axpby_f32": [c_p, c_p, c_p, c_f, c_f, c_f, c_l, c_p],
@@ -97,7 +99,7 @@ _SIGS = {
     "indm_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
 }
 _LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_segreduce_ws_floats", "indm_rowreduce_ws_floats",
-             "indm_dsm_ws_floats", "indm_sqnorm_ws_floats"}
+             "indm_dsm_ws_floats", "indm_sqnorm_ws_floats", "indm_ires_bwd_act_ws_floats"}
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 
@@ -419,12 +421,20 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
     return dx
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None):
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None, x_gate=None):
     """Gradient of conv2d w.r.t. its RSCK weight. x [N,H,W,Ci], dy [N,OH,OW,Co] -> [KH,KW,Ci,Co].
     dy_gate (optional, dy's shape): computes with dy .* dy_gate; on the skinny-x form the gate rides on the GEMM's
-    operand loader (the wide tensor is read once, no gated copy is written)."""
+    operand loader (the wide tensor is read once, no gated copy is written).  x_gate: the same for x on the
+    skinny-dy form."""
     N, H, W, Ci = x.shape
     _, OH, OW, Co = dy.shape
+    if x_gate is not None:
+        if dy_gate is None and _skinny(kh, kw, stride, pad, Co, Ci):
+            dycol = tap_spread(dy, 1, alpha)
+            q = gemm(x.reshape(-1, Ci), dycol.reshape(-1, 9 * Co), trans_a=True, splitk=True,
+                     gate=x_gate.reshape(-1, Ci))
+            return q.view(Ci, 3, 3, Co).permute(1, 2, 0, 3).contiguous()
+        x = mul(x, x_gate)
     if dy_gate is not None:
         if _skinny(kh, kw, stride, pad, Ci, Co):
             # (dy .* g)^T [Co x pixels] x xcol [pixels x 9*Ci]  ->  [Co, 9*Ci], transposed back to RSCK (tiny)
@@ -567,6 +577,24 @@ def sincos_bwd(da, dd, a, d):
     _chk(lib().indm_sincos_act_bwd_f32(_ptr(da), _ptr(dd), _ptr(a), _ptr(d), _ptr(dp), a.numel(), _stream()),
          "indm_sincos_act_bwd_f32")
     return dp
+
+
+def ires_bwd_act(da, du, d, a, t, want_dt=False, rows_per_seg=None):
+    """One Sin level of the iResBlock's hand-written backward: dp = da*d - 4 pi^2 a (du*t); optionally dt = du*d and the
+    per-segment column sums of dp ([rows / rows_per_seg, C]: the per-image bias gradient).  -> (dp, dt, seg)."""
+    C = a.shape[-1]
+    R = a.numel() // C
+    dp = torch.empty_like(a)
+    dt = torch.empty_like(a) if want_dt else None
+    seg = ws = None
+    if rows_per_seg is not None:
+        if rows_per_seg % 64 or R % rows_per_seg:
+            raise RuntimeError("ires_bwd_act: rows_per_seg must be a multiple of 64 that divides the row count")
+        seg = torch.empty((R // rows_per_seg, C), dtype=torch.float32, device=a.device)
+        ws = _ws(lib().indm_ires_bwd_act_ws_floats(R, C), a.device)
+    _chk(lib().indm_ires_bwd_act_f32(_ptr(da), _ptr(du), _ptr(d), _ptr(a), _ptr(t), _ptr(dp), _ptr(dt), _ptr(seg), R, C,
+                                     rows_per_seg or 0, _ptr(ws), _stream()), "indm_ires_bwd_act_f32")
+    return dp, dt, seg
 
 
 ACT_SILU, ACT_ELU = 1, 2

@@ -107,13 +107,25 @@ def conv2d_dgrad(dy, w, in_hw, stride=1, pad=1, alpha=1.0, res=None, beta=1.0, g
     return dx.contiguous()
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None):
+def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None, x_gate=None):
     if dy_gate is not None:
         dy = dy * dy_gate
+    if x_gate is not None:
+        x = x * x_gate
     N, H, W, Ci = x.shape
     Co = dy.shape[-1]
     dw = torch.nn.grad.conv2d_weight(_nchw(x), (Co, Ci, kh, kw), _nchw(dy), stride, pad)
     return (alpha * dw.permute(2, 3, 1, 0)).contiguous()
+
+
+def ires_bwd_act(da, du, d, a, t, want_dt=False, rows_per_seg=None):
+    dp = da * d - (2.0 * math.pi) ** 2 * a * (du * t)
+    dt = du * d if want_dt else None
+    seg = None
+    if rows_per_seg is not None:
+        C = a.shape[-1]
+        seg = dp.reshape(-1, rows_per_seg, C).sum(1)
+    return dp, dt, seg
 
 
 def _dropout_mask_unavailable(drop_p):

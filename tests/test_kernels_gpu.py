@@ -637,3 +637,28 @@ def test_gemm_conv_randomised_shapes():
             close(out, ref, rtol=1e-5, atol=1e-4, name=f"dgrad case {case}")
             out, ref = run_both("conv2d_wgrad", x, dy, k, k, stride=s, pad=p)
             close(out, ref, rtol=1e-5, atol=3e-3, name=f"wgrad case {case}")
+
+
+@pytest.mark.parametrize("R,C,rps", [(256, 32, 64), (2048, 512, 1024), (1024, 512, 256), (192, 48, None), (100, 7, None)])
+@pytest.mark.parametrize("want_dt", [False, True])
+def test_ires_bwd_act(R, C, rps, want_dt):
+    """one Sin level of the hand-written iResBlock backward: dp, the chain cotangent dt and the per-image column sums"""
+    ts = [rnd(R, C, seed=i) for i in range(5)]
+    out, ref = run_both("ires_bwd_act", *ts, want_dt=want_dt, rows_per_seg=rps)
+    close(out[0], ref[0], name="ires dp")
+    if want_dt:
+        close(out[1], ref[1], name="ires dt")
+    else:
+        assert out[1] is None
+    if rps:
+        close(out[2], ref[2], rtol=2e-5, atol=2e-5 * math.sqrt(rps), name="ires seg")
+    else:
+        assert out[2] is None
+
+
+@pytest.mark.parametrize("C,Cw", [(3, 512), (12, 512), (3, 32)])
+def test_conv2d_wgrad_x_gate(C, Cw):
+    """weight grad of a conv with a wide x and skinny dy where x carries a gate (the VJP chain's dW3)"""
+    x, g, dy = rnd(4, 16, 16, Cw, seed=1), rnd(4, 16, 16, Cw, seed=2), rnd(4, 16, 16, C, seed=3)
+    out, ref = run_both("conv2d_wgrad", x, dy, 3, 3, x_gate=g)
+    close(out, ref, rtol=2e-5, atol=2e-5 * 32, name="wgrad x_gate")
