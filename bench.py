@@ -5,8 +5,11 @@
 
 A "step" is one call of the reference-API train_step_fn (flow forward + log-det, score loss, backward, one
 flat-gradient all-reduce when N > 1, fused clip+AdamW+EMA for both networks) on configs/vp/CIFAR10/indm_nll
-at batch 128 PER GPU (weak scaling), fp32, dropout 0.1, random-init weights of the full architecture
+at batch 128 PER GPU (weak scaling; `--global-batch G` shards a fixed global batch instead: strong scaling, the
+partitioning of SURVEY 8e / BASELINE configs #3-#5), fp32, dropout 0.1, random-init weights of the full architecture
 (61.8 M + 13.2 M parameters).  Rank 0 prints ONE JSON line; see DESIGN.md "Measurement".
+Extra keys at N = 1: `cpu_baseline` (+ `cpu_baseline_8_threads`), `nelbo`, `sampling` (BASELINE config #5: 1000-step
+predictor-only PC sampling throughput of the deep num_res_blocks = 8 NCSN++ at batch 256, hipGraph-captured step).
 """
 import argparse
 import json
@@ -70,21 +73,23 @@ class _RecordingRng:
         return int(self._rec("poisson", self.base.poisson(lam)))
 
 
-def cpu_baseline_child(path, batch):
+def cpu_baseline_child(path, batch, threads=0):
     """Child process: one full-size oracle training step on the host cores (bounded sample), plus the oracle's NELBO
-    bits/dim of two synthetic images with the noise it drew (the parent replays that noise on the GPU)."""
+    bits/dim of two synthetic images with the noise it drew (the parent replays that noise on the GPU).
+    threads > 0: only the training step, on that many threads (the 8-thread figure comparable with SURVEY App. C)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import indm_oracle as O
     from indm_amd import configs
-    torch.set_num_threads(_usable_cores())
+    torch.set_num_threads(threads if threads > 0 else _usable_cores())
     blob = torch.load(path)
     cfg = configs.get_config("vp/CIFAR10/indm_nll")
     torch.manual_seed(4242)
-    rec = _RecordingRng(O.Rng())
-    xe = synthetic_batch(2, cfg.data.image_size, 4242, "cpu")
-    t0 = time.time()
-    nb, nbr = O.nelbo_fn(blob["score"], blob["flow"], cfg, O.get_sde(cfg), xe, rec)
-    torch.save({"events": rec.events, "bpd": nb, "bpd_residual": nbr, "seconds": time.time() - t0}, path + ".nelbo")
+    if threads <= 0:
+        rec = _RecordingRng(O.Rng())
+        xe = synthetic_batch(2, cfg.data.image_size, 4242, "cpu")
+        t0 = time.time()
+        nb, nbr = O.nelbo_fn(blob["score"], blob["flow"], cfg, O.get_sde(cfg), xe, rec)
+        torch.save({"events": rec.events, "bpd": nb, "bpd_residual": nbr, "seconds": time.time() - t0}, path + ".nelbo")
     st = O.OracleState(blob["score"], cfg.optim.lr, cfg.model.ema_rate, cfg)
     fst = O.OracleState(blob["flow"], cfg.flow.lr, cfg.flow.ema_rate, cfg)
     x = synthetic_batch(batch, cfg.data.image_size, 999, "cpu")
@@ -105,18 +110,24 @@ def cpu_baseline(cfg, score, flow, batch=16, timeout=420):
         torch.save({"score": {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()},
                     "flow": {k: v.cpu() for k, v in flow.reference_state_dict(prefix="").items()}}, path)
         env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", path,
-                                "--batch", str(batch)], capture_output=True, text=True, timeout=timeout, env=env)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-            res = json.loads(line)
-        except Exception as e:  # noqa: BLE001
-            return {"value": None, "unit": "images/s", "cores": _usable_cores(), "kind": "port",
-                    "sample": f"oracle step at batch {batch} did not finish within {timeout}s ({type(e).__name__})"}, None
+
+        def child(threads, limit):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", path,
+                                    "--batch", str(batch), "--cpu-threads", str(threads)], capture_output=True,
+                                   text=True, timeout=limit, env=env)
+                res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            except Exception as e:  # noqa: BLE001
+                return {"value": None, "unit": "images/s", "cores": threads or _usable_cores(), "kind": "port",
+                        "sample": f"oracle step at batch {batch} did not finish within {limit}s ({type(e).__name__})"}
+            return {"value": batch / res["dt"], "unit": "images/s", "cores": res["threads"], "kind": "port",
+                    "sample": f"1 full-size vp/CIFAR10/indm_nll train step at batch {batch} on the CPU oracle "
+                              f"(oracle/indm_oracle.py, torch CPU fp32, {res['threads']} threads): {res['dt']:.1f} s"}
+
+        full = child(0, timeout)
         nelbo = torch.load(path + ".nelbo", weights_only=False) if os.path.exists(path + ".nelbo") else None
-    return {"value": batch / res["dt"], "unit": "images/s", "cores": res["threads"], "kind": "port",
-            "sample": f"1 full-size vp/CIFAR10/indm_nll train step at batch {batch} on the CPU oracle "
-                      f"(oracle/indm_oracle.py, torch CPU fp32, {res['threads']} threads): {res['dt']:.1f} s"}, nelbo
+        eight = child(8, 240) if (full["value"] is not None and _usable_cores() > 8) else None
+    return full, nelbo, eight
 
 
 def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
@@ -152,6 +163,65 @@ def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
     return out
 
 
+def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
+    """BASELINE config #5: predictor-only PC sampling (`sampling.method=pc`, Euler-Maruyama, no corrector) of the deep
+    NCSN++ (`model.num_res_blocks = 8`, random init) at batch 256.  Times `steps` consecutive sampler steps (the first
+    two -- eager warm-up and graph capture -- are excluded), reports the per-step wall time next to the GPU time of
+    the same steps measured with HIP events on the launch stream (they agree when the captured hipGraph keeps the GPU
+    back-to-back busy), and the images/s of a full 1000-step run incl. the flow's fixed-point inverse."""
+    import copy
+    from indm_amd import hip, sampling, sde_lib, utils
+    from indm_amd.rng import DeviceRng
+    cfg = copy.deepcopy(cfg0)
+    cfg.model.num_res_blocks = nrb
+    cfg.sampling.method, cfg.sampling.predictor, cfg.sampling.corrector = "pc", "euler_maruyama", "none"
+    cfg.sampling.batch_size = batch
+    torch.manual_seed(cfg.seed + 5)
+    score = utils.create_model(cfg, dev).eval()
+    flow.eval()
+    sde = sde_lib.get_sde(cfg)
+    st = sampling._Stepper(cfg, sde, score, DeviceRng(dev, seed=77))
+    res = {}
+    with torch.no_grad():
+        x = st.rng.randn_image(batch, 3, cfg.data.image_size, cfg.data.image_size)
+        ts = torch.linspace(sde.T, cfg.sampling.truncation_time, 1000)
+        rows = []
+        for i in range(steps + 2):
+            vt = torch.ones(batch) * ts[i]
+            rows.append(torch.stack([sde.model_labels(vt).float()] + [v.float() for v in st.em_coeffs(vt)]))
+        table = torch.stack(rows).to(dev)
+        for mode in ("graph", "eager"):
+            gp = sampling._GraphedPredictor(st, x, table, use_graph=(mode == "graph"))
+            gp.step(0); gp.step(1)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.time()
+            e0.record()
+            for i in range(2, steps + 2):
+                gp.step(i)
+            e1.record()
+            torch.cuda.synchronize()
+            wall = (time.time() - t0) / steps
+            res[mode] = {"wall_ms_per_step": 1e3 * wall, "gpu_ms_per_step": e0.elapsed_time(e1) / steps}
+        t0 = time.time()
+        from indm_amd.flow import flow_forward
+        flow_forward(cfg, flow, torch.randn(batch, 3, 32, 32, device=dev), log_det=None, reverse=True,
+                     rng=DeviceRng(dev, seed=78))
+        torch.cuda.synchronize()
+        t_inv = time.time() - t0
+    g = res["graph"]
+    flops = 2.0 * 21.693e9 * batch * (nrb / 4.0)   # score forward, App. C (nrb = 4) scaled to the deeper net: lower bound
+    flow.train()
+    del score
+    return {"workload": f"pc_sampler step (EM predictor, no corrector), NCSN++ num_res_blocks={nrb}, batch {batch}, "
+                        f"fp32, {steps} timed steps of a 1000-step schedule",
+            "hipgraph": g, "eager_launches": res["eager"],
+            "sampler_steps_per_s": 1e3 / g["wall_ms_per_step"],
+            "flow_inverse_s": t_inv,
+            "images_per_s_1000_step_sampling": batch / (1000 * g["wall_ms_per_step"] * 1e-3 + t_inv),
+            "nfe_per_image": 1000}
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of `kernel_key` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
     in separate runs of this same command, gfx950 FETCH_SIZE correction applied; profiles/*traffic*.json).  PMC
@@ -173,7 +243,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: a fixed GLOBAL batch sharded evenly over the ranks (SURVEY 8e: 128 -> 16/rank, "
+                         "512 -> 64, 256 -> 32 at 8 GPUs); overrides --batch")
+    ap.add_argument("--no-sampling", action="store_true", help="skip the config-#5 sampling leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = the headline (exact fp32 MFMA); bf16 = MFMA inputs rounded to bf16, fp32 accumulate "
@@ -181,13 +256,18 @@ def main():
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
-        return cpu_baseline_child(args.cpu_baseline_child, args.batch)
+        return cpu_baseline_child(args.cpu_baseline_child, args.batch, args.cpu_threads)
 
     from indm_amd import configs, hip, losses, parallel, sde_lib, utils
     from indm_amd.flow import create_flow_model
     from indm_amd.rng import DeviceRng
 
     rank, world, local = parallel.init_distributed()
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+        args.batch = args.global_batch // world
     # host-side work per step is a few [B]-vector ops: keep every rank's intra-op pool small so N ranks on one host do
     # not oversubscribe its cores
     torch.set_num_threads(max(1, min(8, _usable_cores() // max(world, 1))))
@@ -239,12 +319,17 @@ def main():
                               file=sys.stderr, flush=True)
     barrier()
     hip.profile_start(only=dominant) if dominant else None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.time()
     last = None
+    marks[0].record()
     for i in range(args.steps):
         last = step_fn(state, flow_state, batches[args.warmup + i], rng=rng)
+        marks[i + 1].record()    # GPU-side step boundaries (no host sync): the median step time of SURVEY 8(d)
     barrier()
     elapsed = time.time() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     prof = hip.profile_stop() if dominant else {}
     if dist_on:
         t = torch.tensor([elapsed], device=dev)
@@ -258,7 +343,8 @@ def main():
             "metric": "training images/sec, CIFAR-10 INDM (VP, NLL)",
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "ms_per_step_median": median_ms, "value_at_median_step": args.batch * world / (median_ms * 1e-3),
             "config": {"workload": "configs/vp/CIFAR10/indm_nll.py train step (flow 16-16 idim 512 + NCSN++ nf128), "
                                    f"batch {args.batch}/GPU, 32x32x3, "
                                    + ("fp32" if args.dtype == "f32" else "bf16 MFMA inputs / fp32 accumulate (NOT the "
@@ -280,10 +366,15 @@ def main():
         else:
             out["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], oracle_nelbo = cpu_baseline(cfg, score, flow)
+            out["cpu_baseline"], oracle_nelbo, out["cpu_baseline_8_threads"] = cpu_baseline(cfg, score, flow)
             out["nelbo"] = nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_sampling:
+            try:
+                out["sampling"] = sampling_leg(cfg, flow, dev)
+            except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of an extra leg)
+                out["sampling"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if dist_on:
         torch.distributed.destroy_process_group()

@@ -210,6 +210,10 @@ int indm_slogdet_inv_f32(const float* W, int n, float* logdet, float* inv, void*
 
 /* ---- SDE / loss / sampler / optimiser --------------------------------------------------------------------- */
 
+/* Standard-normal noise on the device (Philox4x32-10 + Box-Muller); replaces the torch.randn / randn_like calls of
+ * losses.py:103, sampling.py:196,209,283 and iresblock.py:137.  `state` points to {seed, offset} (two uint64) in device
+ * memory; the launch advances offset by ceil(n/4), so a captured hipGraph of a sampler step draws fresh noise per replay. */
+int indm_philox_randn_f32(float* out, long n, void* state, void* stream);
 /* out = mc[b]*x + sd[b]*noise: sde.marginal_prob + perturbation, sde_lib.py:153-157,284-287; losses.py:103-105 */
 int indm_sde_perturb_f32(const float* x, const float* noise, const float* mc, const float* sd, float* out, long B,
                          long D, void* stream);

@@ -196,6 +196,50 @@ __global__ __launch_bounds__(64) void slogdet_inv_kernel(const float* __restrict
 }  // namespace
 
 // out[b,:] = mc[b]*x[b,:] + sd[b]*noise[b,:]   (noise / sd may be null -> pure scaling)
+// Standard-normal noise from a counter-based generator (Philox4x32-10 + Box-Muller): out[4i..4i+3] come from counter
+// (offset + i) under key `seed`.  `state` = {seed, offset} lives in DEVICE memory and the offset is advanced by the
+// launch itself (a second, one-thread kernel in stream order), so a captured hipGraph of a sampler step draws fresh
+// noise on every replay.  Replaces torch.randn on the step (the reference draws from the global torch generator:
+// losses.py:103, sampling.py:196,209,283; iresblock.py:137).
+namespace {
+__global__ __launch_bounds__(256) void philox_randn_kernel(float* __restrict__ out, long n,
+                                                           const unsigned long long* __restrict__ state) {
+  const unsigned long long seed = state[0], off = state[1];
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  const long groups = (n + 3) >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
+    const unsigned long long c = off + (unsigned long long)i;
+    const uint4 r = philox4x32(key, make_uint4((uint32_t)c, (uint32_t)(c >> 32), 0x6e646d69u, 0u));
+    const float r0 = sqrtf(-2.f * logf(u32_to_unit(r.x))), r1 = sqrtf(-2.f * logf(u32_to_unit(r.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.28318530717958647692f * u32_to_unit(r.y), &s0, &c0);
+    sincosf(6.28318530717958647692f * u32_to_unit(r.w), &s1, &c1);
+    const float v[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+    const long b = i << 2;
+    if (b + 3 < n) {
+      *(float4*)(out + b) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int k = 0; k < 4 && b + k < n; ++k) out[b + k] = v[k];
+    }
+  }
+}
+__global__ void philox_advance_kernel(unsigned long long* state, unsigned long long by) { state[1] += by; }
+}  // namespace
+
+// out: n floats (16-byte aligned); state: device pointer to {seed, offset} (two uint64), advanced by ceil(n/4).
+INDM_API int indm_philox_randn_f32(float* out, long n, void* state, void* stream) {
+  if (n < 0 || !state) return INDM_E_ARG;
+  if (n == 0) return INDM_OK;
+  if ((uintptr_t)out & 15) return INDM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long groups = (n + 3) >> 2;
+  hipLaunchKernelGGL(philox_randn_kernel, dim3(ew_grid(groups, 256)), dim3(256), 0, st, out, n,
+                     (const unsigned long long*)state);
+  hipLaunchKernelGGL(philox_advance_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)state,
+                     (unsigned long long)groups);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
 INDM_API int indm_sde_perturb_f32(const float* x, const float* noise, const float* mc, const float* sd, float* out,
                                   long B, long D, void* stream) {
   return ew2_launch(B * D, (hipStream_t)stream, [=] __device__(long i) {

@@ -76,6 +76,7 @@ _SIGS = {
     "indm_multi_copy_f32": [c_p, c_i, c_l, c_p],
     "indm_lop_normalize_multi_fwd_f32": [c_p, c_i, c_i, c_l, c_f, c_p],
     "indm_lop_normalize_multi_bwd_f32": [c_p, c_p, c_i, c_i, c_l, c_f, c_p],
+    "indm_philox_randn_f32": [c_p, c_l, c_p, c_p],
     "indm_sde_perturb_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
     "indm_dsm_ws_floats": [c_l, c_l],
     "indm_dsm_loss_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p],
@@ -786,6 +787,20 @@ def lop_normalize_multi_bwd(dwns, ws, l1s, coeff):
 
 
 # --------------------------------------------------------------------------- SDE / loss / sampler / optimiser
+def philox_state(seed, device):
+    """{seed, offset = 0} as an int64[2] device tensor (the generator state of philox_randn)."""
+    return torch.tensor([int(seed) & ((1 << 63) - 1), 0], dtype=torch.int64).to(device)
+
+
+def philox_randn(shape, state):
+    """Standard normals of `shape` drawn on the device from the Philox state tensor (advanced in stream order)."""
+    if not state.is_cuda or state.dtype != torch.int64:
+        raise RuntimeError("philox_randn: state must be an int64[2] tensor on the GPU")
+    out = torch.empty(shape, dtype=torch.float32, device=state.device)
+    _chk(lib().indm_philox_randn_f32(_ptr(out), out.numel(), state.data_ptr(), _stream()), "indm_philox_randn_f32")
+    return out
+
+
 def sde_perturb(x, noise, mc, sd):
     out = torch.empty_like(x)
     B = x.shape[0]

@@ -65,11 +65,24 @@ class DeviceRng:
         self.cpu_gen = torch.Generator().manual_seed((seed + 1) % (1 << 63))
         self.np = np.random.RandomState((seed + 2 if poisson_seed is None else poisson_seed) % (1 << 32))
         self._drop = (seed * 1000003 + 12345) % (1 << 63)
+        # on the GPU the normals come from the library's own Philox kernel (indm_philox_randn_f32): its {seed, offset}
+        # state lives in device memory and advances in stream order, so a captured hipGraph draws fresh noise per replay
+        self.philox = None
+        if self.device.type == "cuda":
+            from . import hip
+            self.philox = hip.philox_state(mix64(seed, 0x5eed), self.device)
 
     def randn_image(self, n, c, h, w):
+        if self.philox is not None:
+            from . import hip
+            return hip.philox_randn((n, h, w, c), self.philox)
         return torch.randn((n, h, w, c), device=self.device, generator=self.gen)
 
     def randn(self, *shape):
+        if self.philox is not None:
+            from . import hip
+            return hip.philox_randn(tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape,
+                                    self.philox)
         return torch.randn(*shape, device=self.device, generator=self.gen)
 
     def rand(self, *shape):

@@ -36,31 +36,23 @@ class _Stepper:
         """raw model output and the factor k[b] with score = k * out"""
         labels = self.sde.model_labels(t)
         out = self.net(x, labels.to(x.device), nhwc=True)
-        if self.ddpm:
-            k = -1.0 / self.sde.marginal_coeffs(t)[1]
-        else:
-            k = torch.ones_like(t)
-        return out, k
+        return out, self.score_factor(t)
 
-    def em(self, x, t):
-        """EulerMaruyamaPredictor.update_fn sampling.py:191-197 with RSDE.sde sde_lib.py:96-103"""
+    def em_coeffs(self, t):
+        """EulerMaruyamaPredictor.update_fn sampling.py:191-197 with RSDE.sde sde_lib.py:96-103 as per-image
+        coefficients of  x' = a x + b net_out + c z  ([B] host vectors)."""
         sde = self.sde
         dt = -1.0 / sde.N
-        out, k = self.net_out(x, t)
         g = sde.diffusion(t)
         if self.vp:
             a = 1.0 + (-0.5 * sde.beta_t(t)) * dt
         else:
             a = torch.ones_like(t)
-        b = -(g ** 2) * k * dt
-        c = g * np.sqrt(-dt)
-        z = self.rng.randn_image(*_nchw(x))
-        return hip.affine_update(x, out, z, _d(a, x), _d(b, x), _d(c, x))
+        return a, -(g ** 2) * self.score_factor(t) * dt, g * np.sqrt(-dt)
 
-    def rd(self, x, t, next_t=None, probability_flow=False):
+    def rd_coeffs(self, t, next_t=None, probability_flow=False):
         """ReverseDiffusionPredictor.update_fn sampling.py:205-210 with RSDE.discretize sde_lib.py:105-118"""
         sde = self.sde
-        out, k = self.net_out(x, t)
         pf = 0.5 if probability_flow else 1.0
         if next_t is None or next_t[0].item() > 0:
             a_f, G = sde.discretize_coeffs(t, next_t)      # f = (a_f - 1) x
@@ -68,8 +60,21 @@ class _Stepper:
         else:
             a = torch.ones_like(t)
             G = sde.diffusion(t) * torch.sqrt(t - next_t)
-        b = (G ** 2) * k * pf
-        c = torch.zeros_like(G) if probability_flow else G
+        return a, (G ** 2) * self.score_factor(t) * pf, (torch.zeros_like(G) if probability_flow else G)
+
+    def score_factor(self, t):
+        """k[b] with score = k * raw network output (models/utils.py:167-177)"""
+        return -1.0 / self.sde.marginal_coeffs(t)[1] if self.ddpm else torch.ones_like(t)
+
+    def em(self, x, t):
+        out, _ = self.net_out(x, t)
+        a, b, c = self.em_coeffs(t)
+        z = self.rng.randn_image(*_nchw(x))
+        return hip.affine_update(x, out, z, _d(a, x), _d(b, x), _d(c, x))
+
+    def rd(self, x, t, next_t=None, probability_flow=False):
+        out, _ = self.net_out(x, t)
+        a, b, c = self.rd_coeffs(t, next_t, probability_flow)
         z = self.rng.randn_image(*_nchw(x))
         return hip.affine_update(x, out, z, _d(a, x), _d(b, x), _d(c, x))
 
@@ -90,6 +95,46 @@ class _Stepper:
             step, ncoef = hip.langevin_step(gsq, nsq, alpha, float(snr))
             x, x_mean = hip.affine_update(x, grad, noise, torch.ones_like(step), step, ncoef)
         return x, x_mean
+
+
+class _GraphedPredictor:
+    """The predictor-only sampler step (score network forward + Philox noise + fused affine update) captured ONCE as a
+    hipGraph and replayed for every step: its launch sequence is static (unlike the training step, whose Poisson
+    series lengths change per block per step).  Everything a step needs from the host -- network labels and the three
+    coefficient vectors -- is precomputed for ALL steps into one device table [steps, 4, B]; a replay is preceded only
+    by a device-to-device copy of that step's row into the graph's static input.  The state x lives in a static
+    buffer the graph updates in place; the noise comes from the device-resident Philox state, which the captured
+    launch advances itself.  The first step runs eagerly (it readies workspaces / kernel attributes), the second is
+    captured, all later ones are replays: the kernels and their order are exactly the eager path's."""
+
+    def __init__(self, st, x, table, use_graph=True):
+        self.st, self.table, self.use_graph = st, table, use_graph
+        self.x = x.clone()
+        self.row = torch.empty_like(table[0])
+        self.graph, self.x_mean, self.steps_done = None, None, 0
+        self._keep = None   # workspace buffers whose addresses the captured launches hold
+
+    def _body(self):
+        out = self.st.net(self.x, self.row[0], nhwc=True)
+        z = self.st.rng.randn_image(*_nchw(self.x))
+        x_new, self.x_mean = hip.affine_update(self.x, out, z, self.row[1], self.row[2], self.row[3])
+        self.x.copy_(x_new)
+
+    def step(self, i):
+        self.row.copy_(self.table[i])
+        if self.steps_done == 0 or not self.use_graph:
+            self._body()
+        elif self.graph is None:
+            torch.cuda.synchronize()
+            self._keep = list(hip._ws_cache.values())
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._body()
+            self.graph.replay()
+        else:
+            self.graph.replay()
+        self.steps_done += 1
+        return self.x, self.x_mean
 
 
 def _nchw(x):
@@ -142,8 +187,9 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
         return ops.to_nhwc(before_data.to(device).float())
 
     def pc_sampler(model, flow_model, temperature=1.0, data_mean=None, final_time=0.0, before_data=None,
-                   sample_dir=None, r=None, rng=None, iters=None):
-        """sampling.py:410-456"""
+                   sample_dir=None, r=None, rng=None, iters=None, graph=None):
+        """sampling.py:410-456.  graph: capture the predictor step as a hipGraph (None = automatically, when the
+        sampler is predictor-only, runs on the GPU and draws its noise from the device-side Philox state)."""
         rng = rng or default_rng(device)
         with torch.no_grad():
             num_scales = config.sampling.num_scales if config.sampling.num_scales != sde.N else sde.N
@@ -151,14 +197,32 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
             timesteps = torch.linspace(sde.T, eps, num_scales)
             st = _Stepper(config, sde, model, rng)
             x_mean = x
+            graphable = (corrector == "none" and predictor in ("euler_maruyama", "reverse_diffusion") and x.is_cuda
+                         and getattr(rng, "philox", None) is not None)
+            if graph is None:
+                graph = graphable and num_scales >= 8
+            elif graph and not graphable:
+                raise RuntimeError("pc_sampler(graph=True) needs a predictor-only sampler on the GPU with a DeviceRng")
+            gp = None
+            if graph:
+                rows = []
+                for i in range(num_scales):
+                    vec_t = torch.ones(B) * timesteps[i]
+                    abc = st.em_coeffs(vec_t) if predictor == "euler_maruyama" else st.rd_coeffs(vec_t, None,
+                                                                                                   probability_flow)
+                    rows.append(torch.stack([sde.model_labels(vec_t).float()] + [v.float() for v in abc]))
+                gp = _GraphedPredictor(st, x, torch.stack(rows).to(x.device))
             for i in range(num_scales):
                 vec_t = torch.ones(B) * timesteps[i]
                 if config.sampling.snr_scheduling == "none":
                     snr_temp = config.sampling.snr
                 else:
                     snr_temp = config.sampling.begin_snr + (config.sampling.end_snr - config.sampling.begin_snr) * i / num_scales
-                x, x_mean = corrector_update(st, x, vec_t, snr_temp)
-                x, x_mean = predictor_update(st, x, vec_t, None)
+                if gp is not None:
+                    x, x_mean = gp.step(i)
+                else:
+                    x, x_mean = corrector_update(st, x, vec_t, snr_temp)
+                    x, x_mean = predictor_update(st, x, vec_t, None)
                 if i == num_scales - 2 and sample_dir is not None:
                     # the start point pc_sampler_search resumes from (sampling.py:436-445; read back by
                     # sampling_lib.get_samples for VE pc_denoise)

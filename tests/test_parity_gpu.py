@@ -95,3 +95,36 @@ def test_bf16_compute_mode_training_step():
     finally:
         hip.set_compute_dtype("f32")
     assert hip.compute_dtype() == "f32"
+
+
+def test_philox_noise_and_graphed_sampler():
+    """(a) indm_philox_randn_f32: N(0,1) moments, device-resident state advancing in stream order, reproducible from the
+    seed; (b) the predictor-only pc_sampler with its step captured as a hipGraph returns bit-identical latents to the
+    eager launch sequence on the same Philox seed (same kernels, same order), and consecutive calls differ."""
+    from indm_amd import hip, sampling, sde_lib, utils
+    from indm_amd.rng import DeviceRng
+    st = hip.philox_state(123, torch.device("cuda"))
+    a = hip.philox_randn((1 << 20,), st)
+    b = hip.philox_randn((1 << 20,), st)
+    assert int(st[1]) == 2 * (1 << 18) and not torch.equal(a, b)
+    for v in (a, b):
+        assert abs(float(v.mean())) < 5e-3 and abs(float(v.var()) - 1.0) < 5e-3
+        assert abs(float((v ** 4).mean()) - 3.0) < 5e-2 and float(v.abs().max()) < 6.5
+    assert abs(float((a * b).mean())) < 5e-3
+    st2 = hip.philox_state(123, torch.device("cuda"))
+    assert torch.equal(hip.philox_randn((1 << 20,), st2), a)
+    odd = hip.philox_randn((3, 5, 7), st2)          # n % 4 != 0 tail
+    assert odd.shape == (3, 5, 7) and torch.isfinite(odd).all()
+
+    d, cfg, score, fl = pc.build("mini_vp_nll", "cuda")
+    cfg.sampling.method, cfg.sampling.num_scales = "pc", 12
+    cfg.sampling.predictor, cfg.sampling.corrector = "euler_maruyama", "none"
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    fn = sampling.get_sampling_fn(cfg, sde, (4, 3, 32, 32), utils.get_data_inverse_scaler(cfg),
+                                  cfg.sampling.truncation_time, device="cuda")
+    eager = fn(score, fl, rng=DeviceRng("cuda", seed=9), graph=False)
+    graphed = fn(score, fl, rng=DeviceRng("cuda", seed=9), graph=True)
+    assert torch.equal(eager[0], graphed[0]) and torch.equal(eager[1], graphed[1]) and eager[2] == graphed[2]
+    other = fn(score, fl, rng=DeviceRng("cuda", seed=10), graph=True)
+    assert not torch.equal(other[0], graphed[0]) and torch.isfinite(other[1]).all()
