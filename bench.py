@@ -373,6 +373,8 @@ def main():
         if world == 1 and not args.no_sampling:
             try:
                 out["sampling"] = sampling_leg(cfg, flow, dev)
+                # the per-rank shard of config #5 on 8 GPUs (256 / 8 images): here the captured graph matters
+                out["sampling"]["per_rank_shard_of_8"] = sampling_leg(cfg, flow, dev, steps=60, batch=32)
             except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of an extra leg)
                 out["sampling"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))

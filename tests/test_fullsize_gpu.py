@@ -119,3 +119,58 @@ def test_full_size_nelbo_within_north_star_tolerance():
     assert rng.done()
     assert (got.cpu() - want).abs().max().item() < 1e-3, (got, want)          # bits/dim
     assert (got_r.cpu() - want_r).abs().max().item() < 1e-3, (got_r, want_r)
+
+
+@pytest.mark.timeout(1500)
+def test_config5_deep_score_net_and_pc_sampler():
+    """BASELINE config #5: configs/vp/CIFAR10/indm_nll.py with model.num_res_blocks = 8 and sampling.method = pc
+    (Euler-Maruyama predictor, no corrector), at FULL size.  (a) structure: 8 residual blocks per resolution,
+    num_res_for_upsampling = 9 (ncsnpp.py:194-198); (b) score network output + input gradient vs the CPU oracle at batch 2;
+    (c) three PC-sampler steps + the flow's fixed-point inverse vs the oracle on the same recorded noise (the eager launch
+    sequence; the hipGraph-captured step is bit-identical to it, tests/test_parity_gpu.py)."""
+    from indm_amd import sampling
+    from indm_amd.ncsnpp import AttnBlockpp, ResnetBlockBigGANpp
+    torch.manual_seed(5)
+    np.random.seed(5)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.model.num_res_blocks = 8
+    cfg.model.dropout = 0.0
+    cfg.sampling.method, cfg.sampling.predictor, cfg.sampling.corrector, cfg.sampling.num_scales = "pc", "euler_maruyama", "none", 3
+    dev = torch.device("cuda")
+    cfg.device = dev
+    score = utils.create_model(cfg, dev)
+    fl = create_flow_model(cfg).to(dev)
+    nrb = sum(isinstance(m, ResnetBlockBigGANpp) for m in score.all_modules)
+    # down path 4 x 8 + 3 aux; middle 2; up path 4 x 9 + 3 aux
+    assert nrb == 4 * 8 + 3 + 2 + 4 * 9 + 3, nrb
+    assert sum(isinstance(m, AttnBlockpp) for m in score.all_modules) == 8 + 1 + 1
+    with torch.no_grad():
+        for n, p in score.named_parameters():
+            if p.dim() > 1 and p.abs().max() < 1e-6:
+                p.copy_(torch.randn_like(p) * 0.02)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    score.eval(); fl.eval()
+    # (b) score function and its input gradient
+    x = (torch.rand(2, 3, 32, 32) * 2 - 1)
+    t = torch.tensor([0.2, 0.85])
+    gy = torch.randn(2, 3, 32, 32)
+    xo = x.clone().requires_grad_(True)
+    so = O.get_score_fn(sd_s, cfg, O.get_sde(cfg), train=False)(xo, t)
+    (gxo,) = torch.autograd.grad(so, xo, gy)
+    xg = x.to(dev).requires_grad_(True)
+    sg = losses.get_score_fn(cfg, sde_lib.get_sde(cfg), score, train=False, continuous=True)(xg, t)
+    (gxg,) = torch.autograd.grad(sg, xg, gy.to(dev))
+    gu.assert_close(sg, so.detach(), 2e-4, 2e-5, "nrb=8 score")
+    gu.assert_close(gxg, gxo, 5e-4, 5e-5, "nrb=8 score input-grad")
+    # (c) PC sampler
+    rec = RecordingRng()
+    want = O.pc_sampler(sd_s, sd_f, cfg, O.get_sde(cfg), (2, 3, 32, 32), rec, cfg.sampling.truncation_time)
+    fn = sampling.get_sampling_fn(cfg, sde_lib.get_sde(cfg), (2, 3, 32, 32), utils.get_data_inverse_scaler(cfg),
+                                  cfg.sampling.truncation_time, device=dev)
+    rng = ReplayRng(rec.events, dev)
+    got = fn(score, fl, rng=rng)
+    assert rng.done() and got[2] == want[2]
+    gu.assert_close(got[0], want[0], 5e-4, 5e-4, "config #5 pc before-flow latents")
+    gu.assert_close(got[1], want[1], 3e-3, 3e-3, "config #5 pc samples")
