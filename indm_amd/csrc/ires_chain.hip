@@ -1,0 +1,228 @@
+// Back-to-back contraction of the residual flow's vector-Jacobian chain (iresblock.py:253-273).
+//
+// One Neumann / power-series iteration multiplies a 3-/12-channel vector through the transposed g-net:
+//     t3 = C3^T v            [M, 512]   (thin transposed 3x3 conv, igemm_thin.hip)
+//     t2 = (t3 .* d2) W2^T   [M, 512]   <- the dominant fp32 MFMA contraction of the step
+//     P  = (t2 .* d1) W1f^T  [M, 9C]    <- HBM-bound thin-N GEMM (9C = 27 / 108), then a 9-tap gather
+// Run as separate launches, t2 (268 MB at batch 128) is written by the second and re-read -- together with its gate
+// d1 -- by the third.  This kernel keeps the 512-wide row of t2 ON CHIP: a workgroup owns 64 rows of M and ALL 512
+// columns of t2, so the second contraction (over those 512 columns) finishes inside the workgroup:
+//   stage 1   acc = W2T^T-major product: D[n][m] = sum_k W2T[k][n] * (t3 .* d2)[m][k]   (fp32 MFMA 32x32x2, operands swapped so that
+//             the accumulator of lane (l31, lhi) holds t2[m = l31][n = 8a + b + 4 lhi], exactly the A-operand layout
+//             of the next MFMA: no LDS transpose between the two GEMMs)
+//   gate      acc *= d1[m][n]            (16-byte loads, 128-byte rows completed across 4 instructions)
+//   stage 2   out[m][j] += sum_n acc[n][m] * W1p[n][j]   per wave over its 64 n's, then an 8-way reduction over
+//             the waves through LDS and a [64, 9C] store.
+// Stage 1 is the direct-to-LDS kernel of igemm.hip (global_load_lds_dwordx4, [row][16 k] images XOR-swizzled on the
+// source address, half-slab skew) on a 64 x 512 block tile: the same 40 KB of operand traffic per 1 MFLOP slab as its
+// 256 x 128 tile (A + gate rows + B rows = 640 either way), A and its gate are read exactly once from HBM, W2T
+// (1 MB) stays in L2.  Saves, per iteration at batch 128: the 268 MB write, the 536 MB gated re-read and one launch.
+#include "indm_common.h"
+
+namespace {
+
+constexpr int BK = 16, TM = 64, TN = 512, NW = 8;
+constexpr int A_SZ = TM * BK, G_SZ = TM * BK, B_SZ = BK * TN, BUF = A_SZ + G_SZ + B_SZ;  // floats per LDS buffer
+
+struct ChainArgs {
+  const float* A;    // t3  [M, K]
+  const float* G;    // d2  [M, K]
+  const float* B;    // W2T [K, 512] row-major
+  const float* D1;   // d1  [M, 512]
+  const float* W1p;  // [512, 32*JB] row-major, zero-padded beyond J
+  float* P;          // [M, J]
+  int M, K, J;
+};
+
+template <int JB>
+__global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * TM;
+  const int nk = p.K / BK;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int swz = (l31 >> 2) & 3;
+  const int nw = wave * 64;
+
+  f32x16 acc[2][2];  // [n-block][m-block]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto dma = [&](const float* src, float* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+  };
+  // per-lane running source pointers: waves 0-3 stage 16 rows of A each, waves 4-7 the same rows of the gate;
+  // every wave stages two k-rows of B (2 KB each = two wave-instructions)
+  const int arow = (wave & 3) * 16 + (lane >> 2);
+  const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
+  const float* pa = (wave < 4 ? p.A : p.G) + (long)(m0 + arow) * p.K + 4 * achunk;
+  const int a_dst = (wave < 4 ? 0 : A_SZ) + (wave & 3) * 16 * BK;
+  const float* pb = p.B + (long)(wave * 2) * TN + 4 * lane;
+  auto stage = [&](int buf) {
+    float* base = smem + buf * BUF;
+    dma(pa, base + a_dst);
+    pa += BK;
+    float* bb = base + A_SZ + G_SZ + wave * 2 * TN;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma(pb + q * 256, bb + q * 256);  // k-row 2w: [0,256) [256,512); k-row 2w+1: ...
+    pb += (long)BK * TN;
+  };
+
+  auto frags = [&](int buf, int sg, float4 (&fm)[2], float4 (&fn)[2]) {
+    const float* as = smem + buf * BUF;
+    const float* bs = as + A_SZ + G_SZ;
+    const int ch = ((sg * 2 + lhi) ^ swz) << 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // m side: (t3 .* d2)[m = 32j + l31][k = 8sg + 4lhi + t]
+      const int o = (j * 32 + l31) * BK + ch;
+      const f32x4 av = *(const f32x4*)(as + o), gv = *(const f32x4*)(as + A_SZ + o);
+      const f32x4 u = av * gv;
+      fm[j] = make_float4(u.x, u.y, u.z, u.w);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // n side: W2T[k][n = nw + 32i + l31]
+      const float* q = bs + (sg * 8 + lhi * 4) * TN + nw + i * 32 + l31;
+      fn[i] = make_float4(q[0], q[TN], q[2 * TN], q[3 * TN]);
+    }
+  };
+  auto mfmas = [&](const float4 (&fm)[2], const float4 (&fn)[2]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float a = t == 0 ? fn[i].x : t == 1 ? fn[i].y : t == 2 ? fn[i].z : fn[i].w;
+          const float b = t == 0 ? fm[j].x : t == 1 ? fm[j].y : t == 2 ? fm[j].z : fm[j].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);  // D[n][m]
+        }
+  };
+
+  float4 fm0[2], fn0[2], fm1[2], fn1[2];
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nk > 1) stage(1);
+  frags(0, 0, fm0, fn0);
+  frags(0, 1, fm1, fn1);
+  mfmas(fm0, fn0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = 1; s < nk; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nk) stage(buf ^ 1);
+    frags(buf, 0, fm0, fn0);
+    mfmas(fm1, fn1);
+    frags(buf, 1, fm1, fn1);
+    mfmas(fm0, fn0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  mfmas(fm1, fn1);
+
+  // ---- gate: acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi]  *=  d1[m][n] ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float* drow = p.D1 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 g[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) g[a] = *(const float4*)(drow + i * 32 + 8 * a);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[i][j][4 * a + 0] *= g[a].x;
+        acc[i][j][4 * a + 1] *= g[a].y;
+        acc[i][j][4 * a + 2] *= g[a].z;
+        acc[i][j][4 * a + 3] *= g[a].w;
+      }
+    }
+  }
+
+  // ---- stage 2: out[m][j] = sum over this wave's 64 n's of u1[m][n] * W1p[n][j]; 8-way reduce through LDS ----
+  const int JP = 32 * JB;
+  float* red = smem;  // [8 waves][64 m][32 j] = 64 KB (the operand buffers are dead)
+#pragma unroll 1
+  for (int jb = 0; jb < JB; ++jb) {
+    f32x16 out[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float w[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        w[r] = p.W1p[(long)(nw + i * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi) * JP + jb * 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          out[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[i][j][r], w[r], out[j], 0, 0, 0);  // D'[m][j]
+    }
+    if (jb > 0) __syncthreads();  // the previous round's reduction has read `red`
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = j * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi;
+        red[(wave * 64 + m) * 32 + l31] = out[j][r];
+      }
+    __syncthreads();
+    // 64 x 32 outputs, 4 per thread: thread -> (m = tid / 8, j = (tid % 8) * 4 .. +3)
+    {
+      const int m = tid >> 3, j0 = (tid & 7) * 4;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) {
+        const float4 v = *(const float4*)(red + (wv * 64 + m) * 32 + j0);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* dst = p.P + (long)(m0 + m) * p.J + jb * 32 + j0;
+      const int left = p.J - (jb * 32 + j0);
+      if (left > 0) dst[0] = s.x;
+      if (left > 1) dst[1] = s.y;
+      if (left > 2) dst[2] = s.z;
+      if (left > 3) dst[3] = s.w;
+    }
+  }
+}
+
+template <int JB>
+int launch_chain(const ChainArgs& p, hipStream_t st) {
+  constexpr size_t bytes = 2 * BUF * sizeof(float);
+  static bool ready = false;
+  if (!ready) {
+    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+        hipSuccess)
+      return INDM_E_LAUNCH;
+    ready = true;
+  }
+  hipLaunchKernelGGL(ires_chain_kernel<JB>, dim3(p.M / TM), dim3(NW * 64), bytes, st, p);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
+}  // namespace
+
+// P[M, J] = ((A .* G) W2T .* D1) W1p[:, :J]   with A, G: [M, K]; W2T: [K, 512]; D1: [M, 512]; W1p: [512, 32 if J <= 32 else 128]
+// (zero-padded columns).  Requirements: M % 64 == 0, K % 16 == 0, K >= 32, J <= 128, 16-byte aligned pointers.
+// Returns 1 when the geometry is not covered (the caller then runs the two contractions separately).
+INDM_API int indm_ires_chain_f32(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
+                                 float* P, int M, int K, int N, int J, void* stream) {
+  if (M < 0 || K <= 0 || N <= 0 || J <= 0) return INDM_E_SHAPE;
+  if (M == 0) return INDM_OK;
+  if (N != TN || (M % TM) || (K % BK) || K < 2 * BK || J > 128) return 1;
+  if (((uintptr_t)A | (uintptr_t)G | (uintptr_t)W2T | (uintptr_t)D1 | (uintptr_t)W1p) & 15) return 1;
+  ChainArgs p = {A, G, W2T, D1, W1p, P, M, K, J};
+  hipStream_t st = (hipStream_t)stream;
+  // two instantiations: J <= 32 (the 3-channel scale: 27) and J <= 128 (the 12- / 48-channel scales: 108); W1p is
+  // padded to 32 / 128 columns accordingly
+  return J <= 32 ? launch_chain<1>(p, st) : launch_chain<4>(p, st);
+}

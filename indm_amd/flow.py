@@ -130,21 +130,28 @@ class IResBlock(nn.Module):
         return t
 
     def vjp_acc(self, v, W, gates, hw, acc, coeff):
-        """One series iteration without a graph: (v^T dg/dx, acc + coeff * v^T dg/dx).  Same contractions as vjp(); the
-        skinny tail (9-tap gather, input gate, accumulation into the Neumann sum) is ONE launch instead of three."""
-        W1, W2, W3, W2T = (w if w.is_contiguous() else w.contiguous() for w in W)
+        """One series iteration without a graph: (v^T dg/dx, acc + coeff * v^T dg/dx); acc may be None.  Same
+        contractions as vjp().  On the skinny (3-/12-channel) production shapes the two wide links
+        ((t3 .* d2) W2^T .* d1) W1^T run as ONE back-to-back launch that keeps the 512-wide intermediate on chip
+        (indm_ires_chain_f32; W[4] = W1 as a zero-padded [512, 32|128] panel from prepare()), and the skinny tail
+        (9-tap gather, input gate, accumulation into the Neumann sum) is one launch instead of three."""
+        W1, W2, W3, W2T = (w if w.is_contiguous() else w.contiguous() for w in W[:4])
         d0, d1, d2 = gates
         N, H, Wd, _ = v.shape
         t = hip.conv2d_dgrad(v, W3, hw)
         C = t.shape[-1]
-        t = hip.gemm(t.view(-1, C), W2T, gate=d2.view(-1, C))
         Ci = W1.shape[2]
         if not hip._skinny(3, 3, 1, 1, Ci, W1.shape[3]):
+            t = hip.gemm(t.view(-1, C), W2T, gate=d2.view(-1, C))
             t = hip.conv2d_dgrad(t.view(N, H, Wd, -1), W1, hw, gate=d1)
             if d0 is not None:
                 t = hip.mul(t, d0)
-            return t, hip.axpby(acc, t, 1.0, coeff)
-        P = hip.gemm(t, W1.reshape(9 * Ci, W1.shape[3]), trans_b=True, gate=d1.view(-1, d1.shape[-1]))
+            return t, (hip.axpby(acc, t, 1.0, coeff) if acc is not None else None)
+        P = hip.ires_chain(t.view(-1, C), d2.view(-1, C), W2T, d1.view(-1, d1.shape[-1]), W[4], 9 * Ci) \
+            if len(W) > 4 and W[4] is not None else None
+        if P is None:
+            t = hip.gemm(t.view(-1, C), W2T, gate=d2.view(-1, C))
+            P = hip.gemm(t, W1.reshape(9 * Ci, W1.shape[3]), trans_b=True, gate=d1.view(-1, d1.shape[-1]))
         return hip.tap_gather_acc(P.view(N, H, Wd, 9 * Ci), -1, d0, acc, coeff)
 
     def forward_logdet(self, x, cb, W, rng, stats):
@@ -164,7 +171,7 @@ class IResBlock(nn.Module):
         if training:  # neumann_logdet_estimator :264-273 -- forward AND backward hand-written (_IResTrain)
             c1, c2, c3 = self.convs
             y, logdet = _IResTrain.apply(x, cb, W[0], W[1], W[2], W[3], c1.bias, c2.bias, c3.bias, eps, self,
-                                         [(-1) ** k * coeff(k) for k in range(1, K + 1)])
+                                         [(-1) ** k * coeff(k) for k in range(1, K + 1)], W[4] if len(W) > 4 else None)
             if stats is not None:
                 stats.append((self, n, logdet.detach()))
             return y, logdet
@@ -173,7 +180,7 @@ class IResBlock(nn.Module):
             vjp = eps
             logdet = None
             for k in range(1, K + 1):
-                vjp = self.vjp(vjp, W, gates, hw)
+                vjp, _ = self.vjp_acc(vjp, W, gates, hw, None, 0.0)
                 tr = hip.rowreduce(vjp, eps, 0, (-1) ** (k + 1) / k * coeff(k))
                 logdet = tr if logdet is None else logdet + tr
         return ops.axpby(x, g), logdet
@@ -211,7 +218,7 @@ class _IResTrain(torch.autograd.Function):
     parity_cases.case_flow_forward_modes / case_two_training_steps)."""
 
     @staticmethod
-    def forward(ctx, x, cb, W1, W2, W3, W2T, b1, b2, b3, eps, blk, coeffs):
+    def forward(ctx, x, cb, W1, W2, W3, W2T, b1, b2, b3, eps, blk, coeffs, panel=None):
         x, cb, W1, W2, W3, W2T, eps = (t if t.is_contiguous() else t.contiguous() for t in (x, cb, W1, W2, W3, W2T, eps))
         N, H, Wd, C = x.shape
         hw = (H, Wd)
@@ -225,7 +232,7 @@ class _IResTrain(torch.autograd.Function):
         del p2
         g = hip.conv2d(a2, W3, bias=b3)
         y = hip.axpby(x, g, 1.0, 1.0)
-        Ws, gates = (W1, W2, W3, W2T), (d0, d1, d2)
+        Ws, gates = (W1, W2, W3, W2T, panel), (d0, d1, d2)
         v, w = eps, eps
         for c in coeffs:                                   # v_k = J^T v_{k-1};  w = eps + sum (-1)^k c_k v_k
             v, w = blk.vjp_acc(v, Ws, gates, hw, w, c)
@@ -294,7 +301,7 @@ class _IResTrain(torch.autograd.Function):
             dx = hip.axpby(gy, hip.sincos_bwd(da0, dd0, a0, d0), 1.0, 1.0)
         else:
             dx = hip.axpby(gy, da0, 1.0, 1.0)
-        return dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3, None, None, None
+        return dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3, None, None, None, None
 
 
 class SqueezeLayer(nn.Module):
@@ -346,7 +353,21 @@ class ResidualFlow(nn.Module):
         cb = ops.gemm(c, w2)                                                           # [NB, B, idim]
         cbs = cb.unbind(0)  # backward = one stack
         w2ts = w2.transpose(1, 2).contiguous().unbind(0)   # W2^T of every block, one launch (used by the VJP chains)
-        return {b: (list(W) + [w2ts[i]], cbs[i]) for i, (b, W) in enumerate(zip(blks, Ws))}
+        # W1 of every block as the [idim, 32 | 128] zero-padded panel of the back-to-back chain kernel (no-grad series
+        # iterations only): one stack + transpose + pad per scale
+        panels = {}
+        with torch.no_grad():
+            for sc in self.blocks():
+                if not sc:
+                    continue
+                w1 = torch.stack([Ws[blks.index(b)][0].detach() for b in sc], dim=0)        # [nb, 3, 3, C, idim]
+                nb_, _, _, C_, I_ = w1.shape
+                if hip._skinny(3, 3, 1, 1, C_, I_) and 9 * C_ <= 128:
+                    pn = torch.nn.functional.pad(w1.reshape(nb_, 9 * C_, I_).transpose(1, 2),
+                                                 (0, (32 if 9 * C_ <= 32 else 128) - 9 * C_)).contiguous()
+                    for b, q in zip(sc, pn.unbind(0)):
+                        panels[b] = q
+        return {b: (list(W) + [w2ts[i], panels.get(b)], cbs[i]) for i, (b, W) in enumerate(zip(blks, Ws))}
 
     def fwdpass(self, x, h, eval_logdet, rng, stats=None):
         """:310-324 -- returns (z, logpx) with logpx = -sum logdet (as the reference)."""

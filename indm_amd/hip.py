@@ -56,6 +56,7 @@ _SIGS = {
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "indm_ires_chain_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_ires_bwd_act_ws_floats": [c_l, c_i],
     "indm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p],
     "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
@@ -200,6 +201,7 @@ class _timed:
         # algorithmic bytes: every operand read once, the result written once (conv callers pass the image size)
         self.bytes = float(nbytes) if nbytes is not None else 4.0 * batch * (M * K + K * N + M * N)
         self.on = _Profile.enabled
+        self.variant = None
 
     def __enter__(self):
         if self.on:
@@ -211,7 +213,7 @@ class _timed:
     def __exit__(self, *a):
         if self.on:
             self.e1.record()
-            key = f"igemm<{self.amode},{self.bmode},{lib().indm_igemm_last_variant().decode()}>"
+            key = f"igemm<{self.amode},{self.bmode},{self.variant or lib().indm_igemm_last_variant().decode()}>"
             if _Profile.shapes:  # INDM_PROFILE_SHAPES=1: one class per problem shape (tools / bench stderr table only)
                 key += " M=%d N=%d K=%d b=%d" % self.shape
             if _Profile.only is None or _Profile.only == key:
@@ -578,6 +580,25 @@ def sincos_bwd(da, dd, a, d):
     _chk(lib().indm_sincos_act_bwd_f32(_ptr(da), _ptr(dd), _ptr(a), _ptr(d), _ptr(dp), a.numel(), _stream()),
          "indm_sincos_act_bwd_f32")
     return dp
+
+
+def ires_chain(t3, d2, w2t, d1, w1p, J):
+    """P[M, J] = ((t3 .* d2) @ w2t .* d1) @ w1p[:, :J] in ONE launch with the 512-wide intermediate kept on chip (the
+    back-to-back contraction of the VJP chain).  t3, d2: [M, K]; w2t: [K, 512]; d1: [M, 512]; w1p: [512, 32 if J <= 32 else 128] (zero-padded).
+    Returns None when the kernel does not cover the geometry (or in bf16 mode): the caller runs the two GEMMs."""
+    if _MFMA["dtype"] != "f32":
+        return None
+    M, K = t3.shape
+    N = w2t.shape[1]
+    P = torch.empty((M, J), dtype=torch.float32, device=t3.device)
+    with _timed("A_ROW", "B_ROW", M, N, K, nbytes=4 * (2 * t3.numel() + d1.numel() + w2t.numel() + P.numel())) as tm:
+        st = lib().indm_ires_chain_f32(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), M, K, N, J, _stream())
+        tm.variant = "ires_chain64x512,gated"
+        tm.flops += 2.0 * M * N * w1p.shape[1]
+    if st == 1:
+        return None
+    _chk(st, "indm_ires_chain_f32")
+    return P
 
 
 def ires_bwd_act(da, du, d, a, t, want_dt=False, rows_per_seg=None):

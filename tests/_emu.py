@@ -118,6 +118,10 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None, x_gate
     return (alpha * dw.permute(2, 3, 1, 0)).contiguous()
 
 
+def ires_chain(t3, d2, w2t, d1, w1p, J):
+    return ((((t3 * d2) @ w2t) * d1) @ w1p[:, :J]).contiguous()
+
+
 def ires_bwd_act(da, du, d, a, t, want_dt=False, rows_per_seg=None):
     dp = da * d - (2.0 * math.pi) ** 2 * a * (du * t)
     dt = du * d if want_dt else None

@@ -662,3 +662,19 @@ def test_conv2d_wgrad_x_gate(C, Cw):
     x, g, dy = rnd(4, 16, 16, Cw, seed=1), rnd(4, 16, 16, Cw, seed=2), rnd(4, 16, 16, C, seed=3)
     out, ref = run_both("conv2d_wgrad", x, dy, 3, 3, x_gate=g)
     close(out, ref, rtol=2e-5, atol=2e-5 * 32, name="wgrad x_gate")
+
+
+@pytest.mark.parametrize("M,K,J", [(64, 512, 27), (256, 512, 27), (128, 512, 108), (192, 32, 27), (8192, 512, 108)])
+def test_ires_chain_back_to_back(M, K, J):
+    """((t3 .* d2) W2T .* d1) W1p in one launch (the 512-wide intermediate never leaves the chip) vs fp64"""
+    JP = 32 if J <= 32 else 128
+    t3, d2, d1 = rnd(M, K, seed=1), rnd(M, K, seed=2), rnd(M, 512, seed=3)
+    w2t = rnd(K, 512, seed=4, scale=K ** -0.5)
+    w1p = torch.zeros(512, JP)
+    w1p[:, :J] = rnd(512, J, seed=5, scale=512 ** -0.5)
+    out, ref = run_both("ires_chain", t3, d2, w2t, d1, w1p, J)
+    assert out is not None and out.shape == (M, J)
+    close(out, ref, rtol=2e-5, atol=2e-5, name="ires_chain")
+    # geometry the kernel does not cover -> None (the caller falls back to two GEMMs)
+    assert hip.ires_chain(t3[:M - 1].contiguous().to(DEV), d2[:M - 1].contiguous().to(DEV), w2t.to(DEV),
+                          d1[:M - 1].contiguous().to(DEV), w1p.to(DEV), J) is None

@@ -1,0 +1,52 @@
+"""Two-rank data-parallel training step over RCCL (backend "nccl" on ROCm), one process per GPU.  Self-skips on
+a single-GPU box (the driver's scaling node has 8); the same logic runs on CPU with gloo in tests/test_parallel_cpu.py."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rank_main(rank, world, port, out_path, fx):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import golden_utils as gu
+    import parity_cases as pc
+    from indm_amd import losses, parallel, sde_lib, utils
+    from indm_amd.rng import ReplayRng
+    parallel.init_distributed()
+    dev = torch.device("cuda", rank)
+    d, cfg, score, fl = pc.build(fx, dev)
+    state, fstate, flat_g = utils.build_states(cfg, score, fl, dev)
+    reducer = parallel.make_allreduce(flat_g, world)
+    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True, world_size=world, allreduce=reducer)
+    score.train(); fl.train()
+    ev = [(k, v if k == "poisson" else v[rank:rank + 1]) for k, v in gu.events(d, "step0")]
+    xb = parallel.shard_batch(torch.from_numpy(d["step0/x"]), rank, world).to(dev)
+    out = step_fn(state, fstate, xb, rng=ReplayRng(ev, dev))
+    torch.cuda.synchronize()
+    torch.save({"loss": out[0], "p": state["optimizer"].flat.p.cpu(), "pf": fstate["optimizer"].flat.p.cpu(),
+                "calls": list(reducer.calls), "sizes": (state["optimizer"].flat.g.numel(), fstate["optimizer"].flat.g.numel())},
+               out_path.format(rank=rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("fx", ["mini_vp_nll", "mini_vp_fid"])
+def test_two_rank_rccl_step(fx, tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL over xGMI); single-GPU box")
+    port = 29500 + os.getpid() % 1000
+    path = str(tmp_path / "r{rank}.pt")
+    mp.spawn(_rank_main, args=(2, port, path, fx), nprocs=2, join=True)
+    a, b = torch.load(path.format(rank=0)), torch.load(path.format(rank=1))
+    assert torch.equal(a["p"], b["p"]) and torch.equal(a["pf"], b["pf"])      # replicas in lock-step
+    ns, nf = a["sizes"]
+    assert a["calls"] == ([ns, nf] if fx == "mini_vp_nll" else [nf, ns]), a["calls"]
+    assert torch.isfinite(a["loss"]).all() and torch.isfinite(b["loss"]).all()
