@@ -110,9 +110,9 @@ def get_elbo_fn(config, sde, inverse_scaler=None, hutchinson_type="Rademacher"):
     return loss_fn
 
 
-def get_div_fn(stepper, sde):
+def get_div_fn(stepper, sde, on_device=False):
     """drift of the probability-flow ODE and its Hutchinson divergence at (x, t) in one pass
-    (likelihood.py:27-38, 62-71)."""
+    (likelihood.py:27-38, 62-71).  on_device: the [B] divergence stays in HBM (the on-device RK45 of ode.py)."""
 
     def drift_div(x, t, epsilon):
         xg = x.detach().requires_grad_(True)
@@ -123,6 +123,8 @@ def get_div_fn(stepper, sde):
             b = -(g ** 2) * k * 0.5
             (vjp,) = torch.autograd.grad(out, xg, ops.scale_rows(epsilon, _d(b, xg)).detach())
         drift = hip.affine_update(x, out.detach(), None, _d(a, x), _d(b, x), _d(b, x), want_mean=False)[0]
+        if on_device:
+            return drift, hip.rowreduce(vjp.contiguous(), epsilon, 0) + _d(a, x) * hip.rowreduce(epsilon, None, 1)
         div = hip.rowreduce(vjp.contiguous(), epsilon, 0).cpu() + a * hip.rowreduce(epsilon, None, 1).cpu()
         return drift, div
 
@@ -131,8 +133,10 @@ def get_div_fn(stepper, sde):
 
 def get_likelihood_fn(config, sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e-5, atol=1e-5,
                       method="RK45"):
-    """likelihood.py:41-140 (SciPy RK45 over a float64 host state; one device RHS per function evaluation)."""
-    from scipy import integrate
+    """likelihood.py:41-140.  method='RK45' (the reference's only choice) runs the adaptive Dormand-Prince integrator of
+    ode.py with its float64 state resident in HBM: no state copy per function evaluation, one scalar to the host per
+    step attempt.  Any other method name goes to scipy.integrate.solve_ivp over a host state, as in the reference."""
+    from . import ode
 
     def likelihood_fn(model, flow_model, data, logdet=None, residual=True, eps_bpd=1e-5, rng=None, stats=None):
         rng = rng or default_rng(data.device)
@@ -153,23 +157,39 @@ def get_likelihood_fn(config, sde, inverse_scaler, hutchinson_type="Rademacher",
                 z_nchw, log_jacob = data, torch.zeros(B)
             zb = ops.to_nhwc(z_nchw)
 
-            def ode_func(t, x):
-                sample = ops.to_nhwc(torch.from_numpy(x[:-B].reshape(shape)).float().to(dev))
-                drift, div = drift_div(sample, torch.ones(B) * t, epsilon)
-                return np.concatenate([ops.to_nchw(drift).cpu().numpy().reshape(-1).astype(np.float64),
-                                       div.numpy().reshape(-1).astype(np.float64)], axis=0)
-
             if residual:
                 noise = rng.randn_image(*shape)
                 start, _, _ = _perturb(sde, zb, torch.ones(B) * eps_bpd, noise)
             else:
                 start = zb
-            init = np.concatenate([ops.to_nchw(start).cpu().numpy().reshape(-1), np.zeros((B,))], axis=0)
-            sol = integrate.solve_ivp(ode_func, (eps_bpd, sde.T), init, rtol=rtol, atol=atol, method=method)
-            nfe = sol.nfev
-            zp = sol.y[:, -1]
-            z = torch.from_numpy(zp[:-B].reshape(shape)).float()
-            delta_logp = torch.from_numpy(zp[-B:]).float()
+            if method == "RK45":
+                # state = [x (NHWC, the layout the kernels use; the solver's norms are permutation-invariant), logp]
+                dd = get_div_fn(st, sde, on_device=True)
+                nx = start.numel()
+
+                def ode_dev(t, y):
+                    drift, div = dd(y[:nx].view(start.shape).float(), torch.ones(B) * t, epsilon)
+                    return torch.cat([drift.reshape(-1).double(), div.double()])
+
+                init = torch.cat([start.reshape(-1).double(), torch.zeros(B, dtype=torch.float64, device=dev)])
+                yT, nfe = ode.rk45_solve(ode_dev, eps_bpd, sde.T, init, rtol=rtol, atol=atol)
+                z = ops.to_nchw(yT[:nx].view(start.shape).float()).cpu()
+                delta_logp = yT[nx:].float().cpu()
+            else:
+                from scipy import integrate
+
+                def ode_func(t, x):
+                    sample = ops.to_nhwc(torch.from_numpy(x[:-B].reshape(shape)).float().to(dev))
+                    drift, div = drift_div(sample, torch.ones(B) * t, epsilon)
+                    return np.concatenate([ops.to_nchw(drift).cpu().numpy().reshape(-1).astype(np.float64),
+                                           div.numpy().reshape(-1).astype(np.float64)], axis=0)
+
+                init = np.concatenate([ops.to_nchw(start).cpu().numpy().reshape(-1), np.zeros((B,))], axis=0)
+                sol = integrate.solve_ivp(ode_func, (eps_bpd, sde.T), init, rtol=rtol, atol=atol, method=method)
+                nfe = sol.nfev
+                zp = sol.y[:, -1]
+                z = torch.from_numpy(zp[:-B].reshape(shape)).float()
+                delta_logp = torch.from_numpy(zp[-B:]).float()
             prior = sde.prior_logp(z)
             if residual:
                 residual_fn = get_likelihood_residual_fn(config, sde, st, eps_bpd=eps_bpd)

@@ -312,9 +312,16 @@ def get_ode_sampler(config, sde, shape, inverse_scaler, denoise=False, rtol=1e-5
                 d = drift(ops.to_nhwc(xd), torch.ones(B) * t)
                 return ops.to_nchw(d).cpu().numpy().reshape(-1).astype(np.float64)
 
-            sol = integrate.solve_ivp(ode_func, (sde.T, eps), ops.to_nchw(x).cpu().numpy().reshape(-1),
-                                      rtol=rtol, atol=atol, method=method)
-            x = ops.to_nhwc(torch.tensor(sol.y[:, -1]).reshape(shape).float().to(device))
+            if method == "RK45":   # on-device Dormand-Prince (ode.py): float64 state in HBM, one scalar per step to the host
+                from . import ode
+                yT, nfev = ode.rk45_solve(lambda t, y: drift(y.view(x.shape).float(), torch.ones(B) * t).reshape(-1).double(),
+                                          sde.T, eps, x.reshape(-1).double(), rtol=rtol, atol=atol)
+                x = yT.view(x.shape).float()
+            else:
+                sol = integrate.solve_ivp(ode_func, (sde.T, eps), ops.to_nchw(x).cpu().numpy().reshape(-1),
+                                          rtol=rtol, atol=atol, method=method)
+                nfev = sol.nfev
+                x = ops.to_nhwc(torch.tensor(sol.y[:, -1]).reshape(shape).float().to(device))
             if denoise:  # denoise_update_fn :568-574
                 vec_eps = torch.ones(B) * eps
                 _, x = st.rd(x, vec_eps, torch.zeros_like(vec_eps), probability_flow=False)
@@ -324,7 +331,7 @@ def get_ode_sampler(config, sde, shape, inverse_scaler, denoise=False, rtol=1e-5
                                         log_det=None, reverse=True, rng=rng, iters=iters)
             else:
                 after = before
-            return inverse_scaler(before), inverse_scaler(after), sol.nfev
+            return inverse_scaler(before), inverse_scaler(after), nfev
 
     return ode_sampler
 
