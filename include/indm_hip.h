@@ -156,6 +156,13 @@ int indm_sincos_act_bwd_f32(const float* da, const float* dd, const float* a, co
  * backward): with u = t .* d a link of the explicit VJP chain and a = Sin(p) the activation of g,
  *   dp = da*d - 4 pi^2 * a * (du*t);  dt_out = du*d (optional);  seg_out[s][c] = per-segment column sums of dp (optional:
  * the per-image conditioning-bias gradient; rows_per_seg % 64 == 0).  All tensors [R, C]; ws: indm_ires_bwd_act_ws_floats. */
+/* Fused single-head attention of AttnBlockpp (models/layerspp.py:88-104): h = softmax(q k^T * scale) v with the
+ * [T, T] logits kept in registers (q, k, v, h: [B, T, C]; lse: [B, T] log-sum-exp per query, saved for the backward).
+ * bwd: Dv[B, T] = <dh[q], h[q]>.  Return 1 = geometry not covered (T not in {64,128,256} or C % 128): unfused path. */
+int indm_attn_fwd_f32(const float* q, const float* k, const float* v, float* h, float* lse, int B, int T, int C,
+                      float scale, void* stream);
+int indm_attn_bwd_f32(const float* q, const float* k, const float* v, const float* dh, const float* lse,
+                      const float* Dv, float* dq, float* dk, float* dv, int B, int T, int C, float scale, void* stream);
 /* Back-to-back contraction of one link pair of the VJP chain: P[M, J] = ((A .* G) W2T .* D1) W1p[:, :J] with the
  * 512-wide intermediate kept on chip (A, G: [M, K]; W2T: [K, 512] row-major; D1: [M, 512]; W1p: [512, 32 if J <= 32 else 128]
  * zero-padded; J = 9*C <= 128).  Returns 1 if the geometry is not covered (M % 64, K % 16, N != 512): the caller then

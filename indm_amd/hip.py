@@ -56,6 +56,8 @@ _SIGS = {
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "indm_attn_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "indm_attn_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "indm_ires_chain_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_ires_bwd_act_ws_floats": [c_l, c_i],
     "indm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p],
@@ -580,6 +582,35 @@ def sincos_bwd(da, dd, a, d):
     _chk(lib().indm_sincos_act_bwd_f32(_ptr(da), _ptr(dd), _ptr(a), _ptr(d), _ptr(dp), a.numel(), _stream()),
          "indm_sincos_act_bwd_f32")
     return dp
+
+
+def attn_fwd(q, k, v, scale):
+    """Fused attention forward: (h, lse) or None when the kernel does not cover the geometry (or in bf16 mode)."""
+    if _MFMA["dtype"] != "f32":
+        return None
+    B, T, C = q.shape
+    h = torch.empty_like(q)
+    lse = torch.empty((B, T), dtype=torch.float32, device=q.device)
+    with _timed("ATTN", "FWD", T, C, T, B) as tm:
+        st = lib().indm_attn_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(h), _ptr(lse), B, T, C, scale, _stream())
+        tm.variant, tm.flops = "attn_fused", 4.0 * B * T * T * C
+    if st == 1:
+        return None
+    _chk(st, "indm_attn_fwd_f32")
+    return h, lse
+
+
+def attn_bwd(q, k, v, h, dh, lse, scale):
+    """Fused attention backward -> (dq, dk, dv); logits / probabilities are recomputed in registers."""
+    B, T, C = q.shape
+    Dv = rowreduce(dh.view(B * T, C), h.view(B * T, C), 0).view(B, T)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    with _timed("ATTN", "BWD", T, C, T, B) as tm:
+        st = lib().indm_attn_bwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(dh), _ptr(lse), _ptr(Dv), _ptr(dq), _ptr(dk),
+                                     _ptr(dv), B, T, C, scale, _stream())
+        tm.variant, tm.flops = "attn_fused", 10.0 * B * T * T * C
+    _chk(st, "indm_attn_bwd_f32")
+    return dq, dk, dv
 
 
 def ires_chain(t3, d2, w2t, d1, w1p, J):

@@ -223,9 +223,7 @@ class AttnBlockpp(nn.Module):
         q = ops.gemm(h, self.NIN_0.W, self.NIN_0.b, weight_b=True).reshape(B, T, C)
         k = ops.gemm(h, self.NIN_1.W, self.NIN_1.b, weight_b=True).reshape(B, T, C)
         v = ops.gemm(h, self.NIN_2.W, self.NIN_2.b, weight_b=True).reshape(B, T, C)
-        w = ops.gemm(q, k, trans_b=True)                      # [B,T,T] logits
-        w = ops.softmax(w, float(int(C) ** (-0.5)))
-        h = ops.gemm(w, v).reshape(B * T, C)
+        h = ops.attention(q, k, v, float(int(C) ** (-0.5))).reshape(B * T, C)   # fused: no [B,T,T] logits in HBM
         a = ops.INV_SQRT2 if self.skip_rescale else 1.0
         out = ops.gemm(h, self.NIN_3.W, self.NIN_3.b, res=x.reshape(B * T, C), alpha=a, beta=a, weight_b=True)
         return out.reshape(B, H, W, C)

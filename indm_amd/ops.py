@@ -253,6 +253,34 @@ def softmax(x, scale=1.0):
     return _Softmax.apply(x, scale)
 
 
+class _Attention(Function):
+    """h = softmax(q k^T * scale) v, fused (the [T,T] logits never reach HBM; recomputed in registers in the backward)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        q, k, v = _c(q), _c(k), _c(v)
+        h, lse = hip.attn_fwd(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, h, lse)
+        ctx.scale = scale
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        q, k, v, h, lse = ctx.saved_tensors
+        dq, dk, dv = hip.attn_bwd(q, k, v, h, _c(dh), lse, ctx.scale)
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, scale):
+    """Single-head attention over [B, T, C] (models/layerspp.py:88-104).  Fused kernel when it covers the geometry
+    (T in {64, 128, 256}, C % 128 == 0, fp32 mode), else the batched-GEMM + softmax composition."""
+    B, T, C = q.shape
+    if hip.compute_dtype() == "f32" and T in (64, 128, 256) and C >= 128 and C % 128 == 0:
+        return _Attention.apply(q, k, v, scale)
+    w = softmax(gemm(q, k, trans_b=True), scale)
+    return gemm(w, v)
+
+
 # ----------------------------------------------------------------------------- elementwise
 class _SinCos(Function):
     """(a, d) = (sin(2 pi p)/(2 pi), cos(2 pi p)) -- the Sin activation and its derivative in one pass."""

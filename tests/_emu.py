@@ -118,6 +118,20 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None, x_gate
     return (alpha * dw.permute(2, 3, 1, 0)).contiguous()
 
 
+def attn_fwd(q, k, v, scale):
+    s = torch.matmul(q, k.transpose(1, 2)) * scale
+    return torch.matmul(torch.softmax(s, dim=-1), v).contiguous(), torch.logsumexp(s, dim=-1)
+
+
+def attn_bwd(q, k, v, h, dh, lse, scale):
+    s = torch.matmul(q, k.transpose(1, 2)) * scale
+    pr = torch.exp(s - lse[..., None])
+    dv = torch.matmul(pr.transpose(1, 2), dh)
+    dp = torch.matmul(dh, v.transpose(1, 2))
+    ds = pr * (dp - (dh * h).sum(-1, keepdim=True)) * scale
+    return torch.matmul(ds, k).contiguous(), torch.matmul(ds.transpose(1, 2), q).contiguous(), dv.contiguous()
+
+
 def ires_chain(t3, d2, w2t, d1, w1p, J):
     return ((((t3 * d2) @ w2t) * d1) @ w1p[:, :J]).contiguous()
 

@@ -678,3 +678,40 @@ def test_ires_chain_back_to_back(M, K, J):
     # geometry the kernel does not cover -> None (the caller falls back to two GEMMs)
     assert hip.ires_chain(t3[:M - 1].contiguous().to(DEV), d2[:M - 1].contiguous().to(DEV), w2t.to(DEV),
                           d1[:M - 1].contiguous().to(DEV), w1p.to(DEV), J) is None
+
+
+@pytest.mark.parametrize("B,T,C", [(3, 256, 256), (2, 64, 256), (2, 128, 128), (5, 256, 128)])
+def test_fused_attention(B, T, C):
+    """AttnBlockpp core (layerspp.py:88-104): softmax(q k^T / sqrt(C)) v forward and the full backward, logits kept in
+    registers, vs the fp64 composition"""
+    q, k, v, dh = (rnd(B, T, C, seed=i, scale=1.5) for i in range(4))
+    scale = float(C) ** -0.5
+    (h, lse), (href, lref) = run_both("attn_fwd", q, k, v, scale)
+    close(h, href, rtol=2e-5, atol=2e-6, name="attn h")
+    close(lse, lref, rtol=1e-5, atol=2e-5, name="attn lse")
+    got = hip.attn_bwd(q.to(DEV), k.to(DEV), v.to(DEV), h, dh.to(DEV), lse, scale)
+    ref = _emu.attn_bwd(q.double(), k.double(), v.double(), href, dh.double(), lref, scale)
+    for g, r, nm in zip(got, ref, ("dq", "dk", "dv")):
+        close(g, r, rtol=3e-5, atol=3e-6, name="attn " + nm)
+    # through autograd (ops.attention) with a sharp softmax (large logits)
+    from indm_amd import ops
+    qs = (q * 6).to(DEV).requires_grad_(True)
+    ks, vs = k.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+    out = ops.attention(qs, ks, vs, scale)
+    gq, gk, gv = torch.autograd.grad(out, [qs, ks, vs], dh.to(DEV))
+    qd, kd, vd = (t.detach().cpu().double().requires_grad_(True) for t in (qs, ks, vs))
+    oref = torch.softmax(qd @ kd.transpose(1, 2) * scale, -1) @ vd
+    rq, rk, rv = torch.autograd.grad(oref, [qd, kd, vd], dh.double())
+    close(out, oref, rtol=2e-5, atol=2e-6, name="sharp attn h")
+    for g, r, nm in zip((gq, gk, gv), (rq, rk, rv), ("dq", "dk", "dv")):
+        close(g, r, rtol=5e-5, atol=5e-6, name="sharp attn " + nm)
+
+
+def test_attention_fallback_geometry():
+    """geometries the fused kernel does not cover go through the batched GEMM + softmax path with the same result"""
+    from indm_amd import ops
+    q, k, v = (rnd(2, 16, 32, seed=i) for i in range(3))
+    out = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 32 ** -0.5)
+    ref = torch.softmax(q.double() @ k.double().transpose(1, 2) * 32 ** -0.5, -1) @ v.double()
+    close(out, ref, name="attention fallback")
+    assert hip.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), 1.0) is None
