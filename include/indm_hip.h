@@ -169,6 +169,8 @@ int indm_attn_bwd_f32(const float* q, const float* k, const float* v, const floa
  * runs indm_gemm_f32 twice.  Replaces two torch.autograd.grad links of iresblock.py:257,269. */
 int indm_ires_chain_f32(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p, float* P,
                         int M, int K, int N, int J, void* stream);
+int indm_ires_chain_bf16(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p, float* P,
+                         int M, int K, int N, int J, void* stream);
 long indm_ires_bwd_act_ws_floats(long R, int C);
 int indm_ires_bwd_act_f32(const float* da, const float* du, const float* d, const float* a, const float* t, float* dp,
                           float* dt_out, float* seg_out, long R, int C, long rows_per_seg, float* ws, void* stream);

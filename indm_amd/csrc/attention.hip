@@ -47,7 +47,7 @@ __global__ __launch_bounds__(WV * 64, 1) void attn_kernel(AttnArgs p) {
   constexpr int BUF1 = NARR * (Y_SZ + X_SZ);                     // floats per phase-1 buffer
   constexpr int ZT = 64, ZC = 128, Z_SZ = ZT * ZC;               // phase-2 tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* lse_s = smem + (2 * BUF1 > Z_SZ ? 2 * BUF1 : Z_SZ);     // DKV: lse / D of all queries
+  float* lse_s = smem + (2 * BUF1 > 2 * Z_SZ ? 2 * BUF1 : 2 * Z_SZ);  // DKV: lse / D of all queries
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5, swz = (l31 >> 2) & 3;
@@ -178,37 +178,50 @@ __global__ __launch_bounds__(WV * 64, 1) void attn_kernel(AttnArgs p) {
       }
   }
 
-  // ---- phase 2: out[x][c] = sum_y W[x][y] Z[y][c], Z streamed in [64 y][128 c] tiles (single-buffered) ----
+  // ---- phase 2: out[x][c] = sum_y W[x][y] Z[y][c], Z streamed in [64 y][128 c] tiles, double-buffered ----
+  // tile sequence (cc, yt) row-major; tile n lives in LDS buffer n & 1; the DMA of tile n+1 overlaps the MFMAs of tile n
   auto phase2 = [&](const f32x16 (&W)[NB], const float* Z, float* out) {
-    for (int cc = 0; cc < C / ZC; ++cc) {
+    constexpr int TPC = NB / 2;  // tiles per 128-column chunk
+    const int ncc = C / ZC;
+    auto stage2 = [&](int par, int cc, int yt) {
+      float* base = smem + par * Z_SZ;
+#pragma unroll
+      for (int n = 0; n < 32 / WV; ++n) {
+        const int rp = wave + n * WV;  // row pair: one wave-instruction = 2 rows of 512 B
+        const float* src = Z + (long)(yt * 64 + rp * 2 + (lane >> 5)) * C + cc * ZC + 4 * (lane & 31);
+        dma16(src, base + rp * 2 * ZC);
+      }
+    };
+    __syncthreads();  // every wave is done with the phase-1 buffers / the previous pass's tiles
+    stage2(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int par = 0;
+    for (int cc = 0; cc < ncc; ++cc) {
       f32x16 acc[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
-      for (int yt = 0; yt < NB / 2; ++yt) {
-        // stage Z[yt*64 .. +64][cc*128 .. +128]: one wave-instruction = 2 rows of 512 B
-        __syncthreads();  // every wave is done reading the previous tile / phase-1 buffers
-#pragma unroll
-        for (int n = 0; n < 32 / WV; ++n) {
-          const int rp = wave + n * WV;  // row pair
-          const float* src = Z + (long)(yt * 64 + rp * 2 + (lane >> 5)) * C + cc * ZC + 4 * (lane & 31);
-          dma16(src, smem + rp * 2 * ZC);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+      for (int yt = 0; yt < TPC; ++yt) {
+        if (yt + 1 < TPC) stage2(par ^ 1, cc, yt + 1);
+        else if (cc + 1 < ncc) stage2(par ^ 1, cc + 1, 0);
+        const float* zb = smem + par * Z_SZ;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int y = yt * 2 + h;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float* zr = smem + (h * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi) * ZC + l31;
+            const float* zr = zb + (h * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi) * ZC + l31;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[y][r], zr[j * 32], acc[j], 0, 0, 0);
           }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        par ^= 1;
       }
       // D'[x = 8 (r>>2) + (r&3) + 4 lhi][c = l31]
 #pragma unroll
@@ -235,7 +248,7 @@ int launch_attn(const AttnArgs& p, int B, hipStream_t st) {
   constexpr int T = NB * 32, OWN = WV * 32;
   constexpr int NARR = MODE == FWD ? 1 : 2;
   constexpr int BUF1 = NARR * (T + OWN) * BK;
-  constexpr int main_f = (2 * BUF1 > 64 * 128 ? 2 * BUF1 : 64 * 128);
+  constexpr int main_f = (2 * BUF1 > 2 * 64 * 128 ? 2 * BUF1 : 2 * 64 * 128);
   constexpr size_t bytes = (size_t)(main_f + (MODE == DKV ? 2 * T : 0)) * sizeof(float);
   static bool ready = false;
   if (!ready) {

@@ -932,7 +932,12 @@ __device__ __forceinline__ f32x2 pk_mul_f32(f32x2 a, f32x2 b) { return a * b; }
 // 16 bytes of zeros in device memory: the source of a padded tap's DMA copy
 __device__ __attribute__((aligned(16))) float indm_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-template <int AM, int BMODE, bool HAS_G, int NW>
+// BF16 = true: the "bf16 compute / fp32 accumulate" mode of BASELINE configs #3-#5 on the same staging: the fp32 LDS
+// images are unchanged (the DMA cannot convert), the two 4-deep fragments a lane reads per slab are rounded to bf16
+// (v_cvt_pk_bf16_f32, RNE; gated operands round the fp32 product) and packed into ONE v_mfma_f32_32x32x16_bf16 per
+// 32 x 32 block and slab -- 8x fewer matrix cycles, so the kernel turns from MFMA-bound into an HBM streamer.  (Any
+// bijection (lane-half, position) -> k is valid for an MFMA as long as both operands use the same one.)
+template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
   static_assert(AM == A_ROW || AM == A_CONV, "k-contiguous A operands");
   static_assert(BK == 16, "written for 16-deep slabs");
@@ -1135,6 +1140,35 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   // first, then the MFMAs of the PREVIOUS slab's second k-group run (their operands are already in registers), so the
   // LDS latency right after the barrier is covered.
   float4 fa0[RM], fb0[RN], fa1[RM], fb1[RN];
+  if constexpr (BF16) {
+    auto pack = [](const float4& lo, const float4& hi) {
+      bf16x8 v;
+      v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+      v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+      return v;
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nk) stage(buf ^ 1, s + 1);
+      frags(buf, 0, fa0, fb0);
+      frags(buf, 1, fa1, fb1);
+      bf16x8 ha[RM], hb[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) ha[i] = pack(fa0[i], fa1[i]);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) hb[j] = pack(fb0[j], fb1[j]);
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1155,6 +1189,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     __syncthreads();
   }
   mfmas(fa1, fb1);
+  }
 
   const bool partial = p.splitk > 1;  // partial sums -> workspace slab z; igemm_splitk_reduce applies the epilogue
   float* C = partial ? p.ws + ((long)z * p.M) * p.N : p.C + (long)bz * p.sC;
@@ -1203,27 +1238,36 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
 
 __global__ void igemm_splitk_reduce(IgemmParams p);
 
-template <int AM, int BMODE, bool HAS_G, int NW>
-int launch_glds(const IgemmParams& p, hipStream_t st) {
+template <int AM, int BMODE, bool HAS_G, int NW, bool BF16>
+int launch_glds_t(const IgemmParams& p, hipStream_t st) {
   constexpr int BUF = 256 * BK + (HAS_G ? 256 * BK : 0) + 128 * BK;
   constexpr size_t bytes = 2 * BUF * sizeof(float);
   static bool ready = false;  // > 64 KB of LDS needs the opt-in once per kernel
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)igemm_glds_kernel<AM, BMODE, HAS_G, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)igemm_glds_kernel<AM, BMODE, HAS_G, NW, BF16>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
       return INDM_E_LAUNCH;
     ready = true;
   }
   dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch * p.splitk);
-  last_variant = HAS_G ? (p.splitk > 1 ? "glds256x128,splitk,gated" : "glds256x128,gated")
-                       : (p.splitk > 1 ? "glds256x128,splitk" : "glds256x128");
-  hipLaunchKernelGGL((igemm_glds_kernel<AM, BMODE, HAS_G, NW>), grid, dim3(NW * 64), bytes, st, p);
+  if (BF16)
+    last_variant = HAS_G ? (p.splitk > 1 ? "glds256x128,splitk,gated,bf16" : "glds256x128,gated,bf16")
+                         : (p.splitk > 1 ? "glds256x128,splitk,bf16" : "glds256x128,bf16");
+  else
+    last_variant = HAS_G ? (p.splitk > 1 ? "glds256x128,splitk,gated" : "glds256x128,gated")
+                         : (p.splitk > 1 ? "glds256x128,splitk" : "glds256x128");
+  hipLaunchKernelGGL((igemm_glds_kernel<AM, BMODE, HAS_G, NW, BF16>), grid, dim3(NW * 64), bytes, st, p);
   if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
   if (p.splitk > 1) {
     hipLaunchKernelGGL(igemm_splitk_reduce, dim3(ew_grid((long)p.batch * p.M * p.N, 256)), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
   }
   return INDM_OK;
+}
+
+template <int AM, int BMODE, bool HAS_G, int NW>
+int launch_glds(const IgemmParams& p, hipStream_t st) {
+  return p.bf16 ? launch_glds_t<AM, BMODE, HAS_G, NW, true>(p, st) : launch_glds_t<AM, BMODE, HAS_G, NW, false>(p, st);
 }
 
 // Deterministic split-K combine + epilogue.
@@ -1285,7 +1329,7 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     // long plain GEMMs, gated or not: direct-to-LDS staging kernel (igemm_glds_kernel), 8 waves
     // (plain ones with a long K loop and 256-wide N stay on the 256 x 256 big tile: 142 vs 138 TF at K = 4096)
     const bool big256 = !p.G && p.K >= 1024 && big_tile_n(p) == 256;
-    if (!big256 && !p.bf16 && p.splitk == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.M >= 1024 &&
+    if ((!big256 || p.bf16) && p.splitk == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.M >= 1024 &&
         p.N >= 64 && (BMODE == B_COL || !(p.N & 3)) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224) {
       if (p.G) return launch_glds<A_ROW, BMODE, true, 8>(p, st);
       return launch_glds<A_ROW, BMODE, false, 8>(p, st);
@@ -1295,7 +1339,7 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     // long convolutions (forward and data-grad): the same direct-to-LDS kernel on the implicit-GEMM A operand;
     // data-grads that fill 256 x 256 tiles stay on the big-tile kernel (118-123 TF)
     const bool big256 = BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform && big_tile_n(p) == 256;
-    if (!big256 && !p.G && !p.bf16 && p.splitk == 1 && p.a_vec && p.b_vec && p.a_tap_uniform &&
+    if ((!big256 || p.bf16) && !p.G && p.splitk == 1 && p.a_vec && p.b_vec && p.a_tap_uniform &&
         (BMODE == B_ROW ? !(p.N & 3) : p.b_tap_uniform != 0) && p.M >= 1024 && p.N >= 64 &&
         (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224)
       return launch_glds<A_CONV, BMODE, false, 8>(p, st);
@@ -1436,7 +1480,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
     }
   }
-  if (am == A_CONV && (bm == B_ROW || bm == B_DGRAD) && ws && !p.bf16 && !p.G && p.a_vec && p.b_vec &&
+  if (am == A_CONV && (bm == B_ROW || bm == B_DGRAD) && ws && !p.G && p.a_vec && p.b_vec &&
       p.a_tap_uniform && (bm == B_ROW ? !(p.N & 3) : p.b_tap_uniform != 0) && p.M >= 1024 && p.N >= 64) {
     // mid-size convolutions (8x8 / 16x16 maps): too few 256 x 128 tiles to fill the chip -> split-K on the
     // direct-to-LDS kernel, chunks of at least 8 slabs
@@ -1451,7 +1495,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       }
     }
   }
-  if (am == A_ROW && (bm == B_ROW || bm == B_COL) && ws && !p.bf16 && p.batch == 1 && p.a_vec && p.b_vec && !(p.K & 15) &&
+  if (am == A_ROW && (bm == B_ROW || bm == B_COL) && ws && p.batch == 1 && p.a_vec && p.b_vec && !(p.K & 15) &&
       p.K >= 512 && p.M >= 1024 && p.N >= 64 && (bm == B_COL || !(p.N & 3))) {
     // plain GEMMs with too few 256 x 128 tiles to fill the chip (the flow's scale-1 edge [32768, 512] x [512, 108],
     // gated or not: 128 tiles, one 4-wave block per CU on the 8-wave engine = 40 TF): split-K on the direct-to-LDS kernel

@@ -34,7 +34,13 @@ struct ChainArgs {
   int M, K, J;
 };
 
-template <int JB>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+
+// BF16: MFMA inputs rounded to bf16 (RNE), fp32 accumulate -- stage 1 packs both 4-deep fragments of a slab into one
+// v_mfma_f32_32x32x16_bf16 (as igemm_glds_kernel<.., BF16>); stage 2 rounds its operands to bf16 and keeps the fp32
+// MFMA (products of bf16 values are exact in fp32: identical to a bf16 MFMA).
+template <int JB, bool BF16>
 __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -105,6 +111,35 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   };
 
   float4 fm0[2], fn0[2], fm1[2], fn1[2];
+  if constexpr (BF16) {
+    auto pack = [](const float4& lo, const float4& hi) {
+      bf16x8 v;
+      v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+      v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+      return v;
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nk) stage(buf ^ 1);
+      frags(buf, 0, fm0, fn0);
+      frags(buf, 1, fm1, fn1);
+      bf16x8 hm[2], hn[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) hm[j] = pack(fm0[j], fm1[j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) hn[i] = pack(fn0[i], fn1[i]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hn[i], hm[j], acc[i][j], 0, 0, 0);  // D[n][m]
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
   stage(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -125,6 +160,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
     __syncthreads();
   }
   mfmas(fm1, fn1);
+  }
 
   // ---- gate: acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi]  *=  d1[m][n] ----
 #pragma unroll
@@ -141,6 +177,10 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
         acc[i][j][4 * a + 1] *= g[a].y;
         acc[i][j][4 * a + 2] *= g[a].z;
         acc[i][j][4 * a + 3] *= g[a].w;
+      }
+      if constexpr (BF16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bf16_round(acc[i][j][r]);
       }
     }
   }
@@ -161,6 +201,10 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         w[r] = p.W1p[(long)(nw + i * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi) * JP + jb * 32 + l31];
+      if constexpr (BF16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = bf16_round(w[r]);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -195,17 +239,17 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   }
 }
 
-template <int JB>
+template <int JB, bool BF16>
 int launch_chain(const ChainArgs& p, hipStream_t st) {
   constexpr size_t bytes = 2 * BUF * sizeof(float);
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
       return INDM_E_LAUNCH;
     ready = true;
   }
-  hipLaunchKernelGGL(ires_chain_kernel<JB>, dim3(p.M / TM), dim3(NW * 64), bytes, st, p);
+  hipLaunchKernelGGL((ires_chain_kernel<JB, BF16>), dim3(p.M / TM), dim3(NW * 64), bytes, st, p);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
@@ -214,8 +258,8 @@ int launch_chain(const ChainArgs& p, hipStream_t st) {
 // P[M, J] = ((A .* G) W2T .* D1) W1p[:, :J]   with A, G: [M, K]; W2T: [K, 512]; D1: [M, 512]; W1p: [512, 32 if J <= 32 else 128]
 // (zero-padded columns).  Requirements: M % 64 == 0, K % 16 == 0, K >= 32, J <= 128, 16-byte aligned pointers.
 // Returns 1 when the geometry is not covered (the caller then runs the two contractions separately).
-INDM_API int indm_ires_chain_f32(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
-                                 float* P, int M, int K, int N, int J, void* stream) {
+static int ires_chain_impl(bool bf16, const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
+                           float* P, int M, int K, int N, int J, void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || J <= 0) return INDM_E_SHAPE;
   if (M == 0) return INDM_OK;
   if (N != TN || (M % TM) || (K % BK) || K < 2 * BK || J > 128) return 1;
@@ -224,5 +268,15 @@ INDM_API int indm_ires_chain_f32(const float* A, const float* G, const float* W2
   hipStream_t st = (hipStream_t)stream;
   // two instantiations: J <= 32 (the 3-channel scale: 27) and J <= 128 (the 12- / 48-channel scales: 108); W1p is
   // padded to 32 / 128 columns accordingly
-  return J <= 32 ? launch_chain<1>(p, st) : launch_chain<4>(p, st);
+  if (bf16) return J <= 32 ? launch_chain<1, true>(p, st) : launch_chain<4, true>(p, st);
+  return J <= 32 ? launch_chain<1, false>(p, st) : launch_chain<4, false>(p, st);
+}
+INDM_API int indm_ires_chain_f32(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
+                                 float* P, int M, int K, int N, int J, void* stream) {
+  return ires_chain_impl(false, A, G, W2T, D1, W1p, P, M, K, N, J, stream);
+}
+// same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
+INDM_API int indm_ires_chain_bf16(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
+                                  float* P, int M, int K, int N, int J, void* stream) {
+  return ires_chain_impl(true, A, G, W2T, D1, W1p, P, M, K, N, J, stream);
 }

@@ -59,6 +59,7 @@ _SIGS = {
     "indm_attn_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "indm_attn_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "indm_ires_chain_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "indm_ires_chain_bf16": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_ires_bwd_act_ws_floats": [c_l, c_i],
     "indm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p],
     "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
@@ -616,15 +617,13 @@ def attn_bwd(q, k, v, h, dh, lse, scale):
 def ires_chain(t3, d2, w2t, d1, w1p, J):
     """P[M, J] = ((t3 .* d2) @ w2t .* d1) @ w1p[:, :J] in ONE launch with the 512-wide intermediate kept on chip (the
     back-to-back contraction of the VJP chain).  t3, d2: [M, K]; w2t: [K, 512]; d1: [M, 512]; w1p: [512, 32 if J <= 32 else 128] (zero-padded).
-    Returns None when the kernel does not cover the geometry (or in bf16 mode): the caller runs the two GEMMs."""
-    if _MFMA["dtype"] != "f32":
-        return None
+    Returns None when the kernel does not cover the geometry: the caller runs the two GEMMs."""
     M, K = t3.shape
     N = w2t.shape[1]
     P = torch.empty((M, J), dtype=torch.float32, device=t3.device)
     with _timed("A_ROW", "B_ROW", M, N, K, nbytes=4 * (2 * t3.numel() + d1.numel() + w2t.numel() + P.numel())) as tm:
-        st = lib().indm_ires_chain_f32(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), M, K, N, J, _stream())
-        tm.variant = "ires_chain64x512,gated"
+        st = _dense("ires_chain")(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), M, K, N, J, _stream())
+        tm.variant = "ires_chain64x512,gated" + (",bf16" if _MFMA["dtype"] == "bf16" else "")
         tm.flops += 2.0 * M * N * w1p.shape[1]
     if st == 1:
         return None

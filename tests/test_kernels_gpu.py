@@ -715,3 +715,45 @@ def test_attention_fallback_geometry():
     ref = torch.softmax(q.double() @ k.double().transpose(1, 2) * 32 ** -0.5, -1) @ v.double()
     close(out, ref, name="attention fallback")
     assert hip.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), 1.0) is None
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(16384, 512, 512, False), (16384, 512, 512, True), (4096, 256, 1024, True)])
+def test_bf16_glds_gemm(bf16_mode, M, N, K, tb):
+    """bf16 mode on the direct-to-LDS kernel (long GEMMs, gated and plain, split-K variant included): exact products of
+    the bf16-rounded inputs (the gate is multiplied in fp32 and the product rounded), fp32 accumulation"""
+    a, g = rnd(M, K), rnd(M, K, seed=5)
+    b = rnd(N, K, seed=1) if tb else rnd(K, N, seed=1)
+    out = hip.gemm(a.to(DEV), b.to(DEV), trans_b=tb)
+    assert "glds" in hip.lib().indm_igemm_last_variant().decode() and "bf16" in hip.lib().indm_igemm_last_variant().decode()
+    close(out, _emu.gemm(_r16(a).double(), _r16(b).double(), trans_b=tb), rtol=1e-5, atol=1e-5 * math.sqrt(K), name="bf16 glds")
+    out = hip.gemm(a.to(DEV), b.to(DEV), trans_b=tb, gate=g.to(DEV))
+    close(out, _emu.gemm(_r16(a * g).double(), _r16(b).double(), trans_b=tb), rtol=1e-5, atol=1e-5 * math.sqrt(K),
+          name="bf16 glds gated")
+
+
+def test_bf16_glds_conv(bf16_mode):
+    x, w = rnd(64, 32, 32, 128), rnd(3, 3, 128, 128, seed=1, scale=0.1)
+    out = hip.conv2d(x.to(DEV), w.to(DEV))
+    assert "glds" in hip.lib().indm_igemm_last_variant().decode()
+    imgs = [0, 31, 63]
+    ref = _emu.conv2d(_r16(x[imgs]).double(), _r16(w).double())
+    close(out[imgs], ref, rtol=1e-5, atol=2e-4, name="bf16 glds conv")
+    dy = rnd(64, 32, 32, 128, seed=4)
+    out = hip.conv2d_dgrad(dy.to(DEV), w.to(DEV), (32, 32))
+    close(out[imgs], _emu.conv2d_dgrad(_r16(dy[imgs]).double(), _r16(w).double(), (32, 32)), rtol=1e-5, atol=2e-4,
+          name="bf16 glds dgrad")
+
+
+@pytest.mark.parametrize("M,J", [(256, 27), (8192, 108)])
+def test_bf16_ires_chain(bf16_mode, M, J):
+    JP = 32 if J <= 32 else 128
+    t3, d2, d1 = rnd(M, 512, seed=1), rnd(M, 512, seed=2), rnd(M, 512, seed=3)
+    w2t = rnd(512, 512, seed=4, scale=512 ** -0.5)
+    w1p = torch.zeros(512, JP)
+    w1p[:, :J] = rnd(512, J, seed=5, scale=512 ** -0.5)
+    out = hip.ires_chain(t3.to(DEV), d2.to(DEV), w2t.to(DEV), d1.to(DEV), w1p.to(DEV), J)
+    t2 = (_r16(t3 * d2).double() @ _r16(w2t).double()).float()
+    ref = _r16(t2 * d1).double() @ _r16(w1p[:, :J]).double()
+    # t2 is rounded to fp32 here and accumulated in a different order on the GPU: its bf16 rounding may flip for
+    # values next to a rounding boundary (relative 2^-9 on a single term of a 512-term sum)
+    close(out, ref, rtol=2e-4, atol=2e-4, name="bf16 ires_chain")
