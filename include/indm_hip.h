@@ -81,6 +81,8 @@ int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, 
  * Returns 1 (not an error) when the geometry is not covered; the caller then uses indm_tap_spread_f32 + indm_gemm_f32. */
 int indm_conv3x3_thin_f32(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout, int sign,
                           float alpha, const float* bias, const float* bias2, const float* R, float beta, void* stream);
+int indm_conv3x3_thin_bf16(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout, int sign,
+                          float alpha, const float* bias, const float* bias2, const float* R, float beta, void* stream);
 
 /* Name of the kernel variant this thread's last dense launch (gemm / conv2d_*) was dispatched to, e.g.
  * "glds256x128,gated", "big256x256", "thin128x128", "128x32": bench.py labels its live per-kernel timings with it. */

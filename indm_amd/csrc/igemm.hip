@@ -612,7 +612,10 @@ __device__ __forceinline__ float4 b_fast(const IgemmParams& p, const float* B, i
 //     8*sg + 4*h + t -- the SAME k as the k-contiguous operand supplies in that MFMA.
 // The MFMA only sums over k, so any bijection lane-half/step -> k is valid as long as A and B agree; that frees
 // the k-contiguous operands from transposing LDS writes.
-template <int AM, int BMODE, int TN, bool HAS_G>
+// BF16 = true ("bf16 compute / fp32 accumulate"): same staging; per slab both 4-deep fragments of a lane are rounded
+// and packed into one v_mfma_f32_32x32x16_bf16 per 32 x 32 block.  The kernel is then HBM-bound, so the slab is issued
+// in plain order (fetch s+2, read fragments, RM*RN MFMAs, store s+1, barrier) instead of the fp32 weave.
+template <int AM, int BMODE, int TN, bool HAS_G, bool BF16 = false>
 __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(IgemmParams p) {
   static_assert(BK == 16, "big-tile kernel is written for 16-deep slabs");
   constexpr int TM = 256, NT = 256;
@@ -825,6 +828,66 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
     __syncthreads();
   };
 
+  if constexpr (BF16) {
+    auto pack = [](const float4& lo, const float4& hi) {
+      bf16x8 v;
+      v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
+      v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
+      return v;
+    };
+    auto slab16 = [&](auto PAR, int s) {
+      using OTH = std::integral_constant<int, 1 - decltype(PAR)::value>;
+      const int kt = min(s + 2, nk - 1);
+#pragma unroll
+      for (int j = 0; j < NGA; ++j) gl_a(PAR, j, kt);   // slab s+2 -> register set PAR (its old content is in LDS)
+#pragma unroll
+      for (int j = 0; j < NGB; ++j) gl_b(PAR, j, kt);
+#pragma unroll
+      for (int i = 0; i < RM; ++i) { fr_a(PAR, I0{}, i); fr_a(PAR, I1{}, i); }
+#pragma unroll
+      for (int j = 0; j < RN; ++j) { fr_b(PAR, I0{}, j); fr_b(PAR, I1{}, j); }
+      bf16x8 hb[RN];
+#pragma unroll
+      for (int j = 0; j < RN; ++j) hb[j] = pack(fb[0][j], fb[1][j]);
+#pragma unroll
+      for (int i = 0; i < RM; ++i) {
+        const bf16x8 ha = pack(fa[0][i], fa[1][i]);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+          if constexpr (TN == 256) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(ha), "v"(hb[j]));
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, hb[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NGA; ++j) st_a(OTH{}, OTH{}, j);  // slab s+1 (set 1-PAR) -> LDS buffer 1-PAR
+#pragma unroll
+      for (int j = 0; j < NGB; ++j) st_b(OTH{}, OTH{}, j);
+      __syncthreads();
+    };
+#pragma unroll
+    for (int j = 0; j < NGA; ++j) gl_a(I0{}, j, 0);
+#pragma unroll
+    for (int j = 0; j < NGB; ++j) gl_b(I0{}, j, 0);
+#pragma unroll
+    for (int j = 0; j < NGA; ++j) st_a(I0{}, I0{}, j);
+#pragma unroll
+    for (int j = 0; j < NGB; ++j) st_b(I0{}, I0{}, j);
+    {
+      const int k1 = min(1, nk - 1);
+#pragma unroll
+      for (int j = 0; j < NGA; ++j) gl_a(I1{}, j, k1);
+#pragma unroll
+      for (int j = 0; j < NGB; ++j) gl_b(I1{}, j, k1);
+    }
+    __syncthreads();
+    for (int s = 0; s < nk; s += 2) {
+      slab16(I0{}, s);
+      if (s + 1 < nk) slab16(I1{}, s + 1);
+    }
+  } else {
   // prologue: slab 0 -> LDS buffer 0, slab 1 -> set 1, slab 2 -> set 0; then "k-group B" of slab 0
 #pragma unroll
   for (int j = 0; j < NGA; ++j) gl_a(I0{}, j, 0);
@@ -867,6 +930,7 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
     if (s + 1 < nk) slab(I0{}, s + 1);
   }
   kgroup(I1{}, [&](auto) {});  // k-group 1 of the last slab
+  }
   if constexpr (TN == 256) {
     // the accumulators were written by MFMAs the compiler cannot see: cover the XDL-write -> VALU-read hazard
     // (18 wait states for a 16-pass MFMA) by hand before the epilogue reads them
@@ -1348,7 +1412,7 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     // measured on MI355X (tools/dense_bench.py): the big tile wins on ungated plain GEMMs (+7-8 %) and on data-grad
     // convolutions that fill 256x256 tiles (+7-14 %); gated GEMMs (two operand streams in flight do not fit the
     // register budget) and B_ROW-weight convolutions stay on the 8-wave kernel.
-    const bool eligible = !p.bf16 && !p.G && (AM == A_ROW || (BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform)) &&
+    const bool eligible = !p.G && (AM == A_ROW || (BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform)) &&
                           (BMODE != B_ROW || (p.N & 3) == 0);
     int btn = eligible ? big_tile_n(p) : 0;
     if (AM == A_CONV && btn != 256) btn = 0;
@@ -1356,7 +1420,11 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
       // one wave per SIMD with a 128x128 / 128x64 register tile (see igemm_big_kernel)
       dim3 grid(cdiv(p.M, 256) * cdiv(p.N, btn), p.batch);
       last_variant = btn == 256 ? "big256x256" : "big256x128";
-      if (btn == 256) hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 256, false>), grid, block, 0, st, p);
+      if (p.bf16) {
+        last_variant = btn == 256 ? "big256x256,bf16" : "big256x128,bf16";
+        if (btn == 256) hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 256, false, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 128, false, true>), grid, block, 0, st, p);
+      } else if (btn == 256) hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 256, false>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 128, false>), grid, block, 0, st, p);
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
     }
@@ -1425,10 +1493,12 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return INDM_OK;
   if (p.K < 0) return INDM_E_SHAPE;
   p.ws = ws;
-  if (!p.bf16 && (am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
-    // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip
-    const ThinGemmArgs t = {p.A, p.G, p.B, p.C, p.M, p.N, p.K, am == A_COL, bm == B_COL, p.lda, p.ldb, p.ldc, p.batch,
-                            p.alpha, p.beta, p.bias, p.bias2, p.rpg, p.R, p.ldr, ws, ws_floats};
+  if ((am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
+    // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip (bf16 mode: operands
+    // rounded at the fragment read, exact fp32 MFMA)
+    ThinGemmArgs t = {p.A, p.G, p.B, p.C, p.M, p.N, p.K, am == A_COL, bm == B_COL, p.lda, p.ldb, p.ldc, p.batch,
+                      p.alpha, p.beta, p.bias, p.bias2, p.rpg, p.R, p.ldr, ws, ws_floats};
+    t.bf16 = p.bf16;
     const char* name = "";
     const int r = indm_thin_gemm(t, st, &name);
     if (r != THIN_NA) {
@@ -1436,7 +1506,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       return r;
     }
   }
-  if (am == A_COL && bm == B_ROW && ws && !p.bf16) {
+  if (am == A_COL && bm == B_ROW && ws) {
     // weight-grad GEMMs (tiny output, K = pixels): 256x256 big tiles, one block per CU, split-K sized to 256 blocks
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
     if (p.M >= 256 && p.N >= 256 && !(p.M & 3) && !(p.N & 3) && !(p.K & 15) && p.a_vec && p.b_vec && tiles <= 64 &&
@@ -1451,7 +1521,11 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
         p.splitk = cdiv(p.K, kps);
         last_variant = "big256x256";
         dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, 256)), (unsigned)(p.batch * p.splitk));
-        if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true>), grid, dim3(256), 0, st, p);
+        if (p.bf16) {
+          last_variant = "big256x256,bf16";
+          if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true, true>), grid, dim3(256), 0, st, p);
+          else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, false, true>), grid, dim3(256), 0, st, p);
+        } else if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
         const long total = (long)p.batch * p.M * p.N;
@@ -1460,7 +1534,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       }
     }
   }
-  if (am == A_WGRAD && bm == B_ROW && ws && !p.bf16 && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
+  if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
       p.K >= 16384) {
     // convolution weight grads: same recipe on the implicit-GEMM A operand (256 x 256|128 tiles)
     const int tn = (p.N % 256 == 0) ? 256 : 128;
@@ -1473,7 +1547,11 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       p.splitk = cdiv(p.K, kps);
       dim3 grid((unsigned)tiles, (unsigned)p.splitk);
       last_variant = tn == 256 ? "big256x256" : "big256x128";
-      if (tn == 256) hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
+      if (p.bf16) {
+        last_variant = tn == 256 ? "big256x256,bf16" : "big256x128,bf16";
+        if (tn == 256) hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 256, false, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 128, false, true>), grid, dim3(256), 0, st, p);
+      } else if (tn == 256) hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 128, false>), grid, dim3(256), 0, st, p);
       if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
       hipLaunchKernelGGL(igemm_splitk_reduce, dim3(ew_grid((long)p.M * p.N, 256)), dim3(256), 0, st, p);
@@ -1544,19 +1622,31 @@ INDM_API const char* indm_igemm_last_variant(void) { return last_variant; }
 //   y[p, co] = alpha*(sum_{tap,c} x[n, h - sign*(kh-1), w - sign*(kw-1), c] * w[tap*C + c, co] + bias[co] + bias2[n][co]) + beta*R
 // sign = -1: cross-correlation (conv forward); sign = +1: the transposed convolution (w pre-packed by the caller).
 // Returns 1 when the geometry is not covered (the caller then takes the tap_spread + GEMM route).
-INDM_API int indm_conv3x3_thin_f32(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout,
-                                   int sign, float alpha, const float* bias, const float* bias2, const float* R,
-                                   float beta, void* stream) {
+static int conv3x3_thin_impl(int bf16, const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout,
+                             int sign, float alpha, const float* bias, const float* bias2, const float* R,
+                             float beta, void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return INDM_E_SHAPE;
   if (Nimg == 0) return INDM_OK;
   ThinGemmArgs t = {};
+  t.bf16 = bf16;
   t.B = w; t.C = y; t.M = Nimg * H * W; t.N = Cout; t.K = 9 * C;
   t.ldb = Cout; t.ldc = Cout; t.batch = 1; t.alpha = alpha; t.beta = beta; t.bias = bias; t.bias2 = bias2; t.rpg = H * W;
   t.R = R; t.ldr = Cout; t.X = x; t.cH = H; t.cW = W; t.cC = C; t.csign = sign;
   const int r = indm_thin_conv3x3(t, (hipStream_t)stream);
   if (r == THIN_NA) return 1;
-  last_variant = C <= 3 ? "thin_conv3x3_flat" : "thin_conv3x3_k128";
+  last_variant = C <= 3 ? (bf16 ? "thin_conv3x3_flat,bf16" : "thin_conv3x3_flat") : (bf16 ? "thin_conv3x3_k128,bf16" : "thin_conv3x3_k128");
   return r;
+}
+INDM_API int indm_conv3x3_thin_f32(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout,
+                                   int sign, float alpha, const float* bias, const float* bias2, const float* R,
+                                   float beta, void* stream) {
+  return conv3x3_thin_impl(0, x, w, y, Nimg, H, W, C, Cout, sign, alpha, bias, bias2, R, beta, stream);
+}
+// same with both operands rounded to bf16 (the "bf16 compute / fp32 accumulate" mode)
+INDM_API int indm_conv3x3_thin_bf16(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout,
+                                    int sign, float alpha, const float* bias, const float* bias2, const float* R,
+                                    float beta, void* stream) {
+  return conv3x3_thin_impl(1, x, w, y, Nimg, H, W, C, Cout, sign, alpha, bias, bias2, R, beta, stream);
 }
 
 // C[b] = alpha * (opA(A[b] .* gateA[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]   (gateA optional)

@@ -25,6 +25,10 @@ struct ThinGemmArgs {
   // cC channels (3x3 taps, zero padding), p = (n, h, w); A / lda are ignored, K = 9*cC, M = images*cH*cW
   const float* X;
   int cH, cW, cC, csign;
+  // "bf16 compute / fp32 accumulate" mode: both MFMA operands are rounded to bf16 (RNE) at the fragment read and
+  // multiplied on the exact fp32 MFMA -- products of bf16 values are exact in fp32, so the result equals a bf16 MFMA's.
+  // (These kernels are HBM-bound either way.)
+  int bf16;
 };
 
 enum { THIN_NA = 1 };

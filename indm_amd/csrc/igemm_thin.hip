@@ -8,6 +8,14 @@
 #include "igemm_thin.h"
 
 namespace {
+template <bool ON>
+__device__ __forceinline__ float rb16(float x) {
+  if constexpr (ON) return (float)(__bf16)x;
+  return x;
+}
+}  // namespace
+
+namespace {
 
 // Bijective XCD-aware remap (same as igemm.hip): workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles.
 __device__ __forceinline__ int xcd_remap(int b, int n) {
@@ -33,7 +41,7 @@ constexpr int TK_SMEM = TK_OPER > TK_STAGE ? TK_OPER : TK_STAGE;
 
 enum { TK_STRIDED = 0, TK_FLAT = 1, TK_IM2COL = 2 };
 
-template <int MODE>
+template <int MODE, bool BF16 = false>
 __global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
   constexpr bool FLAT = MODE == TK_FLAT;
   __shared__ __attribute__((aligned(16))) float smem[TK_SMEM];
@@ -136,10 +144,10 @@ __global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
 #pragma unroll 2
     for (int kk = 0; kk < npairs; ++kk) {
       const int k = 2 * kk + lhi;
-      const float a = af[k * TK_LDA];
+      const float a = rb16<BF16>(af[k * TK_LDA]);
       float b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = bf[k * TK_LDB + j * 32];
+      for (int j = 0; j < 4; ++j) b[j] = rb16<BF16>(bf[k * TK_LDB + j * 32]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[j], acc[j], 0, 0, 0);
     }
@@ -223,7 +231,7 @@ __device__ __forceinline__ void async_load1(float& dst, const float* src) {
 // IM2COL: the A tile is gathered from a 3-channel NHWC image (K = 27) instead of being read as a flat run: 128
 // consecutive pixels are whole image rows (128 % W == 0, H*W % 128 == 0, host-checked), so the (row, tap) -> source
 // offset table of a thread's 16 elements is the same for every tile and only the row bound depends on the tile.
-template <bool IM2COL>
+template <bool IM2COL, bool BF16 = false>
 __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel(ThinGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[TF_AS + TF_BS + TF_STG];
   float* as = smem;
@@ -415,15 +423,15 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     // fragments of k-pair kk+1 are requested before the MFMAs of kk
-    float a0 = af[lhi * TK_LDA], b0[4];
+    float a0 = rb16<BF16>(af[lhi * TK_LDA]), b0[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = bf[lhi * TK_LDB + j * 32];
+    for (int j = 0; j < 4; ++j) b0[j] = rb16<BF16>(bf[lhi * TK_LDB + j * 32]);
     for (int kk = 0; kk < npairs; ++kk) {
       const int k = 2 * min(kk + 1, npairs - 1) + lhi;
-      const float a1 = af[k * TK_LDA];
+      const float a1 = rb16<BF16>(af[k * TK_LDA]);
       float b1[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b1[j] = bf[k * TK_LDB + j * 32];
+      for (int j = 0; j < 4; ++j) b1[j] = rb16<BF16>(bf[k * TK_LDB + j * 32]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[j], acc[j], 0, 0, 0);
       a0 = a1;
@@ -457,11 +465,15 @@ int launch_thin_k(const ThinGemmArgs& a, hipStream_t st) {
     int groups = target / tiles_n;
     if (groups > tiles_m) groups = tiles_m;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(igemm_thin_kflat_kernel<false>, dim3(groups * tiles_n), dim3(256), 0, st, a);
+    if (a.bf16) hipLaunchKernelGGL((igemm_thin_kflat_kernel<false, true>), dim3(groups * tiles_n), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_thin_kflat_kernel<false, false>), dim3(groups * tiles_n), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
   }
-  if (flat) hipLaunchKernelGGL(igemm_thin_k_kernel<TK_FLAT>, dim3(tiles), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(igemm_thin_k_kernel<TK_STRIDED>, dim3(tiles), dim3(256), 0, st, a);
+  if (a.bf16) {
+    if (flat) hipLaunchKernelGGL((igemm_thin_k_kernel<TK_FLAT, true>), dim3(tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_thin_k_kernel<TK_STRIDED, true>), dim3(tiles), dim3(256), 0, st, a);
+  } else if (flat) hipLaunchKernelGGL((igemm_thin_k_kernel<TK_FLAT, false>), dim3(tiles), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((igemm_thin_k_kernel<TK_STRIDED, false>), dim3(tiles), dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
@@ -476,7 +488,7 @@ int launch_thin_k(const ThinGemmArgs& a, hipStream_t st) {
 // (deterministic) and writes D or its transpose (the form whose OUTPUT is [wide column][t]).
 constexpr int TW_BK = 32, TW_TN = 128, TW_LDB = TW_TN + 4;
 
-template <int TP, bool HAS_G>
+template <int TP, bool HAS_G, bool BF16 = false>
 __global__ __launch_bounds__(256, (TP == 32 ? 3 : 2)) void thin_wgrad_kernel(const float* __restrict__ thin,
                                                                              const float* __restrict__ wide,
                                                                              const float* __restrict__ gate, float* __restrict__ ws,
@@ -574,9 +586,9 @@ __global__ __launch_bounds__(256, (TP == 32 ? 3 : 2)) void thin_wgrad_kernel(con
       const int k = 2 * kk + lhi;
       float a[RM], b[RN];
 #pragma unroll
-      for (int i = 0; i < RM; ++i) a[i] = af[k * LDA + i * 32];
+      for (int i = 0; i < RM; ++i) a[i] = rb16<BF16>(af[k * LDA + i * 32]);
 #pragma unroll
-      for (int j = 0; j < RN; ++j) b[j] = bf[k * TW_LDB + j * 32];
+      for (int j = 0; j < RN; ++j) b[j] = rb16<BF16>(bf[k * TW_LDB + j * 32]);
 #pragma unroll
       for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -623,7 +635,7 @@ __global__ void thin_wgrad_reduce(const float* __restrict__ ws, float* __restric
 
 // thin: [P, T] contiguous; wide (+gate): [P, N] with row stride ldw; out: [T, N] (ldo) or, transposed, [N, T] (ldo)
 int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, float* out, int T, int N, long P, long ldw,
-                      float alpha, int transpose, long ldo, float* ws, long ws_floats, hipStream_t st) {
+                      float alpha, int transpose, long ldo, float* ws, long ws_floats, hipStream_t st, int bf16) {
   if (T < 1 || T > 128 || (N & 3) || (ldw & 3) || (P % TW_BK) || P < 4096 || P > (1L << 30)) return THIN_NA;
   if (!al16(thin) || !al16(wide) || !al16(gate) || !ws) return THIN_NA;
   const int tiles_n = cdiv(N, TW_TN);
@@ -634,11 +646,15 @@ int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, f
   if (S * T * N > ws_floats || S > 65535) return THIN_NA;
   dim3 grid(tiles_n, (unsigned)S);
   if (T <= 32) {
-    if (gate) hipLaunchKernelGGL((thin_wgrad_kernel<32, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
-    else hipLaunchKernelGGL((thin_wgrad_kernel<32, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+    if (gate) { if (bf16) hipLaunchKernelGGL((thin_wgrad_kernel<32, true, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+      else hipLaunchKernelGGL((thin_wgrad_kernel<32, true, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P); }
+    else { if (bf16) hipLaunchKernelGGL((thin_wgrad_kernel<32, false, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+      else hipLaunchKernelGGL((thin_wgrad_kernel<32, false, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P); }
   } else {
-    if (gate) hipLaunchKernelGGL((thin_wgrad_kernel<128, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
-    else hipLaunchKernelGGL((thin_wgrad_kernel<128, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+    if (gate) { if (bf16) hipLaunchKernelGGL((thin_wgrad_kernel<128, true, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+      else hipLaunchKernelGGL((thin_wgrad_kernel<128, true, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P); }
+    else { if (bf16) hipLaunchKernelGGL((thin_wgrad_kernel<128, false, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
+      else hipLaunchKernelGGL((thin_wgrad_kernel<128, false, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P); }
   }
   if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
   hipLaunchKernelGGL(thin_wgrad_reduce, dim3(cdiv((long)T * N, 256)), dim3(256), 0, st, ws, out, (int)S, T, N, alpha, transpose, ldo);
@@ -658,11 +674,13 @@ int indm_thin_conv3x3(const ThinGemmArgs& a, hipStream_t st) {
     int groups = 512 / tiles_n;  // two blocks per CU (the element tables cost registers)
     if (groups > tiles_m) groups = tiles_m;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(igemm_thin_kflat_kernel<true>, dim3(groups * tiles_n), dim3(256), 0, st, a);
+    if (a.bf16) hipLaunchKernelGGL((igemm_thin_kflat_kernel<true, true>), dim3(groups * tiles_n), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_thin_kflat_kernel<true, false>), dim3(groups * tiles_n), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
   }
   if (!(C & 3) && 9 * C <= 128) {
-    hipLaunchKernelGGL(igemm_thin_k_kernel<TK_IM2COL>, dim3(tiles_m * tiles_n), dim3(256), 0, st, a);
+    if (a.bf16) hipLaunchKernelGGL((igemm_thin_k_kernel<TK_IM2COL, true>), dim3(tiles_m * tiles_n), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_thin_k_kernel<TK_IM2COL, false>), dim3(tiles_m * tiles_n), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
   }
   return THIN_NA;
@@ -681,10 +699,10 @@ int indm_thin_gemm(const ThinGemmArgs& a, hipStream_t st, const char** variant) 
     // thin^T x wide -> [T, N]  (A = thin, contiguous [K, M]; B = wide)
     *variant = (a.M <= 128 ? a.M : a.N) <= 32 ? "thin_wgrad32x128" : "thin_wgrad128x128";
     if (a.M <= 128 && a.N >= 256 && !a.G && a.lda == a.M)
-      return launch_thin_wgrad(a.A, a.B, nullptr, a.C, a.M, a.N, a.K, a.ldb, a.alpha, 0, a.ldc, a.ws, a.ws_floats, st);
+      return launch_thin_wgrad(a.A, a.B, nullptr, a.C, a.M, a.N, a.K, a.ldb, a.alpha, 0, a.ldc, a.ws, a.ws_floats, st, a.bf16);
     // (wide .* gate)^T x thin -> [N_wide, T]  (A = wide (+ gate), B = thin contiguous [K, N])
     if (a.N <= 128 && a.M >= 256 && a.ldb == a.N)
-      return launch_thin_wgrad(a.B, a.A, a.G, a.C, a.N, a.M, a.K, a.lda, a.alpha, 1, a.ldc, a.ws, a.ws_floats, st);
+      return launch_thin_wgrad(a.B, a.A, a.G, a.C, a.N, a.M, a.K, a.lda, a.alpha, 1, a.ldc, a.ws, a.ws_floats, st, a.bf16);
   }
   return THIN_NA;
 }

@@ -54,6 +54,7 @@ _SIGS = {
     "indm_segreduce_f32": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
     "indm_igemm_last_variant": [],
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
+    "indm_conv3x3_thin_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_attn_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
@@ -342,16 +343,14 @@ def tap_spread(y, sign, alpha=1.0):
 def conv3x3_thin(x, w2d, sign, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0):
     """3x3 / pad 1 / stride 1 conv of a skinny NHWC input x [N,H,W,C] with w2d [9C, Co] (rows (tap, c)); the 9-tap gather
     happens inside the thin-K GEMM's operand loader.  sign -1: conv forward, +1: transposed conv (w2d pre-packed).
-    Returns None when the kernel does not cover the geometry (or in bf16 mode): the caller falls back."""
-    if _MFMA["dtype"] != "f32":
-        return None
+    Returns None when the kernel does not cover the geometry: the caller falls back."""
     N, H, W, C = x.shape
     Co = w2d.shape[1]
     y = torch.empty((N, H, W, Co), dtype=torch.float32, device=x.device)
     nbytes = 4 * (x.numel() + w2d.numel() + y.numel() + (res.numel() if res is not None else 0))
     with _timed("A_CONV3", "B_ROW", N * H * W, Co, 9 * C, nbytes=nbytes):
-        st = lib().indm_conv3x3_thin_f32(_ptr(x), _ptr(w2d), _ptr(y), N, H, W, C, Co, sign, alpha, _ptr(bias),
-                                         _ptr(bias2), _ptr(res), beta, _stream())
+        st = _dense("conv3x3_thin")(_ptr(x), _ptr(w2d), _ptr(y), N, H, W, C, Co, sign, alpha, _ptr(bias),
+                                    _ptr(bias2), _ptr(res), beta, _stream())
     if st == 1:
         return None
     _chk(st, "indm_conv3x3_thin_f32")

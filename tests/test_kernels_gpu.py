@@ -757,3 +757,23 @@ def test_bf16_ires_chain(bf16_mode, M, J):
     # t2 is rounded to fp32 here and accumulated in a different order on the GPU: its bf16 rounding may flip for
     # values next to a rounding boundary (relative 2^-9 on a single term of a 512-term sum)
     close(out, ref, rtol=2e-4, atol=2e-4, name="bf16 ires_chain")
+
+
+@pytest.mark.parametrize("C", [3, 12])
+def test_bf16_thin_kernels(bf16_mode, C):
+    """bf16 mode on the HBM-bound thin kernels (skinny 3x3 convs of the flow, their transposes and weight grads):
+    operands rounded to bf16 at the fragment read, exact fp32 MFMA == products of the rounded inputs"""
+    N, H, W, Cw = 8, 32, 32, 512
+    x, w = rnd(N, H, W, C), rnd(3, 3, C, Cw, seed=1, scale=0.3)
+    b = rnd(Cw, seed=2)
+    out = hip.conv2d(x.to(DEV), w.to(DEV), bias=b.to(DEV))
+    assert "thin" in hip.lib().indm_igemm_last_variant().decode()
+    close(out, _emu.conv2d(_r16(x).double(), _r16(w).double(), bias=b.double()), rtol=1e-5, atol=1e-4, name="bf16 thin conv")
+    v = rnd(N, H, W, C, seed=3)
+    w3 = rnd(3, 3, Cw, C, seed=4, scale=0.05)
+    out = hip.conv2d_dgrad(v.to(DEV), w3.to(DEV), (H, W))                     # skinny dy -> wide (thin conv, sign +1)
+    close(out, _emu.conv2d_dgrad(_r16(v).double(), _r16(w3).double(), (H, W)), rtol=1e-5, atol=1e-4, name="bf16 thin conv_t")
+    wide, g = rnd(N, H, W, Cw, seed=5), rnd(N, H, W, Cw, seed=6)
+    out = hip.conv2d_wgrad(x.to(DEV), wide.to(DEV), 3, 3, dy_gate=g.to(DEV))  # thin weight grad, gated wide operand
+    ref = _emu.conv2d_wgrad(_r16(x).double(), _r16(wide * g).double(), 3, 3)
+    close(out, ref, rtol=1e-5, atol=2e-3, name="bf16 thin wgrad")
