@@ -854,11 +854,8 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
         const bf16x8 ha = pack(fa[0][i], fa[1][i]);
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
-          if constexpr (TN == 256) {
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(ha), "v"(hb[j]));
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, hb[j], acc[i][j], 0, 0, 0);
-          }
+          // (the builtin, not inline asm: the hazard recogniser must see the converts that feed these MFMAs)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, hb[j], acc[i][j], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -931,7 +928,7 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
   }
   kgroup(I1{}, [&](auto) {});  // k-group 1 of the last slab
   }
-  if constexpr (TN == 256) {
+  if constexpr (TN == 256 && !BF16) {
     // the accumulators were written by MFMAs the compiler cannot see: cover the XDL-write -> VALU-read hazard
     // (18 wait states for a 16-pass MFMA) by hand before the epilogue reads them
 #pragma unroll
@@ -1420,10 +1417,10 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
       // one wave per SIMD with a 128x128 / 128x64 register tile (see igemm_big_kernel)
       dim3 grid(cdiv(p.M, 256) * cdiv(p.N, btn), p.batch);
       last_variant = btn == 256 ? "big256x256" : "big256x128";
-      if (p.bf16) {
-        last_variant = btn == 256 ? "big256x256,bf16" : "big256x128,bf16";
-        if (btn == 256) hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 256, false, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 128, false, true>), grid, block, 0, st, p);
+      if (p.bf16) {  // (the 256-wide register tile spills with the bf16 fragments: bf16 mode stays on 256 x 128)
+        last_variant = "big256x128,bf16";
+        dim3 g16(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch);
+        hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 128, false, true>), g16, block, 0, st, p);
       } else if (btn == 256) hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 256, false>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((igemm_big_kernel<AM, BMODE, 128, false>), grid, block, 0, st, p);
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
@@ -1508,10 +1505,12 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   }
   if (am == A_COL && bm == B_ROW && ws) {
     // weight-grad GEMMs (tiny output, K = pixels): 256x256 big tiles, one block per CU, split-K sized to 256 blocks
-    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 256) * p.batch;
-    if (p.M >= 256 && p.N >= 256 && !(p.M & 3) && !(p.N & 3) && !(p.K & 15) && p.a_vec && p.b_vec && tiles <= 64 &&
-        p.K >= 8192) {
-      long want = 256 / tiles;
+    // (bf16 mode: 256 x 128 tiles, two blocks per CU -- the 256-wide register tile spills with the bf16 fragments)
+    const int tnw = p.bf16 ? 128 : 256;
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, tnw) * p.batch;
+    if (p.M >= 256 && p.N >= 256 && !(p.M & 3) && !(p.N & 3) && !(p.K & 15) && p.a_vec && p.b_vec &&
+        tiles <= (p.bf16 ? 128 : 64) && p.K >= 8192) {
+      long want = (p.bf16 ? 512 : 256) / tiles;
       while (want > 1 && (p.K / want < 512 || want * p.batch * p.M * p.N > ws_floats)) --want;
       // fewer than 128 blocks (e.g. the 256 x 256 NIN weight grads at K = 32768: 64 blocks, 31 TF) leave most of the
       // chip idle: those go to the 128 x 128 split-K path below
@@ -1519,12 +1518,11 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
         int kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
         p.kps = kps;
         p.splitk = cdiv(p.K, kps);
-        last_variant = "big256x256";
-        dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, 256)), (unsigned)(p.batch * p.splitk));
+        last_variant = p.bf16 ? "big256x128,bf16" : "big256x256";
+        dim3 grid((unsigned)(cdiv(p.M, 256) * cdiv(p.N, tnw)), (unsigned)(p.batch * p.splitk));
         if (p.bf16) {
-          last_variant = "big256x256,bf16";
-          if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true, true>), grid, dim3(256), 0, st, p);
-          else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, false, true>), grid, dim3(256), 0, st, p);
+          if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 128, true, true>), grid, dim3(256), 0, st, p);
+          else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 128, false, true>), grid, dim3(256), 0, st, p);
         } else if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
@@ -1537,7 +1535,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
       p.K >= 16384) {
     // convolution weight grads: same recipe on the implicit-GEMM A operand (256 x 256|128 tiles)
-    const int tn = (p.N % 256 == 0) ? 256 : 128;
+    const int tn = (p.N % 256 == 0 && !p.bf16) ? 256 : 128;
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, tn);
     long want = (tn == 256 ? 256 : 512) / tiles;
     while (want > 1 && (p.K / want < 512 || want * p.M * p.N > ws_floats)) --want;
@@ -1548,9 +1546,8 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       dim3 grid((unsigned)tiles, (unsigned)p.splitk);
       last_variant = tn == 256 ? "big256x256" : "big256x128";
       if (p.bf16) {
-        last_variant = tn == 256 ? "big256x256,bf16" : "big256x128,bf16";
-        if (tn == 256) hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 256, false, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 128, false, true>), grid, dim3(256), 0, st, p);
+        last_variant = "big256x128,bf16";
+        hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 128, false, true>), grid, dim3(256), 0, st, p);
       } else if (tn == 256) hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((igemm_big_kernel<A_WGRAD, B_ROW, 128, false>), grid, dim3(256), 0, st, p);
       if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
