@@ -42,9 +42,11 @@ class RecordingRng(O.Rng):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("name", ["vp/CIFAR10/indm_nll", "ve/CIFAR10/indm"])
+@pytest.mark.parametrize("name", ["vp/CIFAR10/indm_nll", "ve/CIFAR10/indm", "vp/CELEBA/indm_fid"])
 def test_full_size_training_step_matches_oracle(name):
-    """vp: flow_step_fn_nll; ve: the two-phase flow_step_fn_fid with the FIR / Fourier-embedding NCSN++ (upfirdn2d)"""
+    """vp: flow_step_fn_nll; ve: the two-phase flow_step_fn_fid with the FIR / Fourier-embedding NCSN++ (upfirdn2d);
+    vp/CELEBA (BASELINE config #4 at PRODUCTION shapes): 64x64 images, flow.squeeze -> residual flow on 12 @ 32^2 and
+    48 @ 16^2 with the imagenet/64x64 wolf encoder, 5-level NCSN++ (ch_mult 1,1,2,2,2), two-phase fid step"""
     torch.manual_seed(7)
     np.random.seed(7)
     cfg = configs.get_config(name)
@@ -60,7 +62,7 @@ def test_full_size_training_step_matches_oracle(name):
                 p.copy_(torch.randn_like(p) * 0.02)
     sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
     sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
-    x = (torch.rand(2, 3, 32, 32) * 2 - 1)
+    x = (torch.rand(2, 3, cfg.data.image_size, cfg.data.image_size) * 2 - 1)
 
     ost = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, cfg)
     ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
@@ -174,3 +176,84 @@ def test_config5_deep_score_net_and_pc_sampler():
     assert rng.done() and got[2] == want[2]
     gu.assert_close(got[0], want[0], 5e-4, 5e-4, "config #5 pc before-flow latents")
     gu.assert_close(got[1], want[1], 3e-3, 3e-3, "config #5 pc samples")
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name", ["ve/CIFAR10/indm", "vp/CELEBA/indm_fid"])
+def test_bf16_mode_full_size_step_within_tolerance(name):
+    """BASELINE configs #3 / #4 ask for bf16 compute / fp32 accumulate.  One full-size training step in bf16 mode vs the
+    fp32 CPU oracle on the same weights and noise.  Stated tolerance: per-image losses within 3 % relative (+1e-2
+    absolute) -- bf16 carries 8 significant bits through ~60 chained contractions; parameters move by at most
+    2.2 * lr (AdamW's first step).  fp32 stays the parity gate and the headline."""
+    from indm_amd import hip
+    torch.manual_seed(9)
+    np.random.seed(9)
+    cfg = configs.get_config(name)
+    cfg.model.dropout = 0.0
+    cfg.training.batch_size = 2
+    dev = torch.device("cuda")
+    cfg.device = dev
+    score = utils.create_model(cfg, dev)
+    fl = create_flow_model(cfg).to(dev)
+    with torch.no_grad():
+        for n, p in score.named_parameters():
+            if p.dim() > 1 and p.abs().max() < 1e-6:
+                p.copy_(torch.randn_like(p) * 0.02)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
+    x = (torch.rand(2, 3, cfg.data.image_size, cfg.data.image_size) * 2 - 1)
+    ost = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, cfg)
+    ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    rec = RecordingRng()
+    want = O.flow_step_fn_fid(cfg, O.get_sde(cfg), ost, ofst, x, rec)
+    cfg.compute_dtype = "bf16"
+    try:
+        state, fstate, _ = utils.build_states(cfg, score, fl, dev)
+        step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+        assert hip.compute_dtype() == "bf16"
+        score.train(); fl.train()
+        rng = ReplayRng(rec.events, dev)
+        got = step_fn(state, fstate, x.to(dev), rng=rng)
+        assert rng.done()
+    finally:
+        hip.set_compute_dtype("f32")
+    for nm, a, b in zip(("loss", "score", "flow", "logp"), got, want):
+        assert torch.isfinite(a).all()
+        err = (a - b).abs().max().item()
+        assert err <= 3e-2 * b.abs().max().item() + 1e-2, (name, nm, a, b)
+    sf = fl.reference_state_dict(prefix="")
+    for k in list(ofst.trainable)[:: max(1, len(ofst.trainable) // 8)]:
+        assert (sf[k].cpu() - ofst.P[k].detach()).abs().max().item() <= 2.2 * cfg.flow.lr + 1e-6, k
+
+
+@pytest.mark.timeout(1500)
+def test_bf16_mode_nelbo_within_north_star_band():
+    """NELBO bits/dim of the full-size VP model in bf16 compute mode vs the fp32 CPU oracle on the same noise: the
+    north-star band is +-0.01 bits/dim."""
+    from indm_amd import hip
+    torch.manual_seed(13)
+    np.random.seed(13)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    dev = torch.device("cuda")
+    cfg.device = dev
+    score = utils.create_model(cfg, dev)
+    fl = create_flow_model(cfg).to(dev)
+    with torch.no_grad():
+        for n, p in score.named_parameters():
+            if p.dim() > 1 and p.abs().max() < 1e-6:
+                p.copy_(torch.randn_like(p) * 0.02)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
+    x = (torch.rand(2, 3, 32, 32) * 2 - 1)
+    rec = RecordingRng()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    want, _ = O.nelbo_fn(sd_s, sd_f, cfg, O.get_sde(cfg), x, rec)
+    score.eval(); fl.eval()
+    fn = likelihood.get_elbo_fn(cfg, sde_lib.get_sde(cfg), inverse_scaler=utils.get_data_inverse_scaler(cfg))
+    hip.set_compute_dtype("bf16")
+    try:
+        got, _ = fn(score, fl, x.to(dev), rng=ReplayRng(rec.events, dev))
+    finally:
+        hip.set_compute_dtype("f32")
+    assert (got.cpu() - want).abs().max().item() < 1e-2, (got, want)
