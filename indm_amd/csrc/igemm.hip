@@ -18,6 +18,7 @@
 #include "indm_common.h"
 #include "igemm_thin.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -1506,11 +1507,12 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if (am == A_COL && bm == B_ROW && ws) {
     // weight-grad GEMMs (tiny output, K = pixels): 256x256 big tiles, one block per CU, split-K sized to 256 blocks
     // (bf16 mode: 256 x 128 tiles, two blocks per CU -- the 256-wide register tile spills with the bf16 fragments)
-    const int tnw = p.bf16 ? 128 : 256;
+    // 256 x 128 tiles for N <= 256 outputs with M >= 512 ([32768,512]^T x [32768,256]: 140 -> 84 us)
+    const int tnw = (p.bf16 || (p.N <= 256 && p.M >= 512 && !p.G)) ? 128 : 256;
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, tnw) * p.batch;
     if (p.M >= 256 && p.N >= 256 && !(p.M & 3) && !(p.N & 3) && !(p.K & 15) && p.a_vec && p.b_vec &&
-        tiles <= (p.bf16 ? 128 : 64) && p.K >= 8192) {
-      long want = (p.bf16 ? 512 : 256) / tiles;
+        tiles <= (tnw == 128 ? 128 : 64) && p.K >= 8192 && !(tnw == 128 && !p.bf16 && p.G)) {
+      long want = (tnw == 128 ? 512 : 256) / tiles;
       while (want > 1 && (p.K / want < 512 || want * p.batch * p.M * p.N > ws_floats)) --want;
       // fewer than 128 blocks (e.g. the 256 x 256 NIN weight grads at K = 32768: 64 blocks, 31 TF) leave most of the
       // chip idle: those go to the 128 x 128 split-K path below
@@ -1523,6 +1525,9 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
         if (p.bf16) {
           if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 128, true, true>), grid, dim3(256), 0, st, p);
           else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 128, false, true>), grid, dim3(256), 0, st, p);
+        } else if (tnw == 128) {
+          last_variant = "big256x128";
+          hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 128, false>), grid, dim3(256), 0, st, p);
         } else if (p.G) hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_big_kernel<A_COL, B_ROW, 256, false>), grid, dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
@@ -1533,7 +1538,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     }
   }
   if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
-      p.K >= 16384) {
+      (p.K >= 16384 || (p.K >= 8192 && p.M >= 4096))) {  // (8x8 maps: 512-channel inputs only -- measured 245 -> 192 us)
     // convolution weight grads: same recipe on the implicit-GEMM A operand (256 x 256|128 tiles)
     const int tn = (p.N % 256 == 0 && !p.bf16) ? 256 : 128;
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, tn);
