@@ -1001,7 +1001,7 @@ __device__ __attribute__((aligned(16))) float indm_zero16[4] = {0.f, 0.f, 0.f, 0
 // bijection (lane-half, position) -> k is valid for an MFMA as long as both operands use the same one.)
 template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
-  static_assert(AM == A_ROW || AM == A_CONV, "k-contiguous A operands");
+  static_assert(AM == A_ROW || AM == A_CONV || AM == A_COL, "A_ROW / A_CONV: k-contiguous; A_COL: row-contiguous");
   static_assert(BK == 16, "written for 16-deep slabs");
   // NW = 4: waves 2 x 2 of 128 x 64;  NW = 8: waves 4 x 2 of 64 x 64 (four waves per SIMD with two blocks per CU)
   constexpr int TM = 256, TN = 128, WM = (NW == 8 ? 64 : 128), WN = 64, RM = WM / 32, RN = 2;
@@ -1070,6 +1070,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       pg[q] = HAS_G ? G + off : nullptr;
     }
   }
+  if constexpr (AM == A_COL) {  // A stored [K][M]: LDS image [16 k][256 m], one k-row (1 KB) per wave-instruction
+#pragma unroll
+    for (int q = 0; q < 16 / NW; ++q) {
+      const long off = (long)(kbeg + wave * (16 / NW) + q) * p.lda + min(m0 + 4 * lane, p.M - 4);
+      pa[q] = A + off;
+      pg[q] = HAS_G ? G + off : nullptr;
+    }
+  }
   if constexpr (BMODE == B_COL) {
 #pragma unroll
     for (int q = 0; q < 8 / NW; ++q) {
@@ -1116,6 +1124,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         if constexpr (HAS_G) {
           dma(pg[q], base + A_SZ + r0 * BK);
           pg[q] += BK;
+        }
+      } else if constexpr (AM == A_COL) {
+        const int kr = wave * (16 / NW) + q;
+        dma(pa[q], base + kr * TM);
+        pa[q] += (long)BK * p.lda;
+        if constexpr (HAS_G) {
+          dma(pg[q], base + A_SZ + kr * TM);
+          pg[q] += (long)BK * p.lda;
         }
       } else if (p.dil == 1) {  // block-uniform branch
         const bool ok = (unsigned)(ih0[q] + kh) < (unsigned)p.H && (unsigned)(iw0[q] + kw) < (unsigned)p.W;
@@ -1166,6 +1182,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     const int ch = ((sg * 2 + lhi) ^ swz) << 2;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
+      if constexpr (AM == A_COL) {  // [16 k][256 m]: k = 8 sg + 4 lhi + t, rows of TM floats
+        const float* q = as + (sg * 8 + lhi * 4) * TM + mw + i * 32 + l31;
+        fa[i] = make_float4(q[0], q[TM], q[2 * TM], q[3 * TM]);
+        if constexpr (HAS_G) {
+          const float* g = q + A_SZ;
+          fa[i].x *= g[0]; fa[i].y *= g[TM]; fa[i].z *= g[2 * TM]; fa[i].w *= g[3 * TM];
+        }
+        continue;
+      }
       const int o = (mw + i * 32 + l31) * BK + ch;
       if constexpr (HAS_G) {  // gate multiplied as two packed pairs (v_pk_mul_f32: half the VALU issue slots)
         const f32x4 av = *(const f32x4*)(as + o), gv = *(const f32x4*)(as + A_SZ + o);
@@ -1502,6 +1527,19 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     if (r != THIN_NA) {
       last_variant = name;
       return r;
+    }
+  }
+  if (am == A_COL && bm == B_ROW && ws && p.bf16 && p.batch == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.K >= 8192 &&
+      p.M >= 128 && p.N >= 128 && !(p.M & 3) && !(p.N & 3)) {
+    // bf16 mode: the weight-grad GEMMs are HBM streamers -- direct-to-LDS staging of the row-contiguous A (and its
+    // gate) keeps 16 waves per CU in flight without a register-staged prefetch (the gated big tile spills there)
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
+    long want = 512 / tiles;
+    while (want > 1 && (p.K / want < 16 * BK || want * p.M * p.N > ws_floats)) --want;
+    if (want > 1) {
+      p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
+      p.splitk = cdiv(p.K, p.kps);
+      return p.G ? launch_glds<A_COL, B_ROW, true, 8>(p, st) : launch_glds<A_COL, B_ROW, false, 8>(p, st);
     }
   }
   if (am == A_COL && bm == B_ROW && ws) {
