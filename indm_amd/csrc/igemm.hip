@@ -1012,10 +1012,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: LDS destinations of the DMA stay in SGPRs
   const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TN - 1) / TN;
-  const int lt = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // 1-D grid over (tile, batch x split-K slice); the XCD-aware remap runs over the COMBINED index so that the tiles of
+  // one K-slice -- which share their A / B panels -- are neighbours on one XCD's L2 (a 2-D grid put the 8 tiles of
+  // a slice on 8 different XCDs: every panel streamed from HBM once per tile, 4x / 2x the traffic of a bf16 wgrad)
+  const int ntile = tiles_m * tiles_n;
+  const int lg = xcd_remap(blockIdx.x, ntile * p.batch * p.splitk);
+  const int z = lg / ntile, lt = lg - z * ntile;
   const int tm = lt / tiles_n, tn = lt - tm * tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
-  const int z = blockIdx.y;
   const int bz = z / p.splitk, kz = z - bz * p.splitk;
   const float* A = p.A + (long)bz * p.sA;
   const float* G = HAS_G ? p.G + (long)bz * p.sA : nullptr;
@@ -1184,20 +1188,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     for (int i = 0; i < RM; ++i) {
       if constexpr (AM == A_COL) {  // [16 k][256 m]: k = 8 sg + 4 lhi + t, rows of TM floats
         const float* q = as + (sg * 8 + lhi * 4) * TM + mw + i * 32 + l31;
-        fa[i] = make_float4(q[0], q[TM], q[2 * TM], q[3 * TM]);
+        float4 v = make_float4(q[0], q[TM], q[2 * TM], q[3 * TM]);
         if constexpr (HAS_G) {
           const float* g = q + A_SZ;
-          fa[i].x *= g[0]; fa[i].y *= g[TM]; fa[i].z *= g[2 * TM]; fa[i].w *= g[3 * TM];
+          v.x *= g[0]; v.y *= g[TM]; v.z *= g[2 * TM]; v.w *= g[3 * TM];
         }
-        continue;
-      }
-      const int o = (mw + i * 32 + l31) * BK + ch;
-      if constexpr (HAS_G) {  // gate multiplied as two packed pairs (v_pk_mul_f32: half the VALU issue slots)
-        const f32x4 av = *(const f32x4*)(as + o), gv = *(const f32x4*)(as + A_SZ + o);
-        const f32x2 lo = pk_mul_f32(av.lo, gv.lo), hi = pk_mul_f32(av.hi, gv.hi);
-        fa[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        fa[i] = v;
       } else {
-        fa[i] = *(const float4*)(as + o);
+        const int o = (mw + i * 32 + l31) * BK + ch;
+        if constexpr (HAS_G) {  // gate multiplied as two packed pairs (v_pk_mul_f32: half the VALU issue slots)
+          const f32x4 av = *(const f32x4*)(as + o), gv = *(const f32x4*)(as + A_SZ + o);
+          const f32x2 lo = pk_mul_f32(av.lo, gv.lo), hi = pk_mul_f32(av.hi, gv.hi);
+          fa[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+          fa[i] = *(const float4*)(as + o);
+        }
       }
     }
 #pragma unroll
@@ -1240,18 +1245,61 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     for (int s = 0; s < nk; ++s) {
       const int buf = s & 1;
       if (s + 1 < nk) stage(buf ^ 1, s + 1);
-      frags(buf, 0, fa0, fb0);
-      frags(buf, 1, fa1, fb1);
+      // operand by operand: read the two 4-deep fragments, (gate,) round and pack at once -- short live ranges (the
+      // generic frags() + pack kept 2 x (RM + RN) float4 alive and spilled an accumulator in the gated A_COL variant)
       bf16x8 ha[RM], hb[RN];
+      {
 #pragma unroll
-      for (int i = 0; i < RM; ++i) ha[i] = pack(fa0[i], fa1[i]);
+        for (int i = 0; i < RM; ++i) {
+          const float* as = glds_smem + buf * BUF;
+          float4 lo, hi;
+          if constexpr (AM == A_COL) {
+            const float* q = as + (lhi * 4) * TM + mw + i * 32 + l31;
+            lo = make_float4(q[0], q[TM], q[2 * TM], q[3 * TM]);
+            hi = make_float4(q[8 * TM], q[9 * TM], q[10 * TM], q[11 * TM]);
+            if constexpr (HAS_G) {
+              const float* g = q + A_SZ;
+              lo.x *= g[0]; lo.y *= g[TM]; lo.z *= g[2 * TM]; lo.w *= g[3 * TM];
+              hi.x *= g[8 * TM]; hi.y *= g[9 * TM]; hi.z *= g[10 * TM]; hi.w *= g[11 * TM];
+            }
+          } else {
+            const int o = (mw + i * 32 + l31) * BK;
+            const int c0 = (lhi ^ swz) << 2, c1 = ((2 + lhi) ^ swz) << 2;
+            lo = *(const float4*)(as + o + c0);
+            hi = *(const float4*)(as + o + c1);
+            if constexpr (HAS_G) {
+              const float4 g0 = *(const float4*)(as + A_SZ + o + c0), g1 = *(const float4*)(as + A_SZ + o + c1);
+              lo.x *= g0.x; lo.y *= g0.y; lo.z *= g0.z; lo.w *= g0.w;
+              hi.x *= g1.x; hi.y *= g1.y; hi.z *= g1.z; hi.w *= g1.w;
+            }
+          }
+          ha[i] = pack(lo, hi);
+          if constexpr (AM == A_COL && HAS_G) __builtin_amdgcn_sched_barrier(0);  // one operand's reads at a time: <= 128 VGPRs
+        }
 #pragma unroll
-      for (int j = 0; j < RN; ++j) hb[j] = pack(fb0[j], fb1[j]);
+        for (int j = 0; j < RN; ++j) {
+          const float* bs = glds_smem + buf * BUF + A_SZ + G_SZ;
+          float4 lo, hi;
+          if constexpr (BKC) {
+            const int o = (nw + j * 32 + l31) * BK;
+            lo = *(const float4*)(bs + o + ((lhi ^ swz) << 2));
+            hi = *(const float4*)(bs + o + (((2 + lhi) ^ swz) << 2));
+          } else {
+            const float* q = bs + (lhi * 4) * TN + nw + j * 32 + l31;
+            lo = make_float4(q[0], q[TN], q[2 * TN], q[3 * TN]);
+            hi = make_float4(q[8 * TN], q[9 * TN], q[10 * TN], q[11 * TN]);
+          }
+          hb[j] = pack(lo, hi);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < RM; ++i)
 #pragma unroll
         for (int j = 0; j < RN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+      // keep the MFMAs on this side of the barrier: hipcc otherwise sinks three of the four below it and then
+      // rotates the 64 accumulator registers with v_mov every iteration (and spills in the gated A_COL variant)
+      __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -1336,7 +1384,7 @@ int launch_glds_t(const IgemmParams& p, hipStream_t st) {
       return INDM_E_LAUNCH;
     ready = true;
   }
-  dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128), p.batch * p.splitk);
+  dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch * p.splitk);
   if (BF16)
     last_variant = HAS_G ? (p.splitk > 1 ? "glds256x128,splitk,gated,bf16" : "glds256x128,gated,bf16")
                          : (p.splitk > 1 ? "glds256x128,splitk,bf16" : "glds256x128,bf16");

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hn[i], hm[j], acc[i][j], 0, 0, 0);  // D[n][m]
+      __builtin_amdgcn_sched_barrier(0);  // (MFMAs stay above the barrier: no accumulator rotation, see igemm.hip)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
