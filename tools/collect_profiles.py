@@ -1,5 +1,5 @@
 """Turn the raw output of tools/measure_round.sh (gpurun_out/final_*) into the committed summaries under profiles/.
-usage: python tools/collect_profiles.py <tag>     e.g. r01_final"""
+usage: python tools/collect_profiles.py <tag>     e.g. r02_final"""
 import csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +24,9 @@ bmode = {"B_ROW": 0, "B_COL": 1, "B_DGRAD": 2}
 parts = key[len("igemm<"):-1].split(",")
 sub = None
 if parts[2].startswith("glds"):
-    sub = f"igemm_glds_kernel<{amode[parts[0]]}, {bmode[parts[1]]}, {'true' if 'gated' in parts else 'false'}, 8>"
+    sub = f"igemm_glds_kernel<{amode[parts[0]]}, {bmode[parts[1]]}, {'true' if 'gated' in parts else 'false'}, 8, false>"
+elif parts[2].startswith("ires_chain"):
+    sub = "ires_chain_kernel<"      # both instantiations (J <= 32 at scale 0, J <= 128 at scale 1) form the bench class
 out = {"kernel": f"{sub} = {key}", "bench_key": key,
        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
                   "--no-cpu-baseline (tools/measure_round.sh)"}
@@ -35,7 +37,7 @@ for name, d in (("FETCH_SIZE", "final_fetch"), ("WRITE_SIZE", "final_write")):
     # ("...,splitk,gated"): keep only launches with >= 512 workgroups, i.e. the class bench.py reports
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
          if sub and sub in r["Kernel_Name"] and r["Counter_Name"] == name
-         and int(r["Grid_Size"]) // int(r["Workgroup_Size"]) >= 512]
+         and int(r["Grid_Size"]) // int(r["Workgroup_Size"]) >= 512 and ", true>" not in r["Kernel_Name"].split("ires_chain_kernel")[-1][:12]]
     vals[name] = sum(v) / max(1, len(v))
     out["launches"] = len(v)
     out[f"{name}_KB_per_launch"] = vals[name]

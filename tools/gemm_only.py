@@ -1,5 +1,6 @@
 """Run a few launches of one contraction shape (for rocprofv3 --pmc).  usage: gemm_only.py MODE [M N K]
-MODE: nn | nt | ntg | nng (igemm; g = gated), vnn | vnt (vendor torch.matmul, reference point only), conv"""
+MODE: nn | nt | ntg | nng (igemm; g = gated), vnn | vnt (vendor torch.matmul, reference point only), conv,
+chain (the back-to-back VJP-chain kernel at M = 131072, J = 27)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,8 +11,13 @@ a, w = torch.randn(M, K, device="cuda"), torch.randn(K, N, device="cuda")
 wt = w.t().contiguous()
 g_ = torch.randn(M, K, device="cuda")
 x, cw = torch.randn(128, 32, 32, 128, device="cuda"), torch.randn(3, 3, 128, 128, device="cuda")
+d1 = torch.randn(M, 512, device="cuda") if mode == "chain" else None
+w1p = torch.zeros(512, 32, device="cuda")
+w1p[:, :27] = torch.randn(512, 27, device="cuda") / 22.6
 for _ in range(5):
-    if mode == "nn":
+    if mode == "chain":
+        hip.ires_chain(a, g_, w, d1, w1p, 27)
+    elif mode == "nn":
         hip.gemm(a, w)
     elif mode == "nt":
         hip.gemm(a, wt, trans_b=True)
