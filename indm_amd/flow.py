@@ -227,7 +227,9 @@ class _IResTrain(torch.autograd.Function):
         p1 = hip.conv2d(a0, W1, bias=b1)
         a1, d1 = hip.sincos_fwd(p1, True)
         del p1
-        p2 = hip.gemm(a1.view(-1, Cw), W2, bias=b2, bias2=cb, rows_per_group=H * Wd)
+        # a1 W2 through the transposed copy ([N, K] weight form: the ungated direct-to-LDS kernel runs 125 TF on it
+        # against 109 TF on the [K, N] form; the gated one prefers [K, N])
+        p2 = hip.gemm(a1.view(-1, Cw), W2T, trans_b=True, bias=b2, bias2=cb, rows_per_group=H * Wd)
         a2, d2 = hip.sincos_fwd(p2.view(N, H, Wd, -1), True)
         del p2
         g = hip.conv2d(a2, W3, bias=b3)
