@@ -167,12 +167,13 @@ int indm_attn_bwd_f32(const float* q, const float* k, const float* v, const floa
                       const float* Dv, float* dq, float* dk, float* dv, int B, int T, int C, float scale, void* stream);
 /* Back-to-back contraction of one link pair of the VJP chain: P[M, J] = ((A .* G) W2T .* D1) W1p[:, :J] with the
  * 512-wide intermediate kept on chip (A, G: [M, K]; W2T: [K, 512] row-major; D1: [M, 512]; W1p: [512, 32 if J <= 32 else 128]
- * zero-padded; J = 9*C <= 128).  Returns 1 if the geometry is not covered (M % 64, K % 16, N != 512): the caller then
+ * zero-padded; J = 9*C <= 128; T2 optional [M, 512]: also stores the intermediate (A .* G) W2T, which the
+ * gradient-carrying chain needs in its backward).  Returns 1 if the geometry is not covered (M % 64, K % 16, N != 512): the caller then
  * runs indm_gemm_f32 twice.  Replaces two torch.autograd.grad links of iresblock.py:257,269. */
 int indm_ires_chain_f32(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p, float* P,
-                        int M, int K, int N, int J, void* stream);
+                        float* T2, int M, int K, int N, int J, void* stream);
 int indm_ires_chain_bf16(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p, float* P,
-                         int M, int K, int N, int J, void* stream);
+                         float* T2, int M, int K, int N, int J, void* stream);
 long indm_ires_bwd_act_ws_floats(long R, int C);
 int indm_ires_bwd_act_f32(const float* da, const float* du, const float* d, const float* a, const float* t, float* dp,
                           float* dt_out, float* seg_out, long R, int C, long rows_per_seg, float* ws, void* stream);

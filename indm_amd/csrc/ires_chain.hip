@@ -32,6 +32,8 @@ struct ChainArgs {
   const float* W1p;  // [512, 32*JB] row-major, zero-padded beyond J
   float* P;          // [M, J]
   int M, K, J;
+  float* T2;         // optional [M, 512]: the intermediate (t3 .* d2) W2T BEFORE the d1 gate (the gradient-carrying
+                     // chain needs it in its backward)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -163,6 +165,18 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   mfmas(fm1, fn1);
   }
 
+  if (p.T2) {  // uniform: 16-byte pieces, a 128-byte row segment is completed by four stores of the same wave
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* trow = p.T2 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          *(float4*)(trow + i * 32 + 8 * a) =
+              make_float4(acc[i][j][4 * a], acc[i][j][4 * a + 1], acc[i][j][4 * a + 2], acc[i][j][4 * a + 3]);
+    }
+  }
   // ---- gate: acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi]  *=  d1[m][n] ----
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -256,16 +270,16 @@ int launch_chain(const ChainArgs& p, hipStream_t st) {
 
 }  // namespace
 
-// P[M, J] = ((A .* G) W2T .* D1) W1p[:, :J]   with A, G: [M, K]; W2T: [K, 512]; D1: [M, 512]; W1p: [512, 32 if J <= 32 else 128]
+// P[M, J] = ((A .* G) W2T .* D1) W1p[:, :J]  (and, if T2 != NULL, T2[M, 512] = (A .* G) W2T)  with A, G: [M, K]; W2T: [K, 512]; D1: [M, 512]; W1p: [512, 32 if J <= 32 else 128]
 // (zero-padded columns).  Requirements: M % 64 == 0, K % 16 == 0, K >= 32, J <= 128, 16-byte aligned pointers.
 // Returns 1 when the geometry is not covered (the caller then runs the two contractions separately).
 static int ires_chain_impl(bool bf16, const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
-                           float* P, int M, int K, int N, int J, void* stream) {
+                           float* P, float* T2, int M, int K, int N, int J, void* stream) {
   if (M < 0 || K <= 0 || N <= 0 || J <= 0) return INDM_E_SHAPE;
   if (M == 0) return INDM_OK;
   if (N != TN || (M % TM) || (K % BK) || K < 2 * BK || J > 128) return 1;
-  if (((uintptr_t)A | (uintptr_t)G | (uintptr_t)W2T | (uintptr_t)D1 | (uintptr_t)W1p) & 15) return 1;
-  ChainArgs p = {A, G, W2T, D1, W1p, P, M, K, J};
+  if (((uintptr_t)A | (uintptr_t)G | (uintptr_t)W2T | (uintptr_t)D1 | (uintptr_t)W1p | (uintptr_t)T2) & 15) return 1;
+  ChainArgs p = {A, G, W2T, D1, W1p, P, M, K, J, T2};
   hipStream_t st = (hipStream_t)stream;
   // two instantiations: J <= 32 (the 3-channel scale: 27) and J <= 128 (the 12- / 48-channel scales: 108); W1p is
   // padded to 32 / 128 columns accordingly
@@ -273,11 +287,11 @@ static int ires_chain_impl(bool bf16, const float* A, const float* G, const floa
   return J <= 32 ? launch_chain<1, false>(p, st) : launch_chain<4, false>(p, st);
 }
 INDM_API int indm_ires_chain_f32(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
-                                 float* P, int M, int K, int N, int J, void* stream) {
-  return ires_chain_impl(false, A, G, W2T, D1, W1p, P, M, K, N, J, stream);
+                                 float* P, float* T2, int M, int K, int N, int J, void* stream) {
+  return ires_chain_impl(false, A, G, W2T, D1, W1p, P, T2, M, K, N, J, stream);
 }
 // same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
 INDM_API int indm_ires_chain_bf16(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
-                                  float* P, int M, int K, int N, int J, void* stream) {
-  return ires_chain_impl(true, A, G, W2T, D1, W1p, P, M, K, N, J, stream);
+                                  float* P, float* T2, int M, int K, int N, int J, void* stream) {
+  return ires_chain_impl(true, A, G, W2T, D1, W1p, P, T2, M, K, N, J, stream);
 }

@@ -239,8 +239,18 @@ class _IResTrain(torch.autograd.Function):
         for c in coeffs:                                   # v_k = J^T v_{k-1};  w = eps + sum (-1)^k c_k v_k
             v, w = blk.vjp_acc(v, Ws, gates, hw, w, c)
         t3 = hip.conv2d_dgrad(w, W3, hw)
-        t2 = hip.gemm(t3.view(-1, Cw), W2T, gate=d2.view(-1, Cw)).view(N, H, Wd, -1)
-        c1 = hip.conv2d_dgrad(t2, W1, hw, gate=d1)
+        Ci = W1.shape[2]
+        pt = None
+        if panel is not None and hip._skinny(3, 3, 1, 1, Ci, W1.shape[3]):
+            # the gradient-carrying chain on the back-to-back kernel too: it stores t2 (its backward needs it) from the
+            # accumulators and still skips the gated re-read of t2 and d1 by a separate thin-N launch
+            pt = hip.ires_chain(t3.view(-1, Cw), d2.view(-1, Cw), W2T, d1.view(-1, Cw), panel, 9 * Ci, want_t2=True)
+        if pt is not None:
+            t2 = pt[1].view(N, H, Wd, -1)
+            c1 = hip.tap_gather(pt[0].view(N, H, Wd, 9 * Ci), None, -1)
+        else:
+            t2 = hip.gemm(t3.view(-1, Cw), W2T, gate=d2.view(-1, Cw)).view(N, H, Wd, -1)
+            c1 = hip.conv2d_dgrad(t2, W1, hw, gate=d1)
         vj = hip.mul(c1, d0) if blk.preact else c1
         logdet = hip.rowreduce(vj, eps, 0)
         ctx.save_for_backward(a0, d0, a1, d1, a2, d2, t3, t2, c1 if blk.preact else None, w, eps, W1, W2, W3, W2T)

@@ -59,8 +59,8 @@ _SIGS = {
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_attn_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "indm_attn_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
-    "indm_ires_chain_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "indm_ires_chain_bf16": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "indm_ires_chain_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "indm_ires_chain_bf16": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_ires_bwd_act_ws_floats": [c_l, c_i],
     "indm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p],
     "indm_act_fwd_f32": [c_p, c_p, c_l, c_i, c_p],
@@ -613,21 +613,24 @@ def attn_bwd(q, k, v, h, dh, lse, scale):
     return dq, dk, dv
 
 
-def ires_chain(t3, d2, w2t, d1, w1p, J):
+def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
     """P[M, J] = ((t3 .* d2) @ w2t .* d1) @ w1p[:, :J] in ONE launch with the 512-wide intermediate kept on chip (the
     back-to-back contraction of the VJP chain).  t3, d2: [M, K]; w2t: [K, 512]; d1: [M, 512]; w1p: [512, 32 if J <= 32 else 128] (zero-padded).
+    want_t2: also return t2 = (t3 .* d2) @ w2t ([M, 512], stored from the accumulators): -> (P, t2).
     Returns None when the kernel does not cover the geometry: the caller runs the two GEMMs."""
     M, K = t3.shape
     N = w2t.shape[1]
     P = torch.empty((M, J), dtype=torch.float32, device=t3.device)
+    t2 = torch.empty((M, N), dtype=torch.float32, device=t3.device) if want_t2 else None
     with _timed("A_ROW", "B_ROW", M, N, K, nbytes=4 * (2 * t3.numel() + d1.numel() + w2t.numel() + P.numel())) as tm:
-        st = _dense("ires_chain")(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), M, K, N, J, _stream())
+        st = _dense("ires_chain")(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), _ptr(t2), M, K, N, J,
+                                  _stream())
         tm.variant = "ires_chain64x512,gated" + (",bf16" if _MFMA["dtype"] == "bf16" else "")
         tm.flops += 2.0 * M * N * w1p.shape[1]
     if st == 1:
         return None
     _chk(st, "indm_ires_chain_f32")
-    return P
+    return (P, t2) if want_t2 else P
 
 
 def ires_bwd_act(da, du, d, a, t, want_dt=False, rows_per_seg=None):

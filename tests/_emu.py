@@ -132,8 +132,10 @@ def attn_bwd(q, k, v, h, dh, lse, scale):
     return torch.matmul(ds, k).contiguous(), torch.matmul(ds.transpose(1, 2), q).contiguous(), dv.contiguous()
 
 
-def ires_chain(t3, d2, w2t, d1, w1p, J):
-    return ((((t3 * d2) @ w2t) * d1) @ w1p[:, :J]).contiguous()
+def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
+    t2 = (t3 * d2) @ w2t
+    P = ((t2 * d1) @ w1p[:, :J]).contiguous()
+    return (P, t2.contiguous()) if want_t2 else P
 
 
 def ires_bwd_act(da, du, d, a, t, want_dt=False, rows_per_seg=None):

@@ -675,6 +675,9 @@ def test_ires_chain_back_to_back(M, K, J):
     out, ref = run_both("ires_chain", t3, d2, w2t, d1, w1p, J)
     assert out is not None and out.shape == (M, J)
     close(out, ref, rtol=2e-5, atol=2e-5, name="ires_chain")
+    (out, t2), (ref, t2ref) = run_both("ires_chain", t3, d2, w2t, d1, w1p, J, want_t2=True)   # variant that also stores t2
+    close(out, ref, rtol=2e-5, atol=2e-5, name="ires_chain (t2 variant) P")
+    close(t2, t2ref, rtol=2e-5, atol=2e-5, name="ires_chain t2")
     # geometry the kernel does not cover -> None (the caller falls back to two GEMMs)
     assert hip.ires_chain(t3[:M - 1].contiguous().to(DEV), d2[:M - 1].contiguous().to(DEV), w2t.to(DEV),
                           d1[:M - 1].contiguous().to(DEV), w1p.to(DEV), J) is None
