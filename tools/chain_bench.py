@@ -39,9 +39,13 @@ for M, J in ((131072, 27), (32768, 108)):
     def fused():
         return hip.ires_chain(t3, d2, w2t, d1, w1p, J)
 
+    def fused_t2():
+        return hip.ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=True)
+
     a, b = separate(), fused()
     err = (a - b).abs().max().item() / a.abs().max().item()
     us_s, us_f = timeit(separate), timeit(fused)
+    print(f"   fused + t2 store: {timeit(fused_t2):.0f} us")
     fl = 2.0 * M * 512 * (512 + J)
     print(f"M={M} J={J}: separate {us_s:.0f} us ({fl / us_s / 1e6:.1f} TF)  fused {us_f:.0f} us ({fl / us_f / 1e6:.1f} TF)  "
           f"rel diff {err:.2e}")
