@@ -228,6 +228,13 @@ int indm_slogdet_inv_f32(const float* W, int n, float* logdet, float* inv, void*
 
 /* ---- SDE / loss / sampler / optimiser --------------------------------------------------------------------- */
 
+/* Affine coupling of the 64-d prior flow (NICE1d + Affine: flows/couplings/coupling.py:13-177, transform.py:49-81): split,
+ * transform (scale = sigmoid(ls + 2) + 1e-3; inverse divides by scale + 1e-12), recombination and log-det row sum in one
+ * launch.  x, y, prm = (mu | ls): [B, 2F]; logdet: [B]; split 0 continuous / 1 skip; up, inverse: 0/1. */
+int indm_coupling_fwd_f32(const float* x, const float* prm, float* y, float* logdet, int B, int F, int split, int up,
+                          int inverse, void* stream);
+int indm_coupling_bwd_f32(const float* dy, const float* dlogdet, const float* x, const float* prm, float* dx, float* dprm,
+                          int B, int F, int split, int up, int inverse, void* stream);
 /* Standard-normal noise on the device (Philox4x32-10 + Box-Muller); replaces the torch.randn / randn_like calls of
  * losses.py:103, sampling.py:196,209,283 and iresblock.py:137.  `state` points to {seed, offset} (two uint64) in device
  * memory; the launch advances offset by ceil(n/4), so a captured hipGraph of a sampler step draws fresh noise per replay. */

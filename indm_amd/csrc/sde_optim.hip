@@ -196,6 +196,95 @@ __global__ __launch_bounds__(64) void slogdet_inv_kernel(const float* __restrict
 }  // namespace
 
 // out[b,:] = mc[b]*x[b,:] + sd[b]*noise[b,:]   (noise / sd may be null -> pure scaling)
+// ---- affine coupling of the 64-d prior flow (NICE1d + Affine: flows/couplings/coupling.py:13-177, transform.py:49-81) ----
+// x [B, D] is split into (z, zp): 'continuous' = halves, 'skip' = even / odd features; `up` picks which half conditions
+// the other.  params [B, 2F] = (mu | log-scale) come from the MLP on z (three small GEMMs of the caller).
+//   scale = sigmoid(ls + 2) + 1e-3
+//   forward : zp' = scale*zp + mu,            logdet[b] =  sum_f log scale          (transform.py:57-66)
+//   inverse : zp' = (zp - mu)/(scale + 1e-12), logdet[b] = -sum_f log scale          (transform.py:68-76)
+// One wavefront per row: split, transform, recombination and the log-det row sum in one launch (round 1: ~10 ATen
+// elementwise kernels per coupling and direction).
+namespace {
+__device__ __forceinline__ void coupling_idx(int f, int F, int split, int up, int& iz, int& izp) {
+  if (split == 0) {  // continuous: z1 = x[:F], z2 = x[F:]
+    izp = up ? F + f : f;
+    iz = up ? f : F + f;
+  } else {           // skip: z1 = even, z2 = odd
+    izp = up ? 2 * f + 1 : 2 * f;
+    iz = up ? 2 * f : 2 * f + 1;
+  }
+}
+__global__ __launch_bounds__(64) void coupling_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm,
+                                                          float* __restrict__ y, float* __restrict__ logdet, int B, int F,
+                                                          int split, int up, int inverse) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float ld = 0.f;
+  for (int f = lane; f < F; f += 64) {
+    int iz, izp;
+    coupling_idx(f, F, split, up, iz, izp);
+    const float mu = prm[(long)b * 2 * F + f], ls = prm[(long)b * 2 * F + F + f];
+    const float sc = 1.f / (1.f + expf(-(ls + 2.f))) + 1e-3f;
+    const float zp = x[(long)b * 2 * F + izp];
+    y[(long)b * 2 * F + izp] = inverse ? (zp - mu) / (sc + 1e-12f) : sc * zp + mu;
+    y[(long)b * 2 * F + iz] = x[(long)b * 2 * F + iz];
+    ld += logf(sc);
+  }
+  ld = wave_sum(ld);
+  if (lane == 0) logdet[b] = inverse ? -ld : ld;
+}
+__global__ __launch_bounds__(64) void coupling_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dld,
+                                                          const float* __restrict__ x, const float* __restrict__ prm,
+                                                          float* __restrict__ dx, float* __restrict__ dprm, int B, int F,
+                                                          int split, int up, int inverse) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float gl = dld ? dld[b] : 0.f;
+  for (int f = lane; f < F; f += 64) {
+    int iz, izp;
+    coupling_idx(f, F, split, up, iz, izp);
+    const float mu = prm[(long)b * 2 * F + f], ls = prm[(long)b * 2 * F + F + f];
+    const float sg = 1.f / (1.f + expf(-(ls + 2.f)));
+    const float sc = sg + 1e-3f;
+    const float zp = x[(long)b * 2 * F + izp];
+    const float g = dy[(long)b * 2 * F + izp];
+    float dzp, dmu, dsc;
+    if (!inverse) {
+      dzp = g * sc;
+      dmu = g;
+      dsc = g * zp + gl / sc;
+    } else {
+      const float q = 1.f / (sc + 1e-12f);
+      dzp = g * q;
+      dmu = -g * q;
+      dsc = -g * (zp - mu) * q * q - gl / sc;
+    }
+    dx[(long)b * 2 * F + izp] = dzp;
+    dx[(long)b * 2 * F + iz] = dy[(long)b * 2 * F + iz];
+    dprm[(long)b * 2 * F + f] = dmu;
+    dprm[(long)b * 2 * F + F + f] = dsc * sg * (1.f - sg);
+  }
+}
+}  // namespace
+
+// x, y: [B, 2F]; prm: [B, 2F] = (mu | ls); logdet: [B].  split 0 continuous / 1 skip; up 0/1; inverse 0/1.
+INDM_API int indm_coupling_fwd_f32(const float* x, const float* prm, float* y, float* logdet, int B, int F, int split,
+                                   int up, int inverse, void* stream) {
+  if (B < 0 || F <= 0) return INDM_E_SHAPE;
+  if (B == 0) return INDM_OK;
+  hipLaunchKernelGGL(coupling_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, x, prm, y, logdet, B, F, split, up,
+                     inverse);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+// gradient of (y, logdet) w.r.t. (x, prm): dy [B, 2F], dlogdet [B] (may be NULL) -> dx [B, 2F] (the conditioning half
+// passes dy through; the MLP's contribution arrives through dprm), dprm [B, 2F].
+INDM_API int indm_coupling_bwd_f32(const float* dy, const float* dlogdet, const float* x, const float* prm, float* dx,
+                                   float* dprm, int B, int F, int split, int up, int inverse, void* stream) {
+  if (B < 0 || F <= 0) return INDM_E_SHAPE;
+  if (B == 0) return INDM_OK;
+  hipLaunchKernelGGL(coupling_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dy, dlogdet, x, prm, dx, dprm, B, F,
+                     split, up, inverse);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
 // Standard-normal noise from a counter-based generator (Philox4x32-10 + Box-Muller): out[4i..4i+3] come from counter
 // (offset + i) under key `seed`.  `state` = {seed, offset} lives in DEVICE memory and the offset is advanced by the
 // launch itself (a second, one-thread kernel in stream order), so a captured hipGraph of a sampler step draws fresh

@@ -566,25 +566,18 @@ class NICE1d(nn.Module):
         self.net = NICEMLPBlock(in_f, out_f * 2, hidden)
 
     def _run(self, x, backward):
-        d = x.shape[-1]
+        """x: [B, 1, D] (the reference's 3-D latent).  The conditioning half goes through the MLP (three small GEMMs);
+        split / affine transform / recombination / log-det are ONE fused launch (indm_coupling_*)."""
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
         if self.split_type == "continuous":
-            z1, z2 = x[..., :self.z1_features], x[..., self.z1_features:]
+            z1, z2 = x2[:, :self.z1_features], x2[:, self.z1_features:]
         else:
-            z1, z2 = x[..., 0::2], x[..., 1::2]
-        z, zp = (z1, z2) if self.up else (z2, z1)
+            z1, z2 = x2[:, 0::2], x2[:, 1::2]
+        z = z1 if self.up else z2
         params = self.net(z.contiguous())
-        mu, ls = params.chunk(2, dim=-1)
-        scale = torch.sigmoid(ls + 2.0) + 1e-3
-        if not backward:
-            zp = scale * zp + mu
-            logdet = scale.log().reshape(x.shape[0], -1).sum(1)
-        else:
-            zp = (zp - mu) / (scale + 1e-12)
-            logdet = -scale.log().reshape(x.shape[0], -1).sum(1)
-        z1, z2 = (z, zp) if self.up else (zp, z)
-        if self.split_type == "continuous":
-            return torch.cat([z1, z2], dim=-1), logdet
-        return torch.stack([z1, z2], dim=-1).reshape(x.shape), logdet
+        y, logdet = ops.coupling(x2, params, 0 if self.split_type == "continuous" else 1, self.up, backward)
+        return y.reshape(shp), logdet.reshape(shp[0], -1).sum(1)
 
 
 class ActNorm1dFlow(nn.Module):

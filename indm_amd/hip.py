@@ -82,6 +82,8 @@ _SIGS = {
     "indm_lop_normalize_multi_fwd_f32": [c_p, c_i, c_i, c_l, c_f, c_p],
     "indm_lop_normalize_multi_bwd_f32": [c_p, c_p, c_i, c_i, c_l, c_f, c_p],
     "indm_philox_randn_f32": [c_p, c_l, c_p, c_p],
+    "indm_coupling_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "indm_coupling_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_sde_perturb_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
     "indm_dsm_ws_floats": [c_l, c_l],
     "indm_dsm_loss_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p],
@@ -840,6 +842,24 @@ def lop_normalize_multi_bwd(dwns, ws, l1s, coeff):
 
 
 # --------------------------------------------------------------------------- SDE / loss / sampler / optimiser
+def coupling_fwd(x, prm, split, up, inverse):
+    """Affine coupling of the prior flow on [B, 2F] rows -> (y, logdet[B]); split 0 continuous / 1 skip."""
+    B, D = x.shape
+    y = torch.empty_like(x)
+    ld = torch.empty((B,), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_coupling_fwd_f32(_ptr(x), _ptr(prm), _ptr(y), _ptr(ld), B, D // 2, int(split), int(up), int(inverse),
+                                     _stream()), "indm_coupling_fwd_f32")
+    return y, ld
+
+
+def coupling_bwd(dy, dld, x, prm, split, up, inverse):
+    B, D = x.shape
+    dx, dprm = torch.empty_like(x), torch.empty_like(prm)
+    _chk(lib().indm_coupling_bwd_f32(_ptr(dy), _ptr(dld), _ptr(x), _ptr(prm), _ptr(dx), _ptr(dprm), B, D // 2, int(split),
+                                     int(up), int(inverse), _stream()), "indm_coupling_bwd_f32")
+    return dx, dprm
+
+
 def philox_state(seed, device):
     """{seed, offset = 0} as an int64[2] device tensor (the generator state of philox_randn)."""
     return torch.tensor([int(seed) & ((1 << 63) - 1), 0], dtype=torch.int64).to(device)

@@ -253,6 +253,29 @@ def softmax(x, scale=1.0):
     return _Softmax.apply(x, scale)
 
 
+class _Coupling(Function):
+    """Affine coupling of the prior flow: (y, logdet) from x [B, 2F] and the MLP's params [B, 2F] (one launch each way)."""
+
+    @staticmethod
+    def forward(ctx, x, prm, split, up, inverse):
+        x, prm = _c(x), _c(prm)
+        ctx.save_for_backward(x, prm)
+        ctx.cfg = (split, up, inverse)
+        return hip.coupling_fwd(x, prm, split, up, inverse)
+
+    @staticmethod
+    def backward(ctx, dy, dld):
+        x, prm = ctx.saved_tensors
+        split, up, inverse = ctx.cfg
+        dy = torch.zeros_like(x) if dy is None else _c(dy)
+        dx, dprm = hip.coupling_bwd(dy, None if dld is None else _c(dld), x, prm, split, up, inverse)
+        return dx, dprm, None, None, None
+
+
+def coupling(x, prm, split, up, inverse):
+    return _Coupling.apply(x, prm, split, up, inverse)
+
+
 class _Attention(Function):
     """h = softmax(q k^T * scale) v, fused (the [T,T] logits never reach HBM; recomputed in registers in the backward)."""
 

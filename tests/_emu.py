@@ -118,6 +118,40 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None, x_gate
     return (alpha * dw.permute(2, 3, 1, 0)).contiguous()
 
 
+def _coupling_split(x, split, up):
+    F_ = x.shape[1] // 2
+    if split == 0:
+        z1, z2 = x[:, :F_], x[:, F_:]
+    else:
+        z1, z2 = x[:, 0::2], x[:, 1::2]
+    return (z1, z2) if up else (z2, z1)
+
+
+def _coupling_merge(z, zp, split, up):
+    z1, z2 = (z, zp) if up else (zp, z)
+    if split == 0:
+        return torch.cat([z1, z2], dim=1)
+    return torch.stack([z1, z2], dim=-1).reshape(z.shape[0], -1)
+
+
+def coupling_fwd(x, prm, split, up, inverse):
+    z, zp = _coupling_split(x, split, up)
+    mu, ls = prm.chunk(2, dim=1)
+    sc = torch.sigmoid(ls + 2.0) + 1e-3
+    if not inverse:
+        return _coupling_merge(z, sc * zp + mu, split, up).contiguous(), sc.log().sum(1)
+    return _coupling_merge(z, (zp - mu) / (sc + 1e-12), split, up).contiguous(), -sc.log().sum(1)
+
+
+def coupling_bwd(dy, dld, x, prm, split, up, inverse):
+    xx, pp = x.detach().clone().requires_grad_(True), prm.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        y, ld = coupling_fwd(xx, pp, split, up, inverse)
+        gl = torch.zeros_like(ld) if dld is None else dld
+        gx, gp = torch.autograd.grad([y, ld], [xx, pp], [dy, gl])
+    return gx, gp
+
+
 def attn_fwd(q, k, v, scale):
     s = torch.matmul(q, k.transpose(1, 2)) * scale
     return torch.matmul(torch.softmax(s, dim=-1), v).contiguous(), torch.logsumexp(s, dim=-1)

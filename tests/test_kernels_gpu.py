@@ -780,3 +780,18 @@ def test_bf16_thin_kernels(bf16_mode, C):
     out = hip.conv2d_wgrad(x.to(DEV), wide.to(DEV), 3, 3, dy_gate=g.to(DEV))  # thin weight grad, gated wide operand
     ref = _emu.conv2d_wgrad(_r16(x).double(), _r16(wide * g).double(), 3, 3)
     close(out, ref, rtol=1e-5, atol=2e-3, name="bf16 thin wgrad")
+
+
+@pytest.mark.parametrize("split,up,inverse", [(0, 1, 0), (0, 0, 0), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 0, 0)])
+def test_prior_flow_coupling(split, up, inverse):
+    """affine coupling of the 64-d prior flow (coupling.py:13-177, transform.py:49-81): forward / inverse, both split
+    types, value + log-det + gradients"""
+    B, D = 37, 64
+    x, prm = rnd(B, D, seed=1, scale=2.0), rnd(B, D, seed=2, scale=3.0)
+    (y, ld), (yr, ldr) = run_both("coupling_fwd", x, prm, split, up, inverse)
+    close(y, yr, name="coupling y")
+    close(ld, ldr, rtol=2e-5, atol=2e-5, name="coupling logdet")
+    dy, dld = rnd(B, D, seed=3), rnd(B, seed=4)
+    (dx, dp), (dxr, dpr) = run_both("coupling_bwd", dy, dld, x, prm, split, up, inverse)
+    close(dx, dxr, name="coupling dx")
+    close(dp, dpr, rtol=3e-5, atol=3e-5, name="coupling dparams")
