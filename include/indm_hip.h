@@ -165,22 +165,6 @@ int indm_attn_fwd_f32(const float* q, const float* k, const float* v, float* h, 
                       float scale, void* stream);
 int indm_attn_bwd_f32(const float* q, const float* k, const float* v, const float* dh, const float* lse,
                       const float* Dv, float* dq, float* dk, float* dv, int B, int T, int C, float scale, void* stream);
-/* ---- bf16 STORAGE mode of the residual flow (BASELINE configs #3-#5): the 512-channel tensors of an iResBlock live in
- * HBM as bf16 (void* = bf16 data); skinny tensors, parameters, gradients, losses and every accumulator stay fp32. ---- */
-/* C = alpha * ((A .* G) W^T + bias + bias2[m / rpg]); A, G: bf16 [M, K]; W: bf16 [N, K] (k-contiguous weight copy);
- * C: bf16 (out_bf16) or fp32 [M, N]; K % 32 == 0.  Replaces the 1x1 / transposed-1x1 contractions of iresblock.py. */
-int indm_hgemm_bf16(const void* A, const void* G, const void* W, void* C, int M, int N, int K, float alpha,
-                    const float* bias, const float* bias2, int rows_per_group, int out_bf16, void* stream);
-/* bf16-storage back-to-back chain: P[M, J] (fp32) = ((A .* G) W^T .* D1) W1p[:, :J], optional T2[M, 512] (bf16);
- * A, G: bf16 [M, K]; W: bf16 [512, K]; D1: bf16 [M, 512]; W1p: fp32 [512, 32 | 128].  Returns 1 = geometry not covered. */
-int indm_hchain_bf16(const void* A, const void* G, const void* W, const void* D1, const float* W1p, float* P, void* T2,
-                     int M, int K, int N, int J, void* stream);
-/* Sin activation + derivative and one Sin level of the iResBlock backward on bf16 tensors; boundary casts */
-int indm_sincos_act_fwd_bf16(const void* p, void* a, void* d, long n, void* stream);
-int indm_ires_bwd_act_bf16(const void* da, const void* du, const void* d, const void* a, const void* t, void* dp,
-                           void* dt_out, float* seg_out, long R, int C, long rows_per_seg, float* ws, void* stream);
-int indm_cast_f32_bf16(const float* x, void* y, long n, void* stream);
-int indm_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 /* Back-to-back contraction of one link pair of the VJP chain: P[M, J] = ((A .* G) W2T .* D1) W1p[:, :J] with the
  * 512-wide intermediate kept on chip (A, G: [M, K]; W2T: [K, 512] row-major; D1: [M, 512]; W1p: [512, 32 if J <= 32 else 128]
  * zero-padded; J = 9*C <= 128; T2 optional [M, 512]: also stores the intermediate (A .* G) W2T, which the

@@ -59,12 +59,6 @@ _SIGS = {
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_attn_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "indm_attn_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
-    "indm_hgemm_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_i, c_i, c_p],
-    "indm_hchain_bf16": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
-    "indm_sincos_act_fwd_bf16": [c_p, c_p, c_p, c_l, c_p],
-    "indm_ires_bwd_act_bf16": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p],
-    "indm_cast_f32_bf16": [c_p, c_p, c_l, c_p],
-    "indm_cast_bf16_f32": [c_p, c_p, c_l, c_p],
     "indm_ires_chain_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_ires_chain_bf16": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_ires_bwd_act_ws_floats": [c_l, c_i],
@@ -151,19 +145,6 @@ def _ptr(t):
         raise RuntimeError("indm_amd.hip: tensor is not on the GPU; the HIP path has no CPU fallback")
     if t.dtype != torch.float32:
         raise RuntimeError(f"indm_amd.hip: expected float32, got {t.dtype}")
-    if not t.is_contiguous():
-        raise RuntimeError("indm_amd.hip: tensor must be contiguous")
-    return t.data_ptr()
-
-
-def _ptrh(t):
-    """device pointer of a bf16 tensor (the storage mode of the flow's 512-wide tensors)"""
-    if t is None:
-        return None
-    if not t.is_cuda:
-        raise RuntimeError("indm_amd.hip: tensor is not on the GPU; the HIP path has no CPU fallback")
-    if t.dtype != torch.bfloat16:
-        raise RuntimeError(f"indm_amd.hip: expected bfloat16, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError("indm_amd.hip: tensor must be contiguous")
     return t.data_ptr()
@@ -632,74 +613,6 @@ def attn_bwd(q, k, v, h, dh, lse, scale):
         tm.variant, tm.flops = "attn_fused", 10.0 * B * T * T * C
     _chk(st, "indm_attn_bwd_f32")
     return dq, dk, dv
-
-
-# --------------------------------------------------------------------------- bf16 storage mode of the flow
-def to_bf16(x):
-    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _chk(lib().indm_cast_f32_bf16(_ptr(x), _ptrh(y), x.numel(), _stream()), "indm_cast_f32_bf16")
-    return y
-
-
-def to_f32(x):
-    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    _chk(lib().indm_cast_bf16_f32(_ptrh(x), _ptr(y), x.numel(), _stream()), "indm_cast_bf16_f32")
-    return y
-
-
-def hgemm(a, w, gate=None, bias=None, bias2=None, rows_per_group=1, alpha=1.0, out_bf16=True):
-    """C = alpha * ((a .* gate) @ w^T + bias + bias2[row // rows_per_group]); a, gate: bf16 [M, K]; w: bf16 [N, K]
-    (k-contiguous); C: bf16 or fp32 [M, N]."""
-    M, K = a.shape
-    N = w.shape[0]
-    out = torch.empty((M, N), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
-    nbytes = 2 * (a.numel() * (2 if gate is not None else 1) + w.numel()) + out.numel() * (2 if out_bf16 else 4)
-    with _timed("A_ROW", "B_COL", M, N, K, nbytes=nbytes) as tm:
-        st = lib().indm_hgemm_bf16(_ptrh(a), _ptrh(gate), _ptrh(w), out.data_ptr(), M, N, K, alpha, _ptr(bias), _ptr(bias2),
-                                   rows_per_group, int(out_bf16), _stream())
-        tm.variant = "hgemm256x128" + (",gated" if gate is not None else "") + ",bf16store"
-    _chk(st, "indm_hgemm_bf16")
-    return out
-
-
-def hchain(t3, d2, w, d1, w1p, J, want_t2=False):
-    """bf16-storage back-to-back chain: (P fp32 [M, J][, t2 bf16 [M, 512]]) or None when the geometry is not covered."""
-    M, K = t3.shape
-    N = w.shape[0]
-    P = torch.empty((M, J), dtype=torch.float32, device=t3.device)
-    t2 = torch.empty((M, N), dtype=torch.bfloat16, device=t3.device) if want_t2 else None
-    with _timed("A_ROW", "B_COL", M, N, K, nbytes=2 * (2 * t3.numel() + d1.numel() + w.numel()) + 4 * P.numel()) as tm:
-        st = lib().indm_hchain_bf16(_ptrh(t3), _ptrh(d2), _ptrh(w), _ptrh(d1), _ptr(w1p), _ptr(P), _ptrh(t2), M, K, N, J,
-                                    _stream())
-        tm.variant = "hchain64x512,gated,bf16store"
-        tm.flops += 2.0 * M * N * w1p.shape[1]
-    if st == 1:
-        return None
-    _chk(st, "indm_hchain_bf16")
-    return (P, t2) if want_t2 else P
-
-
-def sincos_fwd_h(p):
-    a, d = torch.empty_like(p), torch.empty_like(p)
-    _chk(lib().indm_sincos_act_fwd_bf16(_ptrh(p), _ptrh(a), _ptrh(d), p.numel(), _stream()), "indm_sincos_act_fwd_bf16")
-    return a, d
-
-
-def ires_bwd_act_h(da, du, d, a, t, want_dt=False, rows_per_seg=None):
-    """bf16-storage version of ires_bwd_act: all five inputs and dp / dt bf16, the per-segment sums fp32."""
-    C = a.shape[-1]
-    R = a.numel() // C
-    dp = torch.empty_like(a)
-    dt = torch.empty_like(a) if want_dt else None
-    seg = ws = None
-    if rows_per_seg is not None:
-        if rows_per_seg % 64 or R % rows_per_seg:
-            raise RuntimeError("ires_bwd_act_h: rows_per_seg must be a multiple of 64 that divides the row count")
-        seg = torch.empty((R // rows_per_seg, C), dtype=torch.float32, device=a.device)
-        ws = _ws(lib().indm_ires_bwd_act_ws_floats(R, C), a.device)
-    _chk(lib().indm_ires_bwd_act_bf16(_ptrh(da), _ptrh(du), _ptrh(d), _ptrh(a), _ptrh(t), _ptrh(dp), _ptrh(dt), _ptr(seg), R,
-                                      C, rows_per_seg or 0, _ptr(ws), _stream()), "indm_ires_bwd_act_bf16")
-    return dp, dt, seg
 
 
 def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):

@@ -795,66 +795,3 @@ def test_prior_flow_coupling(split, up, inverse):
     (dx, dp), (dxr, dpr) = run_both("coupling_bwd", dy, dld, x, prm, split, up, inverse)
     close(dx, dxr, name="coupling dx")
     close(dp, dpr, rtol=3e-5, atol=3e-5, name="coupling dparams")
-
-
-# ---- bf16 STORAGE mode of the flow (hgemm.hip, flow_h.hip) ----------------------------------------------------------
-def _h(t):
-    return t.to(DEV).bfloat16().contiguous()
-
-
-@pytest.mark.parametrize("M,N,K,gated,out_h", [(512, 512, 512, True, True), (8192, 512, 512, False, True),
-                                                (1000, 27, 512, True, False), (256, 108, 64, False, False)])
-def test_hgemm_bf16_storage(M, N, K, gated, out_h):
-    """C = (A .* G) W^T + bias + bias2 on bf16 tensors: exact products of the stored bf16 values (the gated operand is
-    the bf16-rounded product), fp32 accumulation, output rounded to bf16 when stored as bf16"""
-    a, g, w = rnd(M, K, seed=1), rnd(M, K, seed=2), rnd(N, K, seed=3, scale=K ** -0.5)
-    bias, rpg = rnd(N, seed=4), 8
-    b2 = rnd((M + rpg - 1) // rpg, N, seed=5)
-    ah, gh, wh = _h(a), _h(g), _h(w)
-    out = hip.hgemm(ah, wh, gate=gh if gated else None, bias=bias.to(DEV), bias2=b2.to(DEV), rows_per_group=rpg, out_bf16=out_h)
-    aa = ah.float().cpu().double()
-    if gated:
-        aa = (ah.float() * gh.float()).bfloat16().float().cpu().double()
-    ref = aa @ wh.float().cpu().double().t() + bias.double() + b2.double().repeat_interleave(rpg, 0)[:M]
-    assert out.dtype == (torch.bfloat16 if out_h else torch.float32)
-    if out_h:   # one bf16 rounding of the result
-        close(out.float(), ref, rtol=2 ** -8, atol=1e-3, name="hgemm bf16 out")
-    else:
-        close(out, ref, rtol=1e-5, atol=1e-4, name="hgemm fp32 out")
-
-
-@pytest.mark.parametrize("M,J", [(128, 27), (4096, 108)])
-def test_hchain_bf16_storage(M, J):
-    JP = 32 if J <= 32 else 128
-    t3, d2, d1 = rnd(M, 512, seed=1), rnd(M, 512, seed=2), rnd(M, 512, seed=3)
-    w = rnd(512, 512, seed=4, scale=512 ** -0.5)            # [n][k]
-    w1p = torch.zeros(512, JP)
-    w1p[:, :J] = rnd(512, J, seed=5, scale=512 ** -0.5)
-    th, dh2, dh1, wh = _h(t3), _h(d2), _h(d1), _h(w)
-    P, t2 = hip.hchain(th, dh2, wh, dh1, w1p.to(DEV), J, want_t2=True)
-    u2 = (th.float() * dh2.float()).bfloat16().float().cpu().double()
-    t2ref = u2 @ wh.float().cpu().double().t()
-    close(t2.float(), t2ref, rtol=2 ** -8, atol=1e-3, name="hchain t2")
-    u1 = (t2ref.float().bfloat16().float() * dh1.float().cpu()).bfloat16().float().double()
-    ref = u1 @ w1p[:, :J].bfloat16().float().double()
-    # t2's bf16 rounding may flip next to a boundary when the fp32 accumulation order differs: bf16-level tolerance
-    close(P, ref, rtol=2e-3, atol=2e-3, name="hchain P")
-
-
-def test_flow_h_elementwise():
-    R, C = 2048, 512
-    p = rnd(R, C, seed=1, scale=0.7)
-    a, d = hip.sincos_fwd_h(_h(p))
-    pf = _h(p).float().cpu().double()
-    close(a.float(), torch.sin(2 * math.pi * pf) / (2 * math.pi), rtol=2 ** -8, atol=1e-4, name="sincos_h a")
-    close(d.float(), torch.cos(2 * math.pi * pf), rtol=2 ** -8, atol=4e-3, name="sincos_h d")
-    ts = [_h(rnd(R, C, seed=i)) for i in range(5)]
-    dp, dt, seg = hip.ires_bwd_act_h(*ts, want_dt=True, rows_per_seg=1024)
-    f = [t.float().cpu().double() for t in ts]
-    rdp, rdt, rseg = _emu.ires_bwd_act(*f, want_dt=True, rows_per_seg=1024)
-    close(dp.float(), rdp, rtol=2 ** -8, atol=1e-2, name="ires_h dp")
-    close(dt.float(), rdt, rtol=2 ** -8, atol=1e-3, name="ires_h dt")
-    close(seg, rseg, rtol=1e-4, atol=1e-2, name="ires_h seg")
-    x = rnd(1000, 7, seed=9)
-    assert torch.equal(hip.to_bf16(x.to(DEV)).cpu(), x.bfloat16())
-    assert torch.equal(hip.to_f32(_h(x)).cpu(), x.bfloat16().float())
