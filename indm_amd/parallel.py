@@ -1,4 +1,5 @@
-"""Data parallelism: one process per GPU, ONE RCCL all-reduce of the flat gradient buffer per step.
+"""Data parallelism: one process per GPU, the flat gradient buffer all-reduced over RCCL/xGMI once per step (each
+element crosses the wire once: the score slice from inside the backward pass, the flow slice after it -- GradReducer).
 
 The reference uses single-process nn.DataParallel (models/utils.py:93, flow_models/flow_model.py:109):
 per-step parameter broadcast + scatter/gather + gradient reduce onto device 0.  Here every rank owns full
