@@ -193,6 +193,14 @@ int indm_squeeze2x_f32(const float* x, float* y, int N, int H, int W, int C, voi
 int indm_unsqueeze2x_f32(const float* x, float* y, int N, int H, int W, int C4, void* stream);
 /* NCHW <-> NHWC at the API edge (dir 0: NCHW->NHWC, 1: NHWC->NCHW) */
 int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, int dir, void* stream);
+/* Column blocks of x[R, Ctot] <-> one flat buffer holding block b as a contiguous [R, C_b] matrix at offset R*offs[b]
+ * (offs: device int32[nblk+1]; dir 0: x -> flat, 1: flat -> x): the per-block slices of the batched Dense_0(act(temb))
+ * product, models/layerspp.py:262-263 */
+int indm_split_cols_f32(const float* x, float* y, const int* offs, int nblk, long R, int Ctot, int dir, void* stream);
+/* nn.utils.weight_norm(Linear): w[o,:] = v[o,:] g[o] / ||v[o,:]||, and its gradient (nnet/weight_norm.py:8-40) */
+int indm_weightnorm_fwd_f32(const float* v, const float* g, float* w, float* nrm, int O, int I, void* stream);
+int indm_weightnorm_bwd_f32(const float* dw, const float* v, const float* g, const float* nrm, float* dv, float* dg,
+                            int O, int I, void* stream);
 /* Lop weight normalisation w / max(1, ||w[:,co]||_1 / coeff) and its gradient: LopConv2d.compute_weight,
  * layers/base/lipschitz.py:350-359 (domain = codomain = inf) */
 int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff, void* stream);

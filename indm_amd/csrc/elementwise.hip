@@ -434,6 +434,77 @@ INDM_API int indm_nchw_nhwc_f32(const float* x, float* y, int N, int C, int HW, 
   });
 }
 
+// Column blocks of x[R, Ctot] <-> one flat buffer in which block b is a CONTIGUOUS [R, C_b] matrix at offset
+// R * offs[b] (C_b = offs[b+1] - offs[b]; offs: device int32[nblk + 1]).  dir 0: x -> flat, dir 1: flat -> x.
+// (The score net computes the time-embedding bias of all of its residual blocks in one GEMM; every block's conv
+// epilogue wants its own columns as a dense [images, C_b] matrix.)
+INDM_API int indm_split_cols_f32(const float* x, float* y, const int* offs, int nblk, long R, int Ctot, int dir,
+                                 void* stream) {
+  if (nblk <= 0 || R < 0 || Ctot <= 0 || (dir != 0 && dir != 1)) return INDM_E_ARG;
+  return ew_launch(R * Ctot, (hipStream_t)stream, [=] __device__(long i) {  // i indexes the [R, Ctot] side
+    const long r = i / Ctot;
+    const int c = (int)(i - r * Ctot);
+    int lo = 0, hi = nblk;  // block of column c: offs[lo] <= c < offs[lo + 1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offs[mid] <= c) lo = mid; else hi = mid;
+    }
+    const int o = offs[lo], cb = offs[lo + 1] - o;
+    const long j = R * o + r * cb + (c - o);
+    if (dir == 0) y[j] = x[i];
+    else y[i] = x[j];
+  });
+}
+
+// weight-normalised linear layer (nn.utils.weight_norm): w[o,:] = v[o,:] * g[o] / ||v[o,:]||_2 ; one wave per row.
+namespace {
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void weightnorm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                             float* __restrict__ w, float* __restrict__ nrm, int O, int I) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float* vr = v + (long)o * I;
+  float s = 0.f;
+  for (int i = lane; i < I; i += 64) s += vr[i] * vr[i];
+  const float n = sqrtf(wave_sum(s));
+  const float sc = g[o] / n;
+  for (int i = lane; i < I; i += 64) w[(long)o * I + i] = vr[i] * sc;
+  if (lane == 0) nrm[o] = n;
+}
+__global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                             const float* __restrict__ g, const float* __restrict__ nrm,
+                                                             float* __restrict__ dv, float* __restrict__ dg, int O, int I) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float* vr = v + (long)o * I;
+  const float* dr = dw + (long)o * I;
+  float s = 0.f;
+  for (int i = lane; i < I; i += 64) s += dr[i] * vr[i];
+  const float dot = wave_sum(s), n = nrm[o], gg = g[o];
+  const float a = gg / n, b = dot * gg / (n * n * n);
+  for (int i = lane; i < I; i += 64) dv[(long)o * I + i] = dr[i] * a - vr[i] * b;
+  if (lane == 0) dg[o] = dot / n;
+}
+}  // namespace
+// v, w: [O, I]; g, nrm: [O]
+INDM_API int indm_weightnorm_fwd_f32(const float* v, const float* g, float* w, float* nrm, int O, int I, void* stream) {
+  if (O <= 0 || I <= 0) return INDM_E_SHAPE;
+  hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(cdiv(O, 4)), dim3(256), 0, (hipStream_t)stream, v, g, w, nrm, O, I);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+INDM_API int indm_weightnorm_bwd_f32(const float* dw, const float* v, const float* g, const float* nrm, float* dv,
+                                     float* dg, int O, int I, void* stream) {
+  if (O <= 0 || I <= 0) return INDM_E_SHAPE;
+  hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(cdiv(O, 4)), dim3(256), 0, (hipStream_t)stream, dw, v, g, nrm, dv, dg, O, I);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
 // Lop normalisation forward: wn[r,c] = w[r,c] / max(1, l1[c]/coeff);  l1[c] = sum_r |w[r,c]|
 INDM_API int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff,
                                         void* stream) {

@@ -561,6 +561,13 @@ INDM_API int indm_colreduce_f32(const float* x, const float* y, float* out, long
                                 float beta, float* ws, void* stream) {
   if (C <= 0) return INDM_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (mode == 0 && R <= 1024) {
+    // a short matrix (the [images, C] per-image bias gradients -> the bias gradient): the second stage alone, with x
+    // as its partial rows -- one launch
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, x, out, C, (int)R, alpha, beta);
+    INDM_CHECK_LAUNCH();
+    return INDM_OK;
+  }
   const long P = colreduce_parts(R, C);
   const long rpb = (R + P - 1) / P;
   const int C4 = (C + 3) / 4;

@@ -290,7 +290,7 @@ class _IResTrain(torch.autograd.Function):
             q1 = dW1 = None
         if dcb is None:
             dcb = hip.segreduce(dp2, rps)
-        db2 = dcb.sum(0)
+        db2 = hip.colreduce(dcb, None, 0)
         # ---- level 2: p2 = a1 W2 + b2 + cb[image] ----
         da1 = hip.gemm(f2(dp2), W2, trans_b=True)
         dW2 = hip.gemm(f2(a1), f2(dp2), trans_a=True, splitk=True)
@@ -303,7 +303,7 @@ class _IResTrain(torch.autograd.Function):
         else:
             dp1, seg1 = hip.sincos_bwd(da1, None, f2(a1), f2(d1)), None
             dW2T = torch.zeros_like(W2T)
-        db1 = seg1.sum(0) if seg1 is not None else hip.colreduce(dp1, None, 0)
+        db1 = hip.colreduce(seg1 if seg1 is not None else dp1, None, 0)
         # ---- level 1: p1 = conv(a0, W1) + b1 ----
         dp1 = dp1.view(N, H, Wd, -1)
         da0 = hip.conv2d_dgrad(dp1, W1, hw)
@@ -374,6 +374,8 @@ class ResidualFlow(nn.Module):
                     continue
                 w1 = torch.stack([Ws[blks.index(b)][0].detach() for b in sc], dim=0)        # [nb, 3, 3, C, idim]
                 nb_, _, _, C_, I_ = w1.shape
+                if hip._skinny(3, 3, 1, 1, C_, I_):
+                    hip.prepack_weights([Ws[blks.index(b)][2] for b in sc])   # W3's two GEMM layouts, whole scale
                 if hip._skinny(3, 3, 1, 1, C_, I_) and 9 * C_ <= 128:
                     pn = torch.nn.functional.pad(w1.reshape(nb_, 9 * C_, I_).transpose(1, 2),
                                                  (0, (32 if 9 * C_ <= 32 else 128) - 9 * C_)).contiguous()
@@ -385,13 +387,13 @@ class ResidualFlow(nn.Module):
         """:310-324 -- returns (z, logpx) with logpx = -sum logdet (as the reference)."""
         scales = self.blocks()
         prep = self.prepare(h)
-        logpx = None
+        lds = []
         for si, blocks in enumerate(scales):
             for b in blocks:
                 W, cb = prep[b]
                 if eval_logdet:
                     x, ld = b.forward_logdet(x, cb, W, rng, stats)
-                    logpx = -ld if logpx is None else logpx - ld
+                    lds.append(ld)
                 else:
                     g, _ = b.g(x, cb, W, False)
                     x = ops.axpby(x, g)
@@ -399,7 +401,11 @@ class ResidualFlow(nn.Module):
                 x = ops.squeeze2x(x)
         for _ in range(len(scales) - 1):
             x = ops.unsqueeze2x(x)
-        return (x, logpx) if eval_logdet else x
+        if not eval_logdet:
+            return x
+        # logpx = -sum_b logdet_b: one stack + one reduction (and views in backward) instead of a chain of 31 [B]-sized
+        # subtractions with 31 negations in backward
+        return x, -(torch.stack(lds).sum(0) if len(lds) > 1 else lds[0])
 
     def bwdpass(self, z, h, iters=None):
         """:326-335 + inverse :237-267"""
@@ -445,11 +451,28 @@ class _BatchNorm(nn.Module):
         if self.training:
             mean, var = stats[0]
             n = x.numel() // x.shape[-1]
-            with torch.no_grad():  # nn.BatchNorm2d momentum 0.1, unbiased running var
-                self.running_mean.mul_(0.9).add_(mean, alpha=0.1)
-                self.running_var.mul_(0.9).add_(var, alpha=0.1 * n / (n - 1))
-                self.num_batches_tracked.add_(1)
+            if _BatchNorm.pending is not None:
+                _BatchNorm.pending.append((self, mean, var, n))   # the encoder applies all of them in a few launches
+            else:
+                _BatchNorm.update_running([(self, mean, var, n)])
         return y
+
+    pending = None   # list while an encoder forward is collecting the running-statistics updates of its layers
+
+    @staticmethod
+    def update_running(items):
+        """nn.BatchNorm2d momentum 0.1, unbiased running var -- for many layers at once (multi-tensor launches;
+        one add per distinct sample count n, whose unbiasing factor is part of the add's alpha)."""
+        if not items:
+            return
+        with torch.no_grad():
+            rm, rv = [m.running_mean for m, *_ in items], [m.running_var for m, *_ in items]
+            torch._foreach_mul_(rm + rv, 0.9)
+            torch._foreach_add_(rm, [mean for _, mean, _, _ in items], alpha=0.1)
+            for n in sorted({n for *_, n in items}):
+                sel = [(m.running_var, var) for m, _, var, k in items if k == n]
+                torch._foreach_add_([a for a, _ in sel], [b for _, b in sel], alpha=0.1 * n / (n - 1))
+            torch._foreach_add_([m.num_batches_tracked for m, *_ in items], 1)
 
 
 class ResNetBlockBatchNorm(nn.Module):
@@ -502,9 +525,14 @@ class GlobalResNetEncoderBatchNorm(nn.Module):
         self.net = net
 
     def forward(self, x):
-        for lvl in range(self.levels):
-            for blk in getattr(self.net, f"resnet{lvl}").main:
-                x = blk(x)
+        outer, _BatchNorm.pending = _BatchNorm.pending, []
+        try:
+            for lvl in range(self.levels):
+                for blk in getattr(self.net, f"resnet{lvl}").main:
+                    x = blk(x)
+        finally:
+            items, _BatchNorm.pending = _BatchNorm.pending, outer
+            _BatchNorm.update_running(items)
         x = ops.elu(ops.conv1x1(x, self.net.top.weight, self.net.top.bias))
         # reference flattens NCHW ([B, out_planes*h*w], global_encoder.py:36)
         return ops.to_nchw(x).reshape(x.shape[0], -1)
@@ -524,9 +552,7 @@ class LinearWeightNorm(nn.Module):
         self.linear = lin
 
     def forward(self, x):
-        v, g = self.linear.weight_v, self.linear.weight_g
-        w = v * (g / v.norm(dim=1, keepdim=True))  # [out,in] <= 64x256: host-sized glue
-        return ops.linear(x, w, self.linear.bias)
+        return ops.linear(x, ops.weight_norm(self.linear.weight_v, self.linear.weight_g), self.linear.bias)
 
 
 # ----------------------------------------------------------------------------- prior flow on h (64-d)
@@ -641,14 +667,14 @@ class PriorFlow(nn.Module):
         self.steps = nn.ModuleList([PriorFlowStep(features, hidden) for _ in range(num_steps)])
 
     def run(self, x, backward):
-        logdet = x.new_zeros(x.shape[0])
+        lds, B = [], x.shape[0]
         steps = list(self.steps)
         for st in (steps if not backward else reversed(steps)):
             seq = [st.actnorm, st.linear] + [getattr(st.unit, n) for n in PriorFlowUnit.ORDER]
             for m in (seq if not backward else reversed(seq)):
                 x, ld = m._run(x, backward)
-                logdet = logdet + ld
-        return x, logdet
+                lds.append(ld.expand(B))   # per-sample [B] or a shared [1]
+        return x, torch.stack(lds).sum(0)
 
 
 class FlowPrior(nn.Module):

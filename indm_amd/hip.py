@@ -76,6 +76,9 @@ _SIGS = {
     "indm_squeeze2x_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_unsqueeze2x_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_nchw_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "indm_split_cols_f32": [c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p],
+    "indm_weightnorm_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_p],
+    "indm_weightnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "indm_lop_normalize_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "indm_lop_normalize_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p],
     "indm_multi_copy_f32": [c_p, c_i, c_l, c_p],
@@ -306,6 +309,24 @@ def _packed_weight(w, kind):
     if cacheable:
         _packed[key] = (weakref.ref(w), w._version, out)
     return out
+
+
+def prepack_weights(ws):
+    """Fill the _packed_weight cache for a list of same-shape RSCK weights with TWO launches per layout (stack +
+    permuted copy) instead of one small copy per weight and layout: the flow does this once per call for the skinny
+    3x3 weights of a whole scale.  Non-parameter tensors only (see _packed_weight)."""
+    import weakref
+    ws = [w for w in ws if not isinstance(w, torch.nn.Parameter)]
+    if not ws:
+        return
+    KH, KW, Ci, Co = ws[0].shape
+    with torch.no_grad():
+        st = torch.stack([w.detach() for w in ws])                                          # [n, KH, KW, Ci, Co]
+        a = st.permute(0, 3, 1, 2, 4).reshape(len(ws), Ci, KH * KW * Co).contiguous()       # "ci_tapco"
+        b = st.permute(0, 1, 2, 4, 3).reshape(len(ws), KH * KW * Co, Ci).contiguous()       # "tapco_ci"
+    for i, w in enumerate(ws):
+        _packed[(id(w), "ci_tapco")] = (weakref.ref(w), w._version, a[i])
+        _packed[(id(w), "tapco_ci")] = (weakref.ref(w), w._version, b[i])
 
 
 def _skinny(kh, kw, stride, pad, c_small, c_wide):
@@ -624,11 +645,15 @@ def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
     N = w2t.shape[1]
     P = torch.empty((M, J), dtype=torch.float32, device=t3.device)
     t2 = torch.empty((M, N), dtype=torch.float32, device=t3.device) if want_t2 else None
-    with _timed("A_ROW", "B_ROW", M, N, K, nbytes=4 * (2 * t3.numel() + d1.numel() + w2t.numel() + P.numel())) as tm:
+    nbytes = 4 * (2 * t3.numel() + d1.numel() + w2t.numel() + P.numel() + (t2.numel() if want_t2 else 0))
+    with _timed("A_ROW", "B_ROW", M, N, K, nbytes=nbytes) as tm:
         st = _dense("ires_chain")(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), _ptr(t2), M, K, N, J,
                                   _stream())
-        tm.variant = "ires_chain64x512,gated" + (",bf16" if _MFMA["dtype"] == "bf16" else "")
-        tm.flops += 2.0 * M * N * w1p.shape[1]
+        # the launch that also stores the 512-wide intermediate (training's last chain link) is its own class:
+        # same MFMA work plus a 4*M*N-byte store
+        tm.variant = ("ires_chain64x512,gated" + (",t2out" if want_t2 else "")
+                      + (",bf16" if _MFMA["dtype"] == "bf16" else ""))
+        tm.flops += 2.0 * M * N * J   # algorithmic: the panel's J live columns, not its zero padding
     if st == 1:
         return None
     _chk(st, "indm_ires_chain_f32")
@@ -719,6 +744,46 @@ def downsample2x(x, alpha=0.25):
     y = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=x.device)
     _chk(lib().indm_downsample2x_f32(_ptr(x), _ptr(y), N, H, W, C, alpha, _stream()), "indm_downsample2x_f32")
     return y
+
+
+_col_offs = {}
+
+
+def split_cols(x, sizes, inverse_of=None):
+    """x [R, sum(sizes)] -> flat buffer of sum(sizes)*R floats in which block b is the contiguous [R, sizes[b]]
+    matrix at offset R * sum(sizes[:b]) (one launch instead of one strided copy per block).
+    inverse_of=R: x is such a flat buffer, the result is the [R, sum(sizes)] matrix."""
+    sizes = tuple(int(v) for v in sizes)
+    key = (sizes, x.device)
+    offs = _col_offs.get(key)
+    if offs is None:
+        acc = [0]
+        for v in sizes:
+            acc.append(acc[-1] + v)
+        offs = _col_offs[key] = torch.tensor(acc, dtype=torch.int32).to(x.device)
+    tot = sum(sizes)
+    R = x.shape[0] if inverse_of is None else int(inverse_of)
+    y = torch.empty((R * tot,) if inverse_of is None else (R, tot), dtype=torch.float32, device=x.device)
+    _chk(lib().indm_split_cols_f32(_ptr(x), _ptr(y), offs.data_ptr(), len(sizes), R, tot, 0 if inverse_of is None else 1,
+                                   _stream()), "indm_split_cols_f32")
+    return y
+
+
+def weightnorm_fwd(v, g):
+    """v [O, I], g [O] (or [O, 1]) -> (w = v * g / ||v||_row, ||v||_row [O])"""
+    O, I = v.shape
+    w, n = torch.empty_like(v), torch.empty((O,), dtype=torch.float32, device=v.device)
+    _chk(lib().indm_weightnorm_fwd_f32(_ptr(v), _ptr(g), _ptr(w), _ptr(n), O, I, _stream()), "indm_weightnorm_fwd_f32")
+    return w, n
+
+
+def weightnorm_bwd(dw, v, g, n):
+    """-> (dv [O, I], dg [O])"""
+    O, I = v.shape
+    dv, dg = torch.empty_like(v), torch.empty((O,), dtype=torch.float32, device=v.device)
+    _chk(lib().indm_weightnorm_bwd_f32(_ptr(dw), _ptr(v), _ptr(g), _ptr(n), _ptr(dv), _ptr(dg), O, I, _stream()),
+         "indm_weightnorm_bwd_f32")
+    return dv, dg
 
 
 def squeeze2x(x):

@@ -360,8 +360,8 @@ class NCSNpp(nn.Module):
         if blocks:
             tb_all = ops.linear(temb_act, torch.cat([b.Dense_0.weight for b in blocks], dim=0),
                                 torch.cat([b.Dense_0.bias for b in blocks], dim=0))
-            for b, t in zip(blocks, tb_all.split([b.out_ch for b in blocks], dim=1)):
-                b.tb_next = t.contiguous()
+            for b, t in zip(blocks, ops.split_cols(tb_all, [b.out_ch for b in blocks])):
+                b.tb_next = t
         h0 = x if nhwc else ops.to_nhwc(x)
         if not self.config.data.centered:
             h0 = ops.axpby(h0, None, 2.0, 0.0, -1.0)  # 2x-1 (ncsnpp.py:278-280)

@@ -59,7 +59,7 @@ class _Gemm(Function):
             dbias2 = hip.segreduce(dc, rpg, alpha)           # per-image sums: one pass over dc
         if has_bias and ctx.needs_input_grad[2]:
             # the per-image sums already hold the whole reduction: no second pass over dc
-            dbias = dbias2.sum(0) if dbias2 is not None else hip.colreduce(dc, None, 0, alpha)
+            dbias = hip.colreduce(dbias2, None, 0) if dbias2 is not None else hip.colreduce(dc, None, 0, alpha)
         if has_res and ctx.needs_input_grad[4]:
             dres = hip.axpby(dc, None, beta, 0.0)
         return da, db, dbias, dbias2, dres, None, None, None, None, None, None, dgate
@@ -115,7 +115,7 @@ class _Conv2d(Function):
         if has_bias2 and ctx.needs_input_grad[3]:
             dbias2 = hip.segreduce(dy, dy.shape[1] * dy.shape[2], alpha)   # per-image sums: one pass over dy
         if has_bias and ctx.needs_input_grad[2]:
-            dbias = dbias2.sum(0) if dbias2 is not None else hip.colreduce(dy, None, 0, alpha)
+            dbias = hip.colreduce(dbias2, None, 0) if dbias2 is not None else hip.colreduce(dy, None, 0, alpha)
         if has_res and ctx.needs_input_grad[4]:
             dres = hip.axpby(dy, None, beta, 0.0)
         return dx, dw, dbias, dbias2, dres, None, None, None, None
@@ -385,6 +385,53 @@ def mul(x, y):
     return _Mul.apply(x, y)
 
 
+class _SplitCols(Function):
+    """[R, sum C_b] -> the per-block dense [R, C_b] matrices (views of one flat buffer): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        x = _c(x)
+        flat = hip.split_cols(x, sizes)
+        ctx.sizes, ctx.R = sizes, x.shape[0]
+        ctx.set_materialize_grads(False)
+        outs, o = [], 0
+        for c in sizes:
+            outs.append(flat[o:o + ctx.R * c].view(ctx.R, c))
+            o += ctx.R * c
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        R = ctx.R
+        gs = [g if g is not None else grads[0].new_zeros((R, c)) for g, c in zip(grads, ctx.sizes)]
+        return (torch.cat(gs, dim=1),) + (None,) * len(ctx.sizes)
+
+
+def split_cols(x, sizes):
+    """tuple of contiguous [R, C_b] column blocks of x [R, sum(sizes)]"""
+    return _SplitCols.apply(x, *[int(v) for v in sizes])
+
+
+class _WeightNorm(Function):
+    @staticmethod
+    def forward(ctx, v, g):
+        v, g = _c(v), _c(g)
+        w, n = hip.weightnorm_fwd(v, g)
+        ctx.save_for_backward(v, g, n)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        v, g, n = ctx.saved_tensors
+        dv, dg = hip.weightnorm_bwd(_c(dw), v, g, n)
+        return dv, dg.view_as(g)
+
+
+def weight_norm(v, g):
+    """nn.utils.weight_norm: v [out, in] * g [out(,1)] / ||v||_row  (one launch forward, one backward)"""
+    return _WeightNorm.apply(v, g)
+
+
 class _RowDot(Function):
     """out[b] = <x[b], y[b]>"""
 
@@ -559,6 +606,7 @@ class _LopNormalizeMulti(Function):
         ctx.save_for_backward(*ws, *l1s)
         ctx.coeff, ctx.n = coeff, len(ws)
         ctx.mark_non_differentiable(*l1s)
+        ctx.set_materialize_grads(False)   # no zero-fill launch per l1 output (96 per step on the flow)
         return tuple(wns) + tuple(l1s)
 
     @staticmethod

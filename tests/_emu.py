@@ -494,3 +494,30 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
         else:
             o = torch.zeros_like(v)
     return o * scale
+
+
+def split_cols(x, sizes, inverse_of=None):
+    sizes = [int(v) for v in sizes]
+    if inverse_of is None:
+        return torch.cat([t.reshape(-1) for t in x.split(sizes, dim=1)])
+    R = int(inverse_of)
+    out, o = [], 0
+    for c in sizes:
+        out.append(x[o:o + R * c].view(R, c))
+        o += R * c
+    return torch.cat(out, dim=1)
+
+
+def weightnorm_fwd(v, g):
+    n = v.norm(dim=1)
+    return v * (g.reshape(-1) / n)[:, None], n
+
+
+def weightnorm_bwd(dw, v, g, n):
+    g = g.reshape(-1)
+    dot = (dw * v).sum(1)
+    return dw * (g / n)[:, None] - v * (dot * g / n ** 3)[:, None], dot / n
+
+
+def prepack_weights(ws):
+    return None

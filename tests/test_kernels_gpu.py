@@ -795,3 +795,47 @@ def test_prior_flow_coupling(split, up, inverse):
     (dx, dp), (dxr, dpr) = run_both("coupling_bwd", dy, dld, x, prm, split, up, inverse)
     close(dx, dxr, name="coupling dx")
     close(dp, dpr, rtol=3e-5, atol=3e-5, name="coupling dparams")
+
+
+@pytest.mark.parametrize("R,C", [(128, 512), (2, 12), (1024, 3), (1, 256), (1025, 64)])
+def test_colreduce_short(R, C):
+    """R <= 1024, mode 0: the single-launch form (per-image bias grads -> bias grad); R = 1025 takes the two-stage one"""
+    x = rnd(R, C)
+    o, r = run_both("colreduce", x, None, mode=0, alpha=0.5)
+    close(o, r, rtol=1e-5, atol=1e-5 * math.sqrt(R), name="colreduce short")
+
+
+@pytest.mark.parametrize("R,sizes", [(128, [128] * 10 + [256] * 34), (2, [128, 256, 4]), (7, [5]), (3, [1, 2, 3, 4, 5])])
+def test_split_cols(R, sizes):
+    x = rnd(R, sum(sizes))
+    flat, ref = run_both("split_cols", x, sizes)
+    assert torch.equal(flat.cpu().double(), ref)
+    back = hip.split_cols(flat, sizes, inverse_of=R)
+    assert torch.equal(back.cpu(), x)
+    # the autograd wrapper hands out dense per-block views and sends their gradients back as one matrix
+    from indm_amd import ops
+    xg = x.to(DEV).requires_grad_(True)
+    parts = ops.split_cols(xg, sizes)
+    o = 0
+    for p, c in zip(parts, sizes):
+        assert p.is_contiguous() and torch.equal(p.detach().cpu(), x[:, o:o + c])
+        o += c
+    sum((i + 1.0) * p.sum() for i, p in enumerate(parts) if i != 1 or len(sizes) == 1).backward()
+    want = torch.cat([torch.full((R, c), (i + 1.0) if (i != 1 or len(sizes) == 1) else 0.0) for i, c in enumerate(sizes)], dim=1)
+    assert torch.equal(xg.grad.cpu(), want)
+
+
+@pytest.mark.parametrize("O,I", [(128, 256), (64, 64), (5, 7), (300, 1000)])
+def test_weightnorm(O, I):
+    v, g, dw = rnd(O, I), rnd(O, 1, seed=1) + 2.0, rnd(O, I, seed=2)
+    (w, n), (rw, rn) = run_both("weightnorm_fwd", v, g)
+    close(w, rw, rtol=1e-5, atol=1e-6, name="weightnorm w")
+    close(n, rn, rtol=1e-5, atol=1e-6, name="weightnorm norm")
+    (dv, dg), (rdv, rdg) = run_both("weightnorm_bwd", dw, v, g, rn.float())
+    close(dv, rdv, rtol=1e-4, atol=1e-5, name="weightnorm dv")
+    close(dg, rdg, rtol=1e-4, atol=1e-5, name="weightnorm dg")
+    # against autograd of the reference expression (nnet/weight_norm.py: nn.utils.weight_norm)
+    vd, gd = v.double().requires_grad_(True), g.double().requires_grad_(True)
+    (vd * (gd / vd.norm(dim=1, keepdim=True)) * dw.double()).sum().backward()
+    close(dv, vd.grad, rtol=1e-4, atol=1e-5, name="weightnorm dv vs autograd")
+    close(dg, gd.grad.reshape(-1), rtol=1e-4, atol=1e-5, name="weightnorm dg vs autograd")
