@@ -42,7 +42,9 @@ __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; 
 // BF16: MFMA inputs rounded to bf16 (RNE), fp32 accumulate -- stage 1 packs both 4-deep fragments of a slab into one
 // v_mfma_f32_32x32x16_bf16 (as igemm_glds_kernel<.., BF16>); stage 2 rounds its operands to bf16 and keeps the fp32
 // MFMA (products of bf16 values are exact in fp32: identical to a bf16 MFMA).
-template <int JB, bool BF16>
+// T2OUT: the launch also stores the intermediate (its own instantiation: a distinct kernel name in profiles, and no
+// run-time branch around the store).
+template <int JB, bool BF16, bool T2OUT>
 __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   mfmas(fm1, fn1);
   }
 
-  if (p.T2) {  // uniform: 16-byte pieces, a 128-byte row segment is completed by four stores of the same wave
+  if constexpr (T2OUT) {  // 16-byte pieces, a 128-byte row segment is completed by four stores of the same wave
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float* trow = p.T2 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
@@ -254,18 +256,22 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   }
 }
 
-template <int JB, bool BF16>
-int launch_chain(const ChainArgs& p, hipStream_t st) {
+template <int JB, bool BF16, bool T2OUT>
+int launch_chain_t(const ChainArgs& p, hipStream_t st) {
   constexpr size_t bytes = 2 * BUF * sizeof(float);
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB, BF16, T2OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess)
       return INDM_E_LAUNCH;
     ready = true;
   }
-  hipLaunchKernelGGL((ires_chain_kernel<JB, BF16>), dim3(p.M / TM), dim3(NW * 64), bytes, st, p);
+  hipLaunchKernelGGL((ires_chain_kernel<JB, BF16, T2OUT>), dim3(p.M / TM), dim3(NW * 64), bytes, st, p);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+template <int JB, bool BF16>
+int launch_chain(const ChainArgs& p, hipStream_t st) {
+  return p.T2 ? launch_chain_t<JB, BF16, true>(p, st) : launch_chain_t<JB, BF16, false>(p, st);
 }
 
 }  // namespace

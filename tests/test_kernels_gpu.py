@@ -839,3 +839,18 @@ def test_weightnorm(O, I):
     (vd * (gd / vd.norm(dim=1, keepdim=True)) * dw.double()).sum().backward()
     close(dv, vd.grad, rtol=1e-4, atol=1e-5, name="weightnorm dv vs autograd")
     close(dg, gd.grad.reshape(-1), rtol=1e-4, atol=1e-5, name="weightnorm dg vs autograd")
+
+
+def test_dequantize_and_scale():
+    """run_lib.py:86-87 ((255 x + u)/256 then the data scaler) as one launch (indm_amd/datasets.py)"""
+    from indm_amd import configs, datasets
+    from indm_amd.rng import DeviceRng
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    x = torch.round(rnd(8, 3, 32, 32).abs().clamp(0, 1) * 255) / 255
+    for centered in (True, False):
+        cfg.data.centered = centered
+        out = datasets.dequantize_and_scale(cfg, x.to(DEV), DeviceRng(torch.device(DEV), seed=5))
+        u = DeviceRng(torch.device(DEV), seed=5).rand(*x.shape).cpu()
+        want = (255.0 * x + u) / 256.0
+        want = want * 2.0 - 1.0 if centered else want
+        close(out, want.double(), rtol=1e-6, atol=1e-6, name="dequantize")

@@ -27,6 +27,17 @@ if parts[2].startswith("glds"):
     sub = f"igemm_glds_kernel<{amode[parts[0]]}, {bmode[parts[1]]}, {'true' if 'gated' in parts else 'false'}, 8, false>"
 elif parts[2].startswith("ires_chain"):
     sub = "ires_chain_kernel<"      # both instantiations (J <= 32 at scale 0, J <= 128 at scale 1) form the bench class
+
+
+def chain_ok(name):
+    """ires_chain_kernel<JB, BF16, T2OUT>: keep the fp32 instantiations of the class bench.py reports (with or
+    without the stored intermediate); every other kernel family passes"""
+    if "ires_chain_kernel<" not in name:
+        return True
+    args = name.split("ires_chain_kernel<")[-1].split(">")[0].replace(" ", "").split(",")
+    return args[1] == "false" and args[2] == ("true" if "t2out" in parts else "false")
+
+
 out = {"kernel": f"{sub} = {key}", "bench_key": key,
        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 1 --warmup 1 "
                   "--no-cpu-baseline (tools/measure_round.sh)"}
@@ -37,7 +48,7 @@ for name, d in (("FETCH_SIZE", "final_fetch"), ("WRITE_SIZE", "final_write")):
     # ("...,splitk,gated"): keep only launches with >= 512 workgroups, i.e. the class bench.py reports
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
          if sub and sub in r["Kernel_Name"] and r["Counter_Name"] == name
-         and int(r["Grid_Size"]) // int(r["Workgroup_Size"]) >= 512 and ", true>" not in r["Kernel_Name"].split("ires_chain_kernel")[-1][:12]]
+         and int(r["Grid_Size"]) // int(r["Workgroup_Size"]) >= 512 and chain_ok(r["Kernel_Name"])]
     vals[name] = sum(v) / max(1, len(v))
     out["launches"] = len(v)
     out[f"{name}_KB_per_launch"] = vals[name]
