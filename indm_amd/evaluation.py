@@ -102,3 +102,57 @@ def get_bpd(config, eval_ds, scaler, nelbo_fn, nll_fn, score_model, flow_model=N
         if config.flow.model != "identity":
             flow_model.train()
     return results
+
+
+# ----------------------------------------------------------------------------- FID / IS statistics
+# The reference feeds samples through an Inception-v3 it downloads at run time (TF-Hub / clean-fid weights:
+# evaluation.py:100-158, cleanfid/features.py) and reduces the pooled features / logits below.  The network is an
+# external asset that is not part of the reference tree (and there is no network here): callers pass the features.
+def feature_statistics(pool3):
+    """mean [D] and covariance [D, D] (rowvar=False, unbiased) of pooled features [N, D] (cleanfid/fid.py:101-103)"""
+    f = np.asarray(pool3, dtype=np.float64)
+    return f.mean(axis=0), np.cov(f, rowvar=False)
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """||mu1 - mu2||^2 + Tr(S1 + S2 - 2 (S1 S2)^(1/2)) with the singular-product fallback of cleanfid/fid.py:27-80"""
+    from scipy import linalg
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    if mu1.shape != mu2.shape or sigma1.shape != sigma2.shape:
+        raise ValueError("feature statistics of different dimensions")
+    diff = mu1 - mu2
+    covmean = linalg.sqrtm(sigma1.dot(sigma2))
+    if not np.isfinite(covmean).all():
+        off = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + off).dot(sigma2 + off))
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            raise ValueError(f"Imaginary component {np.max(np.abs(covmean.imag))}")
+        covmean = covmean.real
+    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2.0 * np.trace(covmean))
+
+
+def fid_from_features(pool3_samples, pool3_data):
+    return frechet_distance(*feature_statistics(pool3_samples), *feature_statistics(pool3_data))
+
+
+def inception_score_from_logits(logits):
+    """exp(E_x KL(p(y|x) || p(y)))  (tfgan.eval.classifier_score_from_logits, evaluation.py:365)"""
+    z = np.asarray(logits, dtype=np.float64)
+    logp = z - z.max(axis=1, keepdims=True)
+    logp = logp - np.log(np.exp(logp).sum(axis=1, keepdims=True))
+    p = np.exp(logp)
+    log_py = np.log(p.mean(axis=0, keepdims=True))
+    return float(np.exp((p * (logp - log_py)).sum(axis=1).mean()))
+
+
+def inception_scores_10_splits(all_logits, split=5000):
+    """evaluation.py:352-374: the score of each of the 10 consecutive 5000-sample splits"""
+    out = []
+    for k in range(10):
+        part = all_logits[k * split:(k + 1) * split]
+        if len(part) != split:
+            raise ValueError(f"split {k} holds {len(part)} logits, expected {split}")
+        out.append(inception_score_from_logits(part))
+    return out

@@ -206,3 +206,32 @@ def test_initialisers_match_the_reference():
             continue
         assert abs(float(v.pow(2).sum()) - ref[1]) <= (8.0 / n ** 0.5) * ref[1] + 1e-9, (k, float(v.pow(2).sum()), ref[1])
         assert float(v.min()) >= 2.5 * min(ref[2], 0.0) - 1e-6 and float(v.max()) <= 2.5 * max(ref[3], 0.0) + 1e-6, k
+
+
+def test_fid_and_inception_score_statistics():
+    """closed forms: FID of two Gaussians' exact statistics; IS of one-hot / uniform predictions"""
+    import numpy as np
+    from indm_amd import evaluation as ev
+    rs = np.random.RandomState(0)
+    d = 6
+    A, B = rs.randn(d, d), rs.randn(d, d)
+    s1, s2 = A @ A.T + np.eye(d), B @ B.T + np.eye(d)
+    m1, m2 = rs.randn(d), rs.randn(d)
+    assert abs(ev.frechet_distance(m1, s1, m1, s1)) < 1e-8
+    # commuting covariances: Tr(S1 + S2 - 2 sqrt(S1 S2)) = sum (sqrt(l1) - sqrt(l2))^2
+    l1, l2 = rs.rand(d) + 0.5, rs.rand(d) + 0.5
+    want = ((m1 - m2) ** 2).sum() + ((np.sqrt(l1) - np.sqrt(l2)) ** 2).sum()
+    assert abs(ev.frechet_distance(m1, np.diag(l1), m2, np.diag(l2)) - want) < 1e-9
+    assert abs(ev.frechet_distance(m1, s1, m2, s2) - ev.frechet_distance(m2, s2, m1, s1)) < 1e-8   # symmetric
+    x = rs.randn(4000, d) @ A.T + m1
+    mu, sg = ev.feature_statistics(x)
+    assert np.allclose(mu, x.mean(0)) and np.allclose(sg, np.cov(x, rowvar=False))
+    assert ev.fid_from_features(x, x) < 1e-8 and ev.fid_from_features(x, x + 3.0) > 9.0 * d - 1e-6
+    K = 10
+    onehot = np.full((5000, K), -50.0)
+    onehot[np.arange(5000), np.arange(5000) % K] = 50.0
+    assert abs(ev.inception_score_from_logits(onehot) - K) < 1e-6          # confident and balanced: IS = #classes
+    assert abs(ev.inception_score_from_logits(np.zeros((100, K))) - 1.0) < 1e-12
+    assert len(ev.inception_scores_10_splits(np.tile(onehot, (10, 1)))) == 10
+    with pytest.raises(ValueError):
+        ev.inception_scores_10_splits(onehot)
