@@ -154,7 +154,19 @@ def _ptr(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of torch's CURRENT stream (side streams of graph capture included); torch.cuda.current_stream()
+    # builds a Stream object through ~10 Python frames (8.6 us per launch = 10 ms of host time per training step)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def to_device(t, device):
+    """Small host tensor ([B] schedule vectors, tables) -> device through pinned memory, non-blocking: a pageable
+    `.to(device)` stages synchronously (0.4 ms each, nine per training step).  The caching host allocator keeps the
+    pinned block alive until the copy has run."""
+    device = torch.device(device)
+    if device.type != "cuda" or t.is_cuda:
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
 
 
 _ws_cache = {}

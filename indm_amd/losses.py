@@ -9,7 +9,7 @@ flat-buffer all-reduce (if distributed) and one fused clip+AdamW+EMA pass per ne
 import numpy as np
 import torch
 
-from . import ops, sde_lib
+from . import hip, ops, sde_lib
 from .flow import flow_forward
 from .optim import FusedAdamW
 from .rng import DeviceRng, default_rng, mix64
@@ -46,11 +46,21 @@ def optimization_manager(config):
 
 
 # ----------------------------------------------------------------------------- model / score wrappers
+def set_mode(model, train):
+    """model.train() / model.eval() as the reference calls them on EVERY use (models/utils.py:118-123), without
+    re-assigning 780 unchanged `training` attributes through nn.Module.__setattr__ (3 ms of host time per step)."""
+    train = bool(train)
+    for m in model.modules():
+        if m.training != train:
+            m.training = train
+    return model
+
+
 def get_model_fn(model, train=False):
     """models/utils.py:96-125"""
 
     def model_fn(x, labels, **kw):
-        model.train() if train else model.eval()
+        set_mode(model, train)
         return model(x, labels, **kw)
 
     return model_fn
@@ -64,15 +74,15 @@ def get_score_fn(config, sde, model, gamma_t=None, train=False, continuous=False
     if isinstance(sde, VPSDE):
         def score_fn(x, t):
             th = t.detach().cpu()
-            out = model_fn(x, (th * 999).to(x.device), rng=rng)
+            out = model_fn(x, hip.to_device(th * 999, x.device), rng=rng)
             if config.training.ddpm_score:
                 std = sde.marginal_coeffs(th)[1]
-                out = ops.scale_rows(out, (-1.0 / std).to(x.device))
+                out = ops.scale_rows(out, hip.to_device(-1.0 / std, x.device))
             return out
     elif isinstance(sde, VESDE):
         def score_fn(x, t):
             labels = sde.marginal_coeffs(t.detach().cpu())[1]
-            return model_fn(x, labels.to(x.device), rng=rng)
+            return model_fn(x, hip.to_device(labels, x.device), rng=rng)
     else:
         raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
     return score_fn
@@ -104,9 +114,9 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
         mc, std, labels = _host_schedule(sde, t)
         z = rng.randn_image(B, C, H, W)                                    # losses.py:103 (NHWC here)
         net = _unwrap(model)
-        net.train() if train else net.eval()
-        xt = ops.sde_perturb(ops.to_nhwc(batch), z, mc.to(dev), std.to(dev))
-        out = net(xt, labels.to(dev), rng=rng, nhwc=True)
+        set_mode(net, train)
+        xt = ops.sde_perturb(ops.to_nhwc(batch), z, hip.to_device(mc, dev), hip.to_device(std, dev))
+        out = net(xt, hip.to_device(labels, dev), rng=rng, nhwc=True)
         if importance_sampling or not config.training.likelihood_weighting:
             w = (0.5 * Z) * torch.ones(B)
             mode = 0
@@ -114,7 +124,7 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
             g2 = sde.diffusion(t) ** 2
             w = 0.5 * Z * g2
             mode = 1
-        return ops.dsm_loss(out, z, std.to(dev), w.float().to(dev), kind, mode, reduce_mean)
+        return ops.dsm_loss(out, z, hip.to_device(std, dev), hip.to_device(w.float(), dev), kind, mode, reduce_mean)
 
     return loss_fn
 
@@ -136,7 +146,7 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         Ts = torch.ones(B) * sde.T
         mc, std = sde.marginal_coeffs(Ts)
         z = rng.randn_image(B, C, H, W)
-        yT = ops.sde_perturb(ops.to_nhwc(batch), z, mc.to(batch.device), std.to(batch.device))
+        yT = ops.sde_perturb(ops.to_nhwc(batch), z, hip.to_device(mc, batch.device), hip.to_device(std, batch.device))
         return sde_lib.prior_logp(sde, yT)
 
     def _zero(state):

@@ -39,11 +39,13 @@ class FlatParams:
         self.p = flat_p[offset:offset + self.numel]
         self.g = flat_g[offset:offset + self.numel]
         o = 0
+        self.gslices = []   # (parameter, its slice of the flat gradient buffer, that slice's address)
         for _, p in self.named:
             n = p.numel()
             self.p[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.p[o:o + n].view(p.shape)
             p.grad = self.g[o:o + n].view(p.shape)
+            self.gslices.append((p, self.g[o:o + n], self.g[o:o + n].data_ptr()))
             o += _pad4(n)
 
     def zero_grad(self):
@@ -59,14 +61,12 @@ class FlatParams:
         Idempotent until the next zero_grad() (the all-reduce and the optimiser then work on the flat buffer)."""
         if getattr(self, "gathered", False):
             return
-        srcs, dsts, o = [], [], 0
-        for _, p in self.named:
-            n = p.numel()
+        srcs, dsts = [], []
+        for p, dst, addr in self.gslices:
             g = p.grad
-            if g is not None and g.data_ptr() != self.g[o:o + n].data_ptr():
+            if g is not None and g.data_ptr() != addr:
                 srcs.append(g if g.is_contiguous() else g.contiguous())
-                dsts.append(self.g[o:o + n])
-            o += _pad4(n)
+                dsts.append(dst)
         hip.multi_copy(srcs, dsts)
         self.gathered = True
 
