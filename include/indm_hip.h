@@ -174,6 +174,12 @@ int indm_ires_chain_f32(const float* A, const float* G, const float* W2T, const 
                         float* T2, int M, int K, int N, int J, void* stream);
 int indm_ires_chain_bf16(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p, float* P,
                          float* T2, int M, int K, int N, int J, void* stream);
+/* bf16 compute with W2T pre-packed once per flow call into bf16 MFMA-fragment order
+ *   W2Tp[s][b][lane][e] = bf16(W2T[16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 b + (lane & 31)]),  s < K/16, b < 16, e < 8
+ * (512 KB, read straight into registers; A and the gate rotate through three 8 KB LDS buffers).  Same results as
+ * indm_ires_chain_bf16. */
+int indm_ires_chain_bf16w(const float* A, const float* G, const void* W2Tp, const float* D1, const float* W1p, float* P,
+                          float* T2, int M, int K, int N, int J, void* stream);
 long indm_ires_bwd_act_ws_floats(long R, int C);
 int indm_ires_bwd_act_f32(const float* da, const float* du, const float* d, const float* a, const float* t, float* dp,
                           float* dt_out, float* seg_out, long R, int C, long rows_per_seg, float* ws, void* stream);

@@ -39,6 +39,102 @@ struct ChainArgs {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 
+// Everything after the first contraction, shared by the kernels below: optional store of the intermediate, the d1
+// gate, the second contraction against the W1 panel and the 8-way cross-wave reduction (see the header comment).
+// acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi] on entry; every wave has passed a
+// workgroup barrier after its last read of the operand buffers (`red` overlays them).
+template <int JB, bool BF16, bool T2OUT>
+__device__ __forceinline__ void chain_epilogue(const ChainArgs& p, f32x16 (&acc)[2][2], float* smem, int tid, int wave,
+                                               int m0, int nw, int l31, int lhi) {
+  if constexpr (T2OUT) {  // 16-byte pieces, a 128-byte row segment is completed by four stores of the same wave
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float* trow = p.T2 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          *(float4*)(trow + i * 32 + 8 * a) =
+              make_float4(acc[i][j][4 * a], acc[i][j][4 * a + 1], acc[i][j][4 * a + 2], acc[i][j][4 * a + 3]);
+    }
+  }
+  // ---- gate: acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi]  *=  d1[m][n] ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float* drow = p.D1 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 g[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) g[a] = *(const float4*)(drow + i * 32 + 8 * a);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        acc[i][j][4 * a + 0] *= g[a].x;
+        acc[i][j][4 * a + 1] *= g[a].y;
+        acc[i][j][4 * a + 2] *= g[a].z;
+        acc[i][j][4 * a + 3] *= g[a].w;
+      }
+      if constexpr (BF16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = bf16_round(acc[i][j][r]);
+      }
+    }
+  }
+
+  // ---- stage 2: out[m][j] = sum over this wave's 64 n's of u1[m][n] * W1p[n][j]; 8-way reduce through LDS ----
+  const int JP = 32 * JB;
+  float* red = smem;  // [8 waves][64 m][32 j] = 64 KB (the operand buffers are dead)
+#pragma unroll 1
+  for (int jb = 0; jb < JB; ++jb) {
+    f32x16 out[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float w[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        w[r] = p.W1p[(long)(nw + i * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi) * JP + jb * 32 + l31];
+      if constexpr (BF16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = bf16_round(w[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          out[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[i][j][r], w[r], out[j], 0, 0, 0);  // D'[m][j]
+    }
+    if (jb > 0) __syncthreads();  // the previous round's reduction has read `red`
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = j * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi;
+        red[(wave * 64 + m) * 32 + l31] = out[j][r];
+      }
+    __syncthreads();
+    // 64 x 32 outputs, 4 per thread: thread -> (m = tid / 8, j = (tid % 8) * 4 .. +3)
+    {
+      const int m = tid >> 3, j0 = (tid & 7) * 4;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) {
+        const float4 v = *(const float4*)(red + (wv * 64 + m) * 32 + j0);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      float* dst = p.P + (long)(m0 + m) * p.J + jb * 32 + j0;
+      const int left = p.J - (jb * 32 + j0);
+      if (left > 0) dst[0] = s.x;
+      if (left > 1) dst[1] = s.y;
+      if (left > 2) dst[2] = s.z;
+      if (left > 3) dst[3] = s.w;
+    }
+  }
+}
+
 // BF16: MFMA inputs rounded to bf16 (RNE), fp32 accumulate -- stage 1 packs both 4-deep fragments of a slab into one
 // v_mfma_f32_32x32x16_bf16 (as igemm_glds_kernel<.., BF16>); stage 2 rounds its operands to bf16 and keeps the fp32
 // MFMA (products of bf16 values are exact in fp32: identical to a bf16 MFMA).
@@ -167,93 +263,130 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   mfmas(fm1, fn1);
   }
 
-  if constexpr (T2OUT) {  // 16-byte pieces, a 128-byte row segment is completed by four stores of the same wave
+  chain_epilogue<JB, BF16, T2OUT>(p, acc, smem, tid, wave, m0, nw, l31, lhi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 compute with PRE-PACKED weights (round 2).  With bf16 MFMAs (8x fewer matrix cycles) the kernel above is no
+// longer MFMA-bound but LDS-bound: every one of the 8 waves re-reads the whole fp32 A and gate slab (its 64 x 64 tile
+// spans all 64 rows) plus its W2T fragments as eight ds_read_b32 each, and the 32 KB fp32 image of the W2T slab is
+// re-staged into LDS for every slab -- 302 us for the 805 MB of A + gate + d1 at batch 128 (2.7 TB/s).  Here the host
+// packs W2T once per flow call into bf16 MFMA-fragment order (`Bp[slab][32-column block][lane][8]`, 512 KB,
+// L2-resident): its slab image shrinks to 16 KB (copied by the waves that use it, one ds_read_b128 per fragment), a
+// buffer to 24 KB, three buffers rotate (two slabs in flight per workgroup, two workgroups per CU), the loop waits with
+// vmcnt(3) for the older slab only and synchronises with a bare s_barrier (no fence: __syncthreads() would drain the
+// copies).  231 us / 82 us at the two scales (302 / 92 before).  Measured alternatives: six buffers with one 144 KB
+// workgroup per CU 254 us (the epilogue no longer overlaps another workgroup's main loop); W2T fragments fetched
+// straight into registers 224 us but vmcnt's in-order retirement then ties the copies to the register loads.  What
+// bounds it now is the 8-fold re-read of the fp32 A / gate slab from LDS (80 KB of ds_read per 16-deep slab and
+// workgroup): removing that needs bf16 A / gate images, i.e. a conversion pass or bf16 storage.
+// Same rounding points (RNE to bf16 of W, of the gated product, of the stage-2 operands) and the same epilogue as
+// ires_chain_kernel<., true, .>: bit-identical results.
+// k order inside a lane's 8-element fragment (both operands): e -> 8 (e >> 2) + 4 lhi + (e & 3).
+struct ChainArgsPW {
+  ChainArgs c;
+  const void* Bp;  // packed bf16 W2T: [K / 16][512 / 32][64 lanes][8]
+};
+constexpr int PW_NBUF = 3, PW_D = PW_NBUF - 1, PW_B = 16 * 64 * 4, PW_BUF = A_SZ + G_SZ + PW_B;  // floats
+
+template <int C>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C) : "memory"); }
+
+template <int JB, bool T2OUT>
+__global__ __launch_bounds__(NW * 64, 4) void ires_chain_pw_kernel(ChainArgsPW q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ChainArgs& p = q.c;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * TM;
+  const int nk = p.K / BK;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int swz = (l31 >> 2) & 3;
+  const int nw = wave * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // three copies per wave and slab: 16 rows of A (waves 0-3) or of the gate (waves 4-7), and the wave's own two
+  // 32-column blocks of the packed W2T slab (1 KB each: lane l of the copy lands at byte 16 l, fragment order)
+  const int arow = (wave & 3) * 16 + (lane >> 2);
+  const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
+  const float* pa = (wave < 4 ? p.A : p.G) + (long)(m0 + arow) * p.K + 4 * achunk;
+  const int a_dst = (wave < 4 ? 0 : A_SZ) + (wave & 3) * 16 * BK;
+  const float* pb = (const float*)q.Bp + ((long)(wave * 2) * 64 + lane) * 4;
+  const int b_dst = A_SZ + G_SZ + wave * 2 * 256;
+  auto dma = [&](const float* src, float* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto stage = [&](int buf) {
+    float* base = smem + buf * PW_BUF;
+    dma(pa, base + a_dst);
+    dma(pb, base + b_dst);
+    dma(pb + 256, base + b_dst + 256);
+    pa += BK;
+    pb += 16 * 256;
+  };
+
+  const int pre = nk < PW_D ? nk : PW_D;
+  for (int d = 0; d < pre; ++d) stage(d);
+  if (nk >= PW_D) wait_vm<3 * (PW_D - 1)>();   // slab 0 has landed, the rest of the prologue is on its way
+  else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  int buf = 0, sbuf = PW_D % PW_NBUF;   // buffer of slab s / of slab s + PW_D
+  for (int s = 0; s < nk; ++s) {
+    if (s + PW_D < nk) stage(sbuf);     // its previous contents (slab s - 1) were read before the last barrier
+    const float* as = smem + buf * PW_BUF;
+    bf16x8 hm[2], hn[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) hn[i] = *(const bf16x8*)(as + b_dst + i * 256 + lane * 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      float* trow = p.T2 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-          *(float4*)(trow + i * 32 + 8 * a) =
-              make_float4(acc[i][j][4 * a], acc[i][j][4 * a + 1], acc[i][j][4 * a + 2], acc[i][j][4 * a + 3]);
-    }
-  }
-  // ---- gate: acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi]  *=  d1[m][n] ----
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const float* drow = p.D1 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float4 g[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) g[a] = *(const float4*)(drow + i * 32 + 8 * a);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        acc[i][j][4 * a + 0] *= g[a].x;
-        acc[i][j][4 * a + 1] *= g[a].y;
-        acc[i][j][4 * a + 2] *= g[a].z;
-        acc[i][j][4 * a + 3] *= g[a].w;
-      }
-      if constexpr (BF16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = bf16_round(acc[i][j][r]);
+      for (int sg = 0; sg < 2; ++sg) {
+        const int o = (j * 32 + l31) * BK + (((sg * 2 + lhi) ^ swz) << 2);
+        const f32x4 u = *(const f32x4*)(as + o) * *(const f32x4*)(as + A_SZ + o);
+        hm[j][4 * sg + 0] = (__bf16)u.x; hm[j][4 * sg + 1] = (__bf16)u.y;
+        hm[j][4 * sg + 2] = (__bf16)u.z; hm[j][4 * sg + 3] = (__bf16)u.w;
       }
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hn[i], hm[j], acc[i][j], 0, 0, 0);  // D[n][m]
+    __builtin_amdgcn_sched_barrier(0);
+    // slab s + 1 must have landed; the younger ones (PW_D - 1 at most) stay in flight: 3 copies per slab
+    const int younger = min(PW_D - 1, nk - 2 - s);
+    if (younger >= 4) wait_vm<12>();
+    else if (younger == 3) wait_vm<9>();
+    else if (younger == 2) wait_vm<6>();
+    else if (younger == 1) wait_vm<3>();
+    else wait_vm<0>();   // (PW_D - 1 bounds `younger`: the deeper cases fold away for a short rotation)
+    __builtin_amdgcn_s_barrier();
+    buf = buf + 1 == PW_NBUF ? 0 : buf + 1;
+    sbuf = sbuf + 1 == PW_NBUF ? 0 : sbuf + 1;
   }
+  chain_epilogue<JB, true, T2OUT>(p, acc, smem, tid, wave, m0, nw, l31, lhi);
+}
 
-  // ---- stage 2: out[m][j] = sum over this wave's 64 n's of u1[m][n] * W1p[n][j]; 8-way reduce through LDS ----
-  const int JP = 32 * JB;
-  float* red = smem;  // [8 waves][64 m][32 j] = 64 KB (the operand buffers are dead)
-#pragma unroll 1
-  for (int jb = 0; jb < JB; ++jb) {
-    f32x16 out[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) out[j][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float w[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        w[r] = p.W1p[(long)(nw + i * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi) * JP + jb * 32 + l31];
-      if constexpr (BF16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) w[r] = bf16_round(w[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          out[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[i][j][r], w[r], out[j], 0, 0, 0);  // D'[m][j]
-    }
-    if (jb > 0) __syncthreads();  // the previous round's reduction has read `red`
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = j * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi;
-        red[(wave * 64 + m) * 32 + l31] = out[j][r];
-      }
-    __syncthreads();
-    // 64 x 32 outputs, 4 per thread: thread -> (m = tid / 8, j = (tid % 8) * 4 .. +3)
-    {
-      const int m = tid >> 3, j0 = (tid & 7) * 4;
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int wv = 0; wv < NW; ++wv) {
-        const float4 v = *(const float4*)(red + (wv * 64 + m) * 32 + j0);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-      float* dst = p.P + (long)(m0 + m) * p.J + jb * 32 + j0;
-      const int left = p.J - (jb * 32 + j0);
-      if (left > 0) dst[0] = s.x;
-      if (left > 1) dst[1] = s.y;
-      if (left > 2) dst[2] = s.z;
-      if (left > 3) dst[3] = s.w;
-    }
+template <int JB, bool T2OUT>
+int launch_chain_pw_t(const ChainArgsPW& q, hipStream_t st) {
+  constexpr size_t bytes = PW_NBUF * PW_BUF * sizeof(float);  // 72 KB (the 64 KB stage-2 reduction buffer overlays it)
+  static bool ready = false;
+  if (!ready) {
+    if (hipFuncSetAttribute((const void*)ires_chain_pw_kernel<JB, T2OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+      return INDM_E_LAUNCH;
+    ready = true;
   }
+  hipLaunchKernelGGL((ires_chain_pw_kernel<JB, T2OUT>), dim3(q.c.M / TM), dim3(NW * 64), bytes, st, q);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
 template <int JB, bool BF16, bool T2OUT>
@@ -300,4 +433,17 @@ INDM_API int indm_ires_chain_f32(const float* A, const float* G, const float* W2
 INDM_API int indm_ires_chain_bf16(const float* A, const float* G, const float* W2T, const float* D1, const float* W1p,
                                   float* P, float* T2, int M, int K, int N, int J, void* stream) {
   return ires_chain_impl(true, A, G, W2T, D1, W1p, P, T2, M, K, N, J, stream);
+}
+
+// bf16 compute with W2T pre-packed by the caller (indm_pack_w2t_bf16 layout): see ires_chain_pw_kernel
+INDM_API int indm_ires_chain_bf16w(const float* A, const float* G, const void* W2Tp, const float* D1, const float* W1p,
+                                   float* P, float* T2, int M, int K, int N, int J, void* stream) {
+  if (M < 0 || K <= 0 || N <= 0 || J <= 0) return INDM_E_SHAPE;
+  if (M == 0) return INDM_OK;
+  if (N != TN || (M % TM) || (K % BK) || K < 2 * BK || J > 128) return 1;
+  if (((uintptr_t)A | (uintptr_t)G | (uintptr_t)W2Tp | (uintptr_t)D1 | (uintptr_t)W1p | (uintptr_t)T2) & 15) return 1;
+  ChainArgsPW q = {{A, G, nullptr, D1, W1p, P, M, K, J, T2}, W2Tp};
+  hipStream_t st = (hipStream_t)stream;
+  if (J <= 32) return T2 ? launch_chain_pw_t<1, true>(q, st) : launch_chain_pw_t<1, false>(q, st);
+  return T2 ? launch_chain_pw_t<4, true>(q, st) : launch_chain_pw_t<4, false>(q, st);
 }

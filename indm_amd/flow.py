@@ -365,6 +365,8 @@ class ResidualFlow(nn.Module):
         cb = ops.gemm(c, w2)                                                           # [NB, B, idim]
         cbs = cb.unbind(0)  # backward = one stack
         w2ts = w2.transpose(1, 2).contiguous().unbind(0)   # W2^T of every block, one launch (used by the VJP chains)
+        if hip.compute_dtype() == "bf16":
+            hip.pack_w2t_bf16(list(w2ts))   # bf16 fragment-order copies for the chain kernel (two launches)
         # W1 of every block as the [idim, 32 | 128] zero-padded panel of the back-to-back chain kernel (no-grad series
         # iterations only): one stack + transpose + pad per scale
         panels = {}

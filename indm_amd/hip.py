@@ -77,6 +77,7 @@ _SIGS = {
     "indm_unsqueeze2x_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_nchw_nhwc_f32": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_split_cols_f32": [c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p],
+    "indm_ires_chain_bf16w": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_weightnorm_fwd_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "indm_weightnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p],
     "indm_lop_normalize_fwd_f32": [c_p, c_p, c_p, c_i, c_i, c_f, c_p],
@@ -648,6 +649,28 @@ def attn_bwd(q, k, v, h, dh, lse, scale):
     return dq, dk, dv
 
 
+_w2t_packed = {}  # id(w2t) -> (weakref, version, packed bf16 copy)
+
+
+def pack_w2t_bf16(w2ts):
+    """bf16 MFMA-fragment-order copies of a list of same-shape [K, 512] fp32 weights (two launches for the whole list),
+    registered for ires_chain's bf16 path:  out[s][b][lane][e] = bf16(w[16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 b + (lane & 31)])."""
+    import weakref
+    if not w2ts:
+        return
+    K, N = w2ts[0].shape
+    if K % 16 or N % 32:
+        return
+    with torch.no_grad():
+        st = torch.stack([w.detach() for w in w2ts]).to(torch.bfloat16)                      # [n, K, N]
+        pk = st.view(len(w2ts), K // 16, 2, 2, 4, N // 32, 32).permute(0, 1, 5, 3, 6, 2, 4).contiguous()
+    if len(_w2t_packed) > 1024:
+        for k in [k for k, v in _w2t_packed.items() if v[0]() is None]:
+            del _w2t_packed[k]
+    for i, w in enumerate(w2ts):
+        _w2t_packed[id(w)] = (weakref.ref(w), w._version, pk[i])
+
+
 def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
     """P[M, J] = ((t3 .* d2) @ w2t .* d1) @ w1p[:, :J] in ONE launch with the 512-wide intermediate kept on chip (the
     back-to-back contraction of the VJP chain).  t3, d2: [M, K]; w2t: [K, 512]; d1: [M, 512]; w1p: [512, 32 if J <= 32 else 128] (zero-padded).
@@ -659,8 +682,13 @@ def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
     t2 = torch.empty((M, N), dtype=torch.float32, device=t3.device) if want_t2 else None
     nbytes = 4 * (2 * t3.numel() + d1.numel() + w2t.numel() + P.numel() + (t2.numel() if want_t2 else 0))
     with _timed("A_ROW", "B_ROW", M, N, K, nbytes=nbytes) as tm:
-        st = _dense("ires_chain")(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), _ptr(t2), M, K, N, J,
-                                  _stream())
+        hit = _w2t_packed.get(id(w2t)) if _MFMA["dtype"] == "bf16" else None
+        if hit is not None and hit[0]() is w2t and hit[1] == w2t._version:
+            st = lib().indm_ires_chain_bf16w(_ptr(t3), _ptr(d2), hit[2].data_ptr(), _ptr(d1), _ptr(w1p), _ptr(P),
+                                             _ptr(t2), M, K, N, J, _stream())
+        else:
+            st = _dense("ires_chain")(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), _ptr(t2), M, K, N, J,
+                                      _stream())
         # the launch that also stores the 512-wide intermediate (training's last chain link) is its own class:
         # same MFMA work plus a 4*M*N-byte store
         tm.variant = ("ires_chain64x512,gated" + (",t2out" if want_t2 else "")

@@ -521,3 +521,7 @@ def weightnorm_bwd(dw, v, g, n):
 
 def prepack_weights(ws):
     return None
+
+
+def pack_w2t_bf16(w2ts):
+    return None

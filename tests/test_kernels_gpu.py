@@ -762,6 +762,36 @@ def test_bf16_ires_chain(bf16_mode, M, J):
     close(out, ref, rtol=2e-4, atol=2e-4, name="bf16 ires_chain")
 
 
+@pytest.mark.parametrize("M,K,J", [(256, 512, 27), (8192, 512, 108), (131072, 512, 27), (64, 32, 5), (192, 48, 128)])
+def test_bf16_ires_chain_packed_weights(bf16_mode, M, K, J):
+    """W2T pre-packed into bf16 fragment order and read straight into registers (three rotating A/gate buffers): the
+    same rounding points as the LDS-image kernel, so the two agree to accumulation order; also vs exact products"""
+    JP = 32 if J <= 32 else 128
+    t3, d2, d1 = rnd(M, K, seed=1), rnd(M, K, seed=2), rnd(M, 512, seed=3)
+    w2t = rnd(K, 512, seed=4, scale=K ** -0.5).to(DEV)
+    w1p = torch.zeros(512, JP)
+    w1p[:, :J] = rnd(512, J, seed=5, scale=512 ** -0.5)
+    args = (t3.to(DEV), d2.to(DEV), w2t, d1.to(DEV), w1p.to(DEV), J)
+    plain, t2_plain = hip.ires_chain(*args, want_t2=True)
+    hip.pack_w2t_bf16([w2t])
+    assert id(w2t) in hip._w2t_packed
+    # the packed layout itself
+    pk = hip._w2t_packed[id(w2t)][2].cpu().float()
+    s_, b_, lane, e = 1 % (K // 16), 7, 45, 6
+    assert pk[s_, b_, lane >> 5, lane & 31, e >> 2, e & 3] == _r16(w2t.cpu())[16 * s_ + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3), 32 * b_ + (lane & 31)]
+    out, t2 = hip.ires_chain(*args, want_t2=True)
+    close(t2, t2_plain.cpu().double(), rtol=1e-5, atol=1e-5, name="packed-weight chain t2 vs LDS-image kernel")
+    close(out, plain.cpu().double(), rtol=2e-4, atol=2e-4, name="packed-weight chain P vs LDS-image kernel")
+    ref_t2 = _r16(t3 * d2).double() @ _r16(w2t.cpu()).double()
+    close(t2, ref_t2, rtol=1e-5, atol=1e-4, name="packed-weight chain t2 vs exact products")
+    out1 = hip.ires_chain(*args)
+    close(out1, out.cpu().double(), rtol=1e-6, atol=1e-6, name="packed-weight chain without the t2 store")
+    w2t.add_(1.0)   # a modified weight must not hit the stale packed copy
+    out2 = hip.ires_chain(*args)
+    assert not torch.allclose(out2, out)
+    del hip._w2t_packed[id(w2t)]
+
+
 @pytest.mark.parametrize("C", [3, 12])
 def test_bf16_thin_kernels(bf16_mode, C):
     """bf16 mode on the HBM-bound thin kernels (skinny 3x3 convs of the flow, their transposes and weight grads):
