@@ -262,7 +262,12 @@ def main():
     from indm_amd.flow import create_flow_model
     from indm_amd.rng import DeviceRng
 
-    rank, world, local = parallel.init_distributed()
+    # test hook (tests/test_bench_multirank_gpu.py): all ranks share GPU 0 and exchange gradients over gloo, so that
+    # the multi-process path of this file can be exercised on a single-GPU box (RCCL refuses two ranks on one device)
+    one_gpu = os.environ.get("INDM_BENCH_ONE_GPU") == "1"
+    rank, world, local = parallel.init_distributed(backend="gloo" if one_gpu else None)
+    if one_gpu:
+        local = 0
     strong = args.global_batch > 0
     if strong:
         if args.global_batch % world:

@@ -1,0 +1,41 @@
+"""bench.py's multi-process path end to end on a single-GPU box: two ranks launched with torch.distributed.run exactly
+as the driver launches N ranks, sharing GPU 0 and exchanging gradients over gloo (INDM_BENCH_ONE_GPU=1; the real run is
+one rank per GPU over RCCL).  Checks the contract line rank 0 prints, for weak and for strong scaling."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, port):
+    env = dict(os.environ, INDM_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--no-sampling"] + extra
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout           # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_bench_weak_and_strong():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    port = 29600 + os.getpid() % 300
+    weak = _run(["--batch", "8"], port)
+    assert weak["n_gpus"] == 2 and weak["steps"] == 2 and weak["warmup"] == 1 and weak["scaling"] == "weak"
+    assert weak["config"]["global_batch"] == 16 and weak["config"]["parallelism"] == "dp2"
+    assert weak["value"] > 0 and abs(weak["value"] - 16 * 1000.0 / weak["ms_per_step"]) < 1e-6 * weak["value"] + 1e-3
+    assert weak["roofline"]["bound"] == "mfma" and weak["roofline"]["achieved"] > 0
+    assert weak["cpu_baseline"] is None            # rank 0 at N = 1 only
+    strong = _run(["--global-batch", "16"], port + 1)
+    assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 16 and strong["n_gpus"] == 2
+    assert strong["value"] > 0
