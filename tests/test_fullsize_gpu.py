@@ -93,6 +93,48 @@ def test_full_size_training_step_matches_oracle(name):
 
 
 @pytest.mark.timeout(1500)
+def test_full_size_loss_curve_matches_oracle():
+    """BASELINE config #2's parity gate ("vs reference loss curve"): EIGHT consecutive optimisation steps of the
+    full-size vp/CIFAR10/indm_nll networks on a fresh batch each, HIP path vs CPU oracle on identical noise.  The four
+    per-image loss vectors agree to 1e-6 .. 1e-5 relative at every step (measured); the gate is 2e-4."""
+    torch.manual_seed(7)
+    np.random.seed(7)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.model.dropout = 0.0
+    cfg.training.batch_size = 2
+    dev = torch.device("cuda")
+    cfg.device = dev
+    score = utils.create_model(cfg, dev)
+    fl = create_flow_model(cfg).to(dev)
+    with torch.no_grad():
+        for n, p in score.named_parameters():
+            if p.dim() > 1 and p.abs().max() < 1e-6:
+                p.copy_(torch.randn_like(p) * 0.02)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
+    ost = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, cfg)
+    ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    state, fstate, _ = utils.build_states(cfg, score, fl, dev)
+    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+    score.train(); fl.train()
+    worst = 0.0
+    for it in range(8):
+        x = torch.rand(2, 3, 32, 32) * 2 - 1
+        rec = RecordingRng()
+        want = O.flow_step_fn_nll(cfg, O.get_sde(cfg), ost, ofst, x, rec)
+        rng = ReplayRng(rec.events, dev)
+        got = step_fn(state, fstate, x.to(dev), rng=rng)
+        assert rng.done()
+        for nm, a, b in zip(("loss", "score", "flow", "logp"), got, want):
+            rel = float(((a.double() - b.double()).abs() / (b.double().abs() + 1e-6)).max())
+            worst = max(worst, rel)
+            assert rel <= 2e-4, (it, nm, rel, a, b)
+    assert state["step"] == 8 and fstate["step"] == 8
+    print(f"worst relative difference over 8 steps: {worst:.2e}")
+
+
+@pytest.mark.timeout(1500)
 def test_full_size_nelbo_within_north_star_tolerance():
     """NELBO bits/dim of the full-size model (flow eval power-series log-det with n+20 terms, score loss integrand,
     Hutchinson divergence, prior, residual) on the HIP path vs the CPU oracle on the same noise: the north-star asks
