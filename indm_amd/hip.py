@@ -333,6 +333,8 @@ def prepack_weights(ws):
     if not ws:
         return
     KH, KW, Ci, Co = ws[0].shape
+    for k in [k for k, v in _packed.items() if v[0]() is None]:   # entries of weights that no longer exist (they pin
+        del _packed[k]                                            # the stacked copies of earlier flow calls)
     with torch.no_grad():
         st = torch.stack([w.detach() for w in ws])                                          # [n, KH, KW, Ci, Co]
         a = st.permute(0, 3, 1, 2, 4).reshape(len(ws), Ci, KH * KW * Co).contiguous()       # "ci_tapco"
@@ -664,9 +666,8 @@ def pack_w2t_bf16(w2ts):
     with torch.no_grad():
         st = torch.stack([w.detach() for w in w2ts]).to(torch.bfloat16)                      # [n, K, N]
         pk = st.view(len(w2ts), K // 16, 2, 2, 4, N // 32, 32).permute(0, 1, 5, 3, 6, 2, 4).contiguous()
-    if len(_w2t_packed) > 1024:
-        for k in [k for k, v in _w2t_packed.items() if v[0]() is None]:
-            del _w2t_packed[k]
+    for k in [k for k, v in _w2t_packed.items() if v[0]() is None]:   # drop the copies of weights that no longer exist
+        del _w2t_packed[k]
     for i, w in enumerate(w2ts):
         _w2t_packed[id(w)] = (weakref.ref(w), w._version, pk[i])
 

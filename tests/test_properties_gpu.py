@@ -111,3 +111,40 @@ def test_training_on_a_fixed_batch_reduces_the_objective(dtype):
         assert state["step"] == 30 and fstate["step"] == 30
     finally:
         hip.set_compute_dtype("f32")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_no_memory_growth_over_many_steps(dtype):
+    """60 training steps (full-size networks, batch 4, varying Poisson series lengths): the memory held between steps
+    and the sizes of the host-side caches (pointer tables, re-laid-out weights, packed bf16 weights) stay bounded."""
+    import gc
+    from indm_amd import losses, sde_lib, utils
+    dev = torch.device(DEV)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.device = dev
+    cfg.training.batch_size = 4
+    cfg.compute_dtype = dtype
+    torch.manual_seed(0)
+    score = utils.create_model(cfg, dev)
+    flow = create_flow_model(cfg).to(dev)
+    state, fstate, _ = utils.build_states(cfg, score, flow, dev)
+    try:
+        step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+        score.train(); flow.train()
+        rng = DeviceRng(dev, seed=11)
+        g = torch.Generator().manual_seed(2)
+        marks = {}
+        for it in range(60):
+            x = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+            out = step_fn(state, fstate, x, rng=rng)
+            del out, x
+            if it in (19, 39, 59):
+                torch.cuda.synchronize()
+                gc.collect()
+                marks[it] = torch.cuda.memory_allocated()
+    finally:
+        hip.set_compute_dtype("f32")
+    assert abs(marks[59] - marks[19]) <= 8 << 20, marks      # a few MB of cached tables at most
+    assert abs(marks[59] - marks[39]) <= 8 << 20, marks
+    assert len(hip._tables) <= 256 and len(hip._packed) <= 1100 and len(hip._w2t_packed) <= 1100
