@@ -128,3 +128,34 @@ def test_philox_noise_and_graphed_sampler():
     assert torch.equal(eager[0], graphed[0]) and torch.equal(eager[1], graphed[1]) and eager[2] == graphed[2]
     other = fn(score, fl, rng=DeviceRng("cuda", seed=10), graph=True)
     assert not torch.equal(other[0], graphed[0]) and torch.isfinite(other[1]).all()
+
+
+@pytest.mark.timeout(600)
+def test_repeated_sampling_and_nelbo_do_not_grow_memory():
+    """The evaluation-side entry points called in a loop (as evaluation.py / sampling_lib.py do for 50k samples): the
+    graphed predictor sampler, the corrector sampler and nelbo_fn release what they allocate (graph pools included)."""
+    import gc
+    from indm_amd import likelihood, sampling, sde_lib, utils
+    from indm_amd.rng import DeviceRng
+    d, cfg, score, fl = pc.build("mini_vp_nll", "cuda")
+    cfg.sampling.method, cfg.sampling.num_scales = "pc", 10
+    cfg.sampling.predictor, cfg.sampling.corrector = "euler_maruyama", "none"
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    inv = utils.get_data_inverse_scaler(cfg)
+    fn = sampling.get_sampling_fn(cfg, sde, (4, 3, 32, 32), inv, cfg.sampling.truncation_time, device="cuda")
+    nelbo = likelihood.get_elbo_fn(cfg, sde, inv)
+    x = torch.rand(4, 3, 32, 32, device="cuda") * 2 - 1
+    rng = DeviceRng("cuda", seed=3)
+    marks = []
+    for it in range(12):
+        out = fn(score, fl, rng=rng, graph=True)
+        out2 = fn(score, fl, rng=rng, graph=False)
+        nb = nelbo(score, fl, x, rng=rng)
+        assert torch.isfinite(out[1]).all() and torch.isfinite(out2[1]).all() and torch.isfinite(nb[0]).all()
+        del out, out2, nb
+        if it in (3, 7, 11):
+            torch.cuda.synchronize()
+            gc.collect()
+            marks.append(torch.cuda.memory_allocated())
+    assert abs(marks[2] - marks[0]) <= 4 << 20 and abs(marks[2] - marks[1]) <= 4 << 20, marks
