@@ -135,6 +135,43 @@ def test_full_size_loss_curve_matches_oracle():
 
 
 @pytest.mark.timeout(1500)
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_full_size_step_at_odd_batch_sizes(B):
+    """Row counts that are not a multiple of the big tiles (M = B * 1024 and B * 256 at the two flow scales, B * HW in
+    the U-Net): ragged tile tails, split-K slices and per-image segment reductions at a batch the goldens never use."""
+    torch.manual_seed(11 + B)
+    np.random.seed(11 + B)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.model.dropout = 0.0
+    cfg.training.batch_size = B
+    dev = torch.device("cuda")
+    cfg.device = dev
+    score = utils.create_model(cfg, dev)
+    fl = create_flow_model(cfg).to(dev)
+    with torch.no_grad():
+        for n, p in score.named_parameters():
+            if p.dim() > 1 and p.abs().max() < 1e-6:
+                p.copy_(torch.randn_like(p) * 0.02)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
+    ost = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, cfg)
+    ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    state, fstate, _ = utils.build_states(cfg, score, fl, dev)
+    step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+    score.train(); fl.train()
+    for it in range(2):
+        x = torch.rand(B, 3, 32, 32) * 2 - 1
+        rec = RecordingRng()
+        want = O.flow_step_fn_nll(cfg, O.get_sde(cfg), ost, ofst, x, rec)
+        rng = ReplayRng(rec.events, dev)
+        got = step_fn(state, fstate, x.to(dev), rng=rng)
+        assert rng.done()
+        for nm, a, b in zip(("loss", "score", "flow", "logp"), got, want):
+            gu.assert_close(a, b, 2e-4, 1e-5, f"batch {B} step {it} {nm}")
+
+
+@pytest.mark.timeout(1500)
 def test_full_size_nelbo_within_north_star_tolerance():
     """NELBO bits/dim of the full-size model (flow eval power-series log-det with n+20 terms, score loss integrand,
     Hutchinson divergence, prior, residual) on the HIP path vs the CPU oracle on the same noise: the north-star asks
