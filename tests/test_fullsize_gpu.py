@@ -135,10 +135,12 @@ def test_full_size_loss_curve_matches_oracle():
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("B", [1, 3, 5])
+@pytest.mark.parametrize("B", [1, 3, 5, 32])
 def test_full_size_step_at_odd_batch_sizes(B):
     """Row counts that are not a multiple of the big tiles (M = B * 1024 and B * 256 at the two flow scales, B * HW in
-    the U-Net): ragged tile tails, split-K slices and per-image segment reductions at a batch the goldens never use."""
+    the U-Net): ragged tile tails, split-K slices and per-image segment reductions at a batch the goldens never use.
+    B = 32 (config #5's per-rank shard) runs the whole step on the production variants (256-row direct-to-LDS tiles,
+    big-tile weight grads, chain kernel at M = 32 768 / 8 192) against the oracle: one step, ~40 s of CPU."""
     torch.manual_seed(11 + B)
     np.random.seed(11 + B)
     cfg = configs.get_config("vp/CIFAR10/indm_nll")
@@ -160,7 +162,7 @@ def test_full_size_step_at_odd_batch_sizes(B):
     state, fstate, _ = utils.build_states(cfg, score, fl, dev)
     step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
     score.train(); fl.train()
-    for it in range(2):
+    for it in range(2 if B < 32 else 1):
         x = torch.rand(B, 3, 32, 32) * 2 - 1
         rec = RecordingRng()
         want = O.flow_step_fn_nll(cfg, O.get_sde(cfg), ost, ofst, x, rec)
