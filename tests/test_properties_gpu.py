@@ -148,3 +148,50 @@ def test_no_memory_growth_over_many_steps(dtype):
     assert abs(marks[59] - marks[19]) <= 8 << 20, marks      # a few MB of cached tables at most
     assert abs(marks[59] - marks[39]) <= 8 << 20, marks
     assert len(hip._tables) <= 256 and len(hip._packed) <= 1100 and len(hip._w2t_packed) <= 1100
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,B", [("vp/CIFAR10/indm_nll", 1), ("vp/CIFAR10/indm_nll", 3), ("ve/CIFAR10/indm", 3),
+                                    ("vp/CELEBA/indm_fid", 1)])
+def test_every_entry_point_runs_at_small_odd_batches(name, B):
+    """Smoke sweep of the whole function-level surface at batch sizes the goldens do not use, full-size networks: a
+    training step in fp32 and in bf16 compute, the flow round trip, nelbo_fn and the configured sampler (8 steps) --
+    everything finite, the round trip within the fixed-point rule."""
+    from indm_amd import likelihood, losses, sampling, sde_lib, utils
+    dev = torch.device(DEV)
+    cfg = configs.get_config(name)
+    cfg.device = dev
+    cfg.training.batch_size = B
+    cfg.sampling.num_scales = 8
+    torch.manual_seed(4)
+    score = utils.create_model(cfg, dev)
+    flow = create_flow_model(cfg).to(dev)
+    state, fstate, _ = utils.build_states(cfg, score, flow, dev)
+    sde = sde_lib.get_sde(cfg)
+    S = cfg.data.image_size
+    x = _r(B, 3, S, S, seed=5)
+    rng = DeviceRng(dev, seed=6)
+    try:
+        for dtype in ("f32", "bf16"):
+            cfg.compute_dtype = dtype
+            step_fn = losses.get_step_fn(cfg, sde, train=True)
+            score.train(); flow.train()
+            out = step_fn(state, fstate, x, rng=rng)
+            assert all(o.shape == (B,) and torch.isfinite(o).all() for o in out), (dtype, out)
+        hip.set_compute_dtype("f32")
+        score.eval(); flow.eval()
+        inv = utils.get_data_inverse_scaler(cfg)
+        with torch.no_grad():
+            z, _ = flow_forward(cfg, flow, x, log_det=None, reverse=False, rng=rng)
+            xr, _ = flow_forward(cfg, flow, z, log_det=None, reverse=True, rng=rng)
+        # the reference's stopping rule is (x - x_prev)^2 / (1e-5 + 1e-5 |y|) < 1 per element and block: ~3e-3 per
+        # block, 32 blocks in a row (after two lr = 1e-3 steps the blocks sit closer to their Lipschitz bound than at init)
+        err = (xr - x).abs()
+        assert err.max().item() < 0.25 and err.mean().item() < 2e-2, (err.max().item(), err.mean().item())
+        nb = likelihood.get_elbo_fn(cfg, sde, inv)(score, flow, x, rng=rng)
+        assert nb[0].shape == (B,) and torch.isfinite(nb[0]).all() and torch.isfinite(nb[1]).all()
+        fn = sampling.get_sampling_fn(cfg, sde, (B, 3, S, S), inv, cfg.sampling.truncation_time, device=DEV)
+        smp = fn(score, flow, rng=rng)
+        assert smp[1].shape == (B, 3, S, S) and torch.isfinite(smp[1]).all()
+    finally:
+        hip.set_compute_dtype("f32")
