@@ -268,18 +268,19 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // bf16 compute with PRE-PACKED weights (round 2).  With bf16 MFMAs (8x fewer matrix cycles) the kernel above is no
-// longer MFMA-bound but LDS-bound: every one of the 8 waves re-reads the whole fp32 A and gate slab (its 64 x 64 tile
-// spans all 64 rows) plus its W2T fragments as eight ds_read_b32 each, and the 32 KB fp32 image of the W2T slab is
-// re-staged into LDS for every slab -- 302 us for the 805 MB of A + gate + d1 at batch 128 (2.7 TB/s).  Here the host
-// packs W2T once per flow call into bf16 MFMA-fragment order (`Bp[slab][32-column block][lane][8]`, 512 KB,
-// L2-resident): its slab image shrinks to 16 KB (copied by the waves that use it, one ds_read_b128 per fragment), a
+// longer MFMA-bound and not yet HBM-bound either: a 16-deep slab holds ~0.3 us of arithmetic between a copy wait and a
+// workgroup barrier (PMC, profiles/r02_pmc_chain_bf16.json: MFMA pipe 25 % busy, LDS index unit 29 %, 45 % of wave time
+// parked at waitcnt / barrier, 805 MB in 240-300 us), every wave fetches its W2T fragments as eight ds_read_b32 and
+// the 32 KB fp32 image of the W2T slab is re-staged for every slab.  Here the host packs W2T once per flow call into
+// bf16 MFMA-fragment order (`Bp[slab][32-column block][lane][8]`, 512 KB, L2-resident): its slab image shrinks to
+// 16 KB (copied by the waves that use it, one ds_read_b128 per fragment: a third fewer LDS and VALU instructions), a
 // buffer to 24 KB, three buffers rotate (two slabs in flight per workgroup, two workgroups per CU), the loop waits with
 // vmcnt(3) for the older slab only and synchronises with a bare s_barrier (no fence: __syncthreads() would drain the
-// copies).  231 us / 82 us at the two scales (302 / 92 before).  Measured alternatives: six buffers with one 144 KB
-// workgroup per CU 254 us (the epilogue no longer overlaps another workgroup's main loop); W2T fragments fetched
-// straight into registers 224 us but vmcnt's in-order retirement then ties the copies to the register loads.  What
-// bounds it now is the 8-fold re-read of the fp32 A / gate slab from LDS (80 KB of ds_read per 16-deep slab and
-// workgroup): removing that needs bf16 A / gate images, i.e. a conversion pass or bf16 storage.
+// copies).  231 us / 82 us at the two scales (302 / 92 before; 204 vs 240 us under the profiler).  Measured
+// alternatives: six buffers with one 144 KB workgroup per CU 254 us (the epilogue no longer overlaps another
+// workgroup's main loop); W2T fragments fetched straight into registers 224 us but vmcnt's in-order retirement then
+// ties the copies to the register loads.  Still latency-bound per slab (MFMA 29 %, LDS 23 %, 42 % parked): the next
+// step is more arithmetic per barrier -- 32- or 64-deep slabs, which need bf16 A / gate images to fit two workgroups.
 // Same rounding points (RNE to bf16 of W, of the gated product, of the stage-2 operands) and the same epilogue as
 // ires_chain_kernel<., true, .>: bit-identical results.
 // k order inside a lane's 8-element fragment (both operands): e -> 8 (e >> 2) + 4 lhi + (e & 3).
