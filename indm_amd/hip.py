@@ -154,10 +154,14 @@ def _ptr(t):
     return t.data_ptr()
 
 
-def _stream():
-    # the raw handle of torch's CURRENT stream (side streams of graph capture included); torch.cuda.current_stream()
-    # builds a Stream object through ~10 Python frames (8.6 us per launch = 10 ms of host time per training step)
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+if hasattr(torch._C, "_cuda_getCurrentRawStream") and hasattr(torch._C, "_cuda_getDevice"):
+    def _stream():
+        # the raw handle of torch's CURRENT stream (side streams of graph capture included); torch.cuda.current_stream()
+        # builds a Stream object through ~10 Python frames (8.6 us per launch = 10 ms of host time per training step)
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+else:  # a torch build without the private accessors
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
 
 
 def to_device(t, device):
