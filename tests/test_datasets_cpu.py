@@ -142,3 +142,16 @@ def test_celeba_folder(tmp_path):
     assert len(train_ds) == 4 and len(eval_ds) == 2
     b = next(iter(eval_ds))
     assert b["image"].shape == (2, 64, 64, 3) and 0.0 <= b["image"].min() and b["image"].max() <= 1.0
+
+
+def test_evaluation_get_batch_consumes_the_dataset_stream(tmp_path):
+    """evaluation.get_bpd's batch helper (evaluation.py:388-494 protocol) reads the dict batches of datasets.Dataset"""
+    from indm_amd import evaluation
+    _write_cifar(str(tmp_path), "py", n_per=16)
+    cfg = _cfg(str(tmp_path), bs=16)
+    _, eval_ds = datasets.get_dataset(cfg)
+    it = iter(eval_ds)
+    b, it = evaluation.get_batch(cfg, it, eval_ds)
+    assert b.shape == (16, 3, 32, 32) and b.dtype == torch.float32 and 0.0 <= float(b.min()) and float(b.max()) <= 1.0
+    b2, it = evaluation.get_batch(cfg, it, eval_ds)             # exhausted -> restarted
+    assert torch.equal(b, b2)
