@@ -217,7 +217,26 @@ def profile_stop():
     return out
 
 
-class _timed:
+class _NoTiming:
+    """what _timed() hands out while no profile is being recorded: a shared do-nothing context (one attribute store
+    instead of an object, two events' worth of bookkeeping and a dict update per dense launch)"""
+    variant, flops = None, 0.0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_TIMING = _NoTiming()
+
+
+def _timed(*a, **k):
+    return _Timed(*a, **k) if _Profile.enabled else _NO_TIMING
+
+
+class _Timed:
     """HIP-event bracket around one dense launch.  The class key names the kernel variant the C side actually
     dispatched to (indm_igemm_last_variant) -- no Python mirror of the dispatch rules."""
 
