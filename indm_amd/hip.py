@@ -715,8 +715,10 @@ def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
                                       _stream())
         # the launch that also stores the 512-wide intermediate (training's last chain link) is its own class:
         # same MFMA work plus a 4*M*N-byte store
-        tm.variant = ("ires_chain64x512,gated" + (",t2out" if want_t2 else "")
-                      + (",bf16" if _MFMA["dtype"] == "bf16" else ""))
+        # (J <= 32 and J <= 128 are two instantiations of the kernel -- JB = 1 / 4 panel blocks in its second stage --
+        # and two rows of a rocprofv3 summary: one class each, so that a class average is ONE kernel's average)
+        tm.variant = (("ires_chain64x512x32,gated" if J <= 32 else "ires_chain64x512x128,gated")
+                      + (",t2out" if want_t2 else "") + (",bf16" if _MFMA["dtype"] == "bf16" else ""))
         tm.flops += 2.0 * M * N * J   # algorithmic: the panel's J live columns, not its zero padding
     if st == 1:
         return None

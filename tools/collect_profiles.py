@@ -26,7 +26,7 @@ sub = None
 if parts[2].startswith("glds"):
     sub = f"igemm_glds_kernel<{amode[parts[0]]}, {bmode[parts[1]]}, {'true' if 'gated' in parts else 'false'}, 8, false>"
 elif parts[2].startswith("ires_chain"):
-    sub = "ires_chain_kernel<"      # both instantiations (J <= 32 at scale 0, J <= 128 at scale 1) form the bench class
+    sub = "ires_chain_kernel<"      # the instantiation is selected by chain_ok() below (JB = 1: J <= 32, JB = 4: J <= 128)
 
 
 def chain_ok(name):
@@ -35,7 +35,8 @@ def chain_ok(name):
     if "ires_chain_kernel<" not in name:
         return True
     args = name.split("ires_chain_kernel<")[-1].split(">")[0].replace(" ", "").split(",")
-    return args[1] == "false" and args[2] == ("true" if "t2out" in parts else "false")
+    jb = "4" if "x128" in parts[2] else "1"
+    return args[0] == jb and args[1] == "false" and args[2] == ("true" if "t2out" in parts else "false")
 
 
 out = {"kernel": f"{sub} = {key}", "bench_key": key,
