@@ -1,7 +1,10 @@
 """Headline benchmark: INDM (VP, NLL) training images/s on synthetic CIFAR-10-shaped batches.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without a torchrun environment: this process starts the N ranks itself (fresh child processes through
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, before anything here
+    touches the GPU), relays rank 0's JSON line and exits with the job's code.  Under torchrun (RANK / WORLD_SIZE set,
+    the driver's N > 1 launch) it is one rank; WORLD_SIZE must equal --gpus.
 
 A "step" is one call of the reference-API train_step_fn (flow forward + log-det, score loss, backward, one
 flat-gradient all-reduce when N > 1, fused clip+AdamW+EMA for both networks) on configs/vp/CIFAR10/indm_nll
@@ -238,6 +241,36 @@ def pmc_traffic(kernel_key):
     return None, None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start N rank processes (one per GPU, RCCL over xGMI) as CHILDREN of
+    this process -- which has not touched the GPU and never will -- and hand their output through.  Returns the job's
+    exit code.  (Never exec-replace: a process image swap after GPU initialisation takes the node down on this pool.)"""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _usable_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] starting {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(lines) != 1:
+        print(f"[bench] expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +290,10 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_child:
         return cpu_baseline_child(args.cpu_baseline_child, args.batch, args.cpu_threads)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # before any GPU call in this process
 
     from indm_amd import configs, hip, losses, parallel, sde_lib, utils
     from indm_amd.flow import create_flow_model
@@ -268,6 +305,8 @@ def main():
     rank, world, local = parallel.init_distributed(backend="gloo" if one_gpu else None)
     if one_gpu:
         local = 0
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks")
     strong = args.global_batch > 0
     if strong:
         if args.global_batch % world:

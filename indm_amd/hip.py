@@ -218,9 +218,14 @@ def profile_stop():
 
 
 class _NoTiming:
-    """what _timed() hands out while no profile is being recorded: a shared do-nothing context (one attribute store
-    instead of an object, two events' worth of bookkeeping and a dict update per dense launch)"""
+    """what _timed() hands out while no profile is being recorded (or the launch cannot belong to the one class being
+    recorded): a shared do-nothing context.  Attribute writes (`tm.variant = ...`, `tm.flops += ...`) are dropped, so
+    the process-wide singleton never accumulates state from the main or the autograd thread."""
+    __slots__ = ()
     variant, flops = None, 0.0
+
+    def __setattr__(self, name, value):
+        pass
 
     def __enter__(self):
         return self
@@ -230,10 +235,25 @@ class _NoTiming:
 
 
 _NO_TIMING = _NoTiming()
+_HOST_NAMED = ("ires_chain", "attn_fused")   # variants named by this module (every other one is chosen by the C side)
 
 
-def _timed(*a, **k):
-    return _Timed(*a, **k) if _Profile.enabled else _NO_TIMING
+def _timed(amode, bmode, *a, variant=None, **k):
+    """variant: the class name when the caller knows it before the launch.  With profile_start(only=key) a launch is
+    bracketed by HIP events only if it can belong to `key`: in bench.py's timed region that is the ~60 launches per
+    step of the dominant kernel instead of all ~1 500 dense launches."""
+    if not _Profile.enabled:
+        return _NO_TIMING
+    only = _Profile.only
+    if only is not None:
+        if variant is not None:
+            if only != f"igemm<{amode},{bmode},{variant}>":
+                return _NO_TIMING
+        elif only.split(",", 2)[-1].startswith(_HOST_NAMED):
+            return _NO_TIMING
+    t = _Timed(amode, bmode, *a, **k)
+    t.variant = variant
+    return t
 
 
 class _Timed:
@@ -652,9 +672,9 @@ def attn_fwd(q, k, v, scale):
     B, T, C = q.shape
     h = torch.empty_like(q)
     lse = torch.empty((B, T), dtype=torch.float32, device=q.device)
-    with _timed("ATTN", "FWD", T, C, T, B) as tm:
+    with _timed("ATTN", "FWD", T, C, T, B, variant="attn_fused") as tm:
         st = lib().indm_attn_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(h), _ptr(lse), B, T, C, scale, _stream())
-        tm.variant, tm.flops = "attn_fused", 4.0 * B * T * T * C
+        tm.flops = 4.0 * B * T * T * C
     if st == 1:
         return None
     _chk(st, "indm_attn_fwd_f32")
@@ -666,10 +686,10 @@ def attn_bwd(q, k, v, h, dh, lse, scale):
     B, T, C = q.shape
     Dv = rowreduce(dh.view(B * T, C), h.view(B * T, C), 0).view(B, T)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
-    with _timed("ATTN", "BWD", T, C, T, B) as tm:
+    with _timed("ATTN", "BWD", T, C, T, B, variant="attn_fused") as tm:
         st = lib().indm_attn_bwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(dh), _ptr(lse), _ptr(Dv), _ptr(dq), _ptr(dk),
                                      _ptr(dv), B, T, C, scale, _stream())
-        tm.variant, tm.flops = "attn_fused", 10.0 * B * T * T * C
+        tm.flops = 10.0 * B * T * T * C
     _chk(st, "indm_attn_bwd_f32")
     return dq, dk, dv
 
@@ -705,7 +725,12 @@ def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
     P = torch.empty((M, J), dtype=torch.float32, device=t3.device)
     t2 = torch.empty((M, N), dtype=torch.float32, device=t3.device) if want_t2 else None
     nbytes = 4 * (2 * t3.numel() + d1.numel() + w2t.numel() + P.numel() + (t2.numel() if want_t2 else 0))
-    with _timed("A_ROW", "B_ROW", M, N, K, nbytes=nbytes) as tm:
+    # the launch that also stores the 512-wide intermediate (training's last chain link) is its own class: same MFMA
+    # work plus a 4*M*N-byte store.  J <= 32 and J <= 128 are two instantiations of the kernel -- JB = 1 / 4 panel blocks
+    # in its second stage -- and two rows of a rocprofv3 summary: one class each, so that a class average is ONE kernel's
+    variant = (("ires_chain64x512x32,gated" if J <= 32 else "ires_chain64x512x128,gated")
+               + (",t2out" if want_t2 else "") + (",bf16" if _MFMA["dtype"] == "bf16" else ""))
+    with _timed("A_ROW", "B_ROW", M, N, K, nbytes=nbytes, variant=variant) as tm:
         hit = _w2t_packed.get(id(w2t)) if _MFMA["dtype"] == "bf16" else None
         if hit is not None and hit[0]() is w2t and hit[1] == w2t._version:
             st = lib().indm_ires_chain_bf16w(_ptr(t3), _ptr(d2), hit[2].data_ptr(), _ptr(d1), _ptr(w1p), _ptr(P),
@@ -713,12 +738,6 @@ def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
         else:
             st = _dense("ires_chain")(_ptr(t3), _ptr(d2), _ptr(w2t), _ptr(d1), _ptr(w1p), _ptr(P), _ptr(t2), M, K, N, J,
                                       _stream())
-        # the launch that also stores the 512-wide intermediate (training's last chain link) is its own class:
-        # same MFMA work plus a 4*M*N-byte store
-        # (J <= 32 and J <= 128 are two instantiations of the kernel -- JB = 1 / 4 panel blocks in its second stage --
-        # and two rows of a rocprofv3 summary: one class each, so that a class average is ONE kernel's average)
-        tm.variant = (("ires_chain64x512x32,gated" if J <= 32 else "ires_chain64x512x128,gated")
-                      + (",t2out" if want_t2 else "") + (",bf16" if _MFMA["dtype"] == "bf16" else ""))
         tm.flops += 2.0 * M * N * J   # algorithmic: the panel's J live columns, not its zero padding
     if st == 1:
         return None

@@ -152,10 +152,19 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
     def _zero(state):
         state["optimizer"].zero_grad()
 
+    _rngs = {}
+
     def _step_rng(device, step):
-        """default noise source of a step: per-rank noise, rank-independent series lengths (see DeviceRng)"""
+        """default noise source of a step: per-rank noise, rank-independent series lengths (see DeviceRng).  ONE
+        resident source per device, re-keyed per step (no per-step generator objects or synchronous state upload)."""
         rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-        return DeviceRng(device, seed=mix64(config.get("seed", 0), step, rank), poisson_seed=mix64(config.get("seed", 0), step) % (1 << 32))
+        seed, pseed = mix64(config.get("seed", 0), step, rank), mix64(config.get("seed", 0), step) % (1 << 32)
+        key = (device.type, device.index)
+        r = _rngs.get(key)
+        if r is None:
+            r = _rngs[key] = DeviceRng(device, seed=seed, poisson_seed=pseed)
+            return r
+        return r.reseed(seed, pseed)
 
     class _HostLosses:
         """The per-image loss vectors the step returns on the CPU (reference API: losses.py:281-284,320).  Their
@@ -230,6 +239,8 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         outs = _HostLosses(4)
         _zero(state)
         _zero(flow_state)
+        if hasattr(allreduce, "begin_step"):
+            allreduce.begin_step()
         if train:
             for k in range(nmb):
                 mb = batch[B // nmb * k: B // nmb * (k + 1)]
@@ -258,6 +269,8 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         outs = _HostLosses(4)
         _zero(state)
         _zero(flow_state)
+        if hasattr(allreduce, "begin_step"):
+            allreduce.begin_step()
         if train:
             for k in range(nmb):
                 mb = batch[B // nmb * k: B // nmb * (k + 1)]

@@ -282,7 +282,10 @@ class _Attention(Function):
     @staticmethod
     def forward(ctx, q, k, v, scale):
         q, k, v = _c(q), _c(k), _c(v)
-        h, lse = hip.attn_fwd(q, k, v, scale)
+        out = hip.attn_fwd(q, k, v, scale)
+        if out is None:   # attention() pre-checks the geometry; what is left is a pointer that is not 16-byte aligned
+            raise RuntimeError("indm_attn_fwd_f32 declined the launch (q/k/v must be 16-byte aligned [B,T,C] tensors)")
+        h, lse = out
         ctx.save_for_backward(q, k, v, h, lse)
         ctx.scale = scale
         return h
@@ -298,7 +301,8 @@ def attention(q, k, v, scale):
     """Single-head attention over [B, T, C] (models/layerspp.py:88-104).  Fused kernel when it covers the geometry
     (T in {64, 128, 256}, C % 128 == 0, fp32 mode), else the batched-GEMM + softmax composition."""
     B, T, C = q.shape
-    if hip.compute_dtype() == "f32" and T in (64, 128, 256) and C >= 128 and C % 128 == 0:
+    if (hip.compute_dtype() == "f32" and T in (64, 128, 256) and C >= 128 and C % 128 == 0
+            and all(t.data_ptr() % 16 == 0 and t.is_contiguous() for t in (q, k, v))):
         return _Attention.apply(q, k, v, scale)
     w = softmax(gemm(q, k, trans_b=True), scale)
     return gemm(w, v)
@@ -403,7 +407,10 @@ class _SplitCols(Function):
     @staticmethod
     def backward(ctx, *grads):
         R = ctx.R
-        gs = [g if g is not None else grads[0].new_zeros((R, c)) for g, c in zip(grads, ctx.sizes)]
+        ref = next((g for g in grads if g is not None), None)
+        if ref is None:
+            return (None,) * (1 + len(ctx.sizes))
+        gs = [g if g is not None else ref.new_zeros((R, c)) for g, c in zip(grads, ctx.sizes)]
         return (torch.cat(gs, dim=1),) + (None,) * len(ctx.sizes)
 
 

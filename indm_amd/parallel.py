@@ -52,10 +52,14 @@ class GradReducer:
 
     def __init__(self, flat_grad, world_size):
         self.flat_grad, self.world_size = flat_grad, world_size
-        self.pending = {}      # id(flat) -> (flat, work) launched early
-        self.armed = {}        # id(flat) -> [flat, remaining parameter count]
-        self.hooked = set()
-        self.calls = []        # element counts of the collectives of the current step (tests / bench report)
+        self.pending = {}      # id(flat) -> (flat, work) launched early; entries live only within one step
+        self.armed = {}        # id(flat) -> [flat, remaining parameter count]; entries live only within one step
+        self.calls = []        # element counts of the collectives of the CURRENT step (reset by begin_step())
+
+    def begin_step(self):
+        """called by the step functions before the first backward pass of a step"""
+        self.calls = []
+        self.armed.clear()
 
     def _launch(self, t, async_op=False):
         self.calls.append(t.numel())
@@ -64,10 +68,12 @@ class GradReducer:
     def arm(self, flat):
         """Start flat's all-reduce from inside the backward pass as soon as every parameter has its gradient."""
         key = id(flat)
-        if key not in self.hooked:
-            self.hooked.add(key)
-            for _, p in flat.named:
-                p.register_post_accumulate_grad_hook(lambda _p, key=key: self._on_grad(key))
+        # the hook handles live ON the FlatParams object (not in a set of ids a later object could re-use)
+        if getattr(flat, "_reducer_hooks", None) is None or flat._reducer_hooks[0] is not self:
+            for h in (getattr(flat, "_reducer_hooks", None) or (None, []))[1]:
+                h.remove()
+            flat._reducer_hooks = (self, [p.register_post_accumulate_grad_hook(lambda _p, f=flat: self._on_grad(id(f)))
+                                          for _, p in flat.named])
         self.armed[key] = [flat, len(flat.named)]
 
     def _on_grad(self, key):

@@ -60,17 +60,29 @@ class DeviceRng:
         block for its whole batch, and equal work per rank removes the wait-for-the-slowest at the all-reduce."""
         self.device = torch.device(device)
         self.gen = torch.Generator(device=self.device)
-        seed = int(seed) % (1 << 63)
-        self.gen.manual_seed(seed)
-        self.cpu_gen = torch.Generator().manual_seed((seed + 1) % (1 << 63))
-        self.np = np.random.RandomState((seed + 2 if poisson_seed is None else poisson_seed) % (1 << 32))
-        self._drop = (seed * 1000003 + 12345) % (1 << 63)
+        self.cpu_gen = torch.Generator()
         # on the GPU the normals come from the library's own Philox kernel (indm_philox_randn_f32): its {seed, offset}
         # state lives in device memory and advances in stream order, so a captured hipGraph draws fresh noise per replay
         self.philox = None
+        self.reseed(seed, poisson_seed)
+
+    def reseed(self, seed, poisson_seed=None):
+        """Re-key every stream of this source in place (a training step re-keys ONE resident source by
+        (seed, step, rank) instead of building a new one: no generator objects, and the Philox state goes to the
+        device through a pinned non-blocking copy into the SAME tensor -- no synchronous upload on the hot path)."""
+        seed = int(seed) % (1 << 63)
+        self.gen.manual_seed(seed)
+        self.cpu_gen.manual_seed((seed + 1) % (1 << 63))
+        self.np = np.random.RandomState((seed + 2 if poisson_seed is None else poisson_seed) % (1 << 32))
+        self._drop = (seed * 1000003 + 12345) % (1 << 63)
         if self.device.type == "cuda":
             from . import hip
-            self.philox = hip.philox_state(mix64(seed, 0x5eed), self.device)
+            host = torch.tensor([mix64(seed, 0x5eed) & ((1 << 63) - 1), 0], dtype=torch.int64)
+            if self.philox is None:
+                self.philox = hip.to_device(host, self.device)
+            else:
+                self.philox.copy_(host.pin_memory(), non_blocking=True)
+        return self
 
     def randn_image(self, n, c, h, w):
         if self.philox is not None:

@@ -1,6 +1,7 @@
 """bench.py's multi-process path end to end on a single-GPU box: two ranks launched with torch.distributed.run exactly
 as the driver launches N ranks, sharing GPU 0 and exchanging gradients over gloo (INDM_BENCH_ONE_GPU=1; the real run is
-one rank per GPU over RCCL).  Checks the contract line rank 0 prints, for weak and for strong scaling."""
+one rank per GPU over RCCL).  Checks the contract line rank 0 prints, for weak and for strong scaling -- and the bare
+`python bench.py --gpus 2` form, where bench.py has to start the ranks itself."""
 import json
 import os
 import subprocess
@@ -13,11 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, port):
+def _run(extra, port, self_launch=False, gpus=2):
     env = dict(os.environ, INDM_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--no-sampling"] + extra
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    launcher = [] if self_launch else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                       "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2",
+                                         "--warmup", "1", "--no-cpu-baseline", "--no-sampling"] + extra
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -39,3 +43,28 @@ def test_two_rank_bench_weak_and_strong():
     strong = _run(["--global-batch", "16"], port + 1)
     assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 16 and strong["n_gpus"] == 2
     assert strong["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bare_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it (the shape of the driver's command): bench.py spawns the two
+    rank processes itself and relays rank 0's line."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    line = _run(["--batch", "8"], None, self_launch=True)
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16
+    assert line["scaling"] == "weak" and line["value"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_world_size_must_match_gpus():
+    """two torchrun ranks but --gpus 4: refuse instead of printing a line with the wrong n_gpus"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, INDM_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29950 + os.getpid() % 40), os.path.join(ROOT, "bench.py"), "--gpus", "4",
+           "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-sampling", "--batch", "8"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
