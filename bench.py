@@ -347,12 +347,17 @@ def main():
         torch.cuda.synchronize()
 
     dominant = None
+    drivers_on = hip.block_drivers()
     for i in range(args.warmup):
         if i == args.warmup - 1:
+            # which dense kernel class owns the most GPU time?  Timed per launch with HIP events on the op-level
+            # composition (the block drivers enqueue the same kernels from C++, where Python cannot bracket them)
+            hip.block_drivers(False)
             hip.profile_start()
         step_fn(state, flow_state, batches[i], rng=rng)
         if i == args.warmup - 1:
             prof = hip.profile_stop()
+            hip.block_drivers(drivers_on)
             if prof:
                 dominant = max(prof, key=lambda k: prof[k]["ms"])
                 if rank == 0 and os.environ.get("INDM_BENCH_PROFILE"):
@@ -362,7 +367,16 @@ def main():
                               f"{p['flops'] / 1e9:10.1f} GFLOP  {p['flops'] / p['ms'] / 1e9:7.2f} TF/s",
                               file=sys.stderr, flush=True)
     barrier()
-    hip.profile_start(only=dominant) if dominant else None
+    # the dominant class inside the timed region: HIP events on the launch stream around ITS launches only -- recorded by
+    # the C-side launch timer when the block drivers own those launches (chain-kernel classes), else by hip.py
+    chain_timer = None
+    if dominant:
+        variant = dominant[len("igemm<"):-1].split(",", 2)[-1]
+        if drivers_on and variant.startswith("ires_chain"):
+            chain_timer = hip.ChainTimer(64 * args.steps * 16)
+            chain_timer.reset(variant)
+            hip.set_chain_timer(chain_timer)
+        hip.profile_start(only=dominant)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.time()
     last = None
@@ -375,6 +389,16 @@ def main():
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     prof = hip.profile_stop() if dominant else {}
+    if chain_timer is not None:
+        hip.set_chain_timer(None)
+        r = chain_timer.read()
+        p0 = prof.get(dominant, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+        # algorithmic bytes per launch of a chain class (hip.ires_chain's figure): t3 + d2 + d1 + W2T + P (+ t2 when stored)
+        M = args.batch * (1024 if "x32" in variant else 256)
+        J = 27 if "x32" in variant else 108
+        nb = 4.0 * (3 * M * 512 + 512 * 512 + M * J + (M * 512 if "t2out" in variant else 0))
+        prof[dominant] = dict(launches=p0["launches"] + r["launches"], flops=p0["flops"] + r["flops"],
+                              bytes=p0["bytes"] + nb * r["launches"], ms=p0["ms"] + r["ms"])
     if dist_on:
         t = torch.tensor([elapsed], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

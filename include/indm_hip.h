@@ -279,6 +279,79 @@ int indm_adamw_ema_f32(float* p, const float* g, float* m, float* v, float* ema,
                        float gscale, float ema_one_minus_decay, void* stream);
 int indm_ema_update_f32(float* s, const float* p, long n, float one_minus_decay, void* stream);
 
+/* ---- block-level drivers: ONE call per residual-flow block ------------------------------------------------- */
+
+/* The iResBlock of the residual flow, flows/resflow/layers/iresblock.py:14-174, as ONE call per direction: the driver
+ * enqueues the whole launch sequence of the block (g-net: Sin -> thin 3x3 -> Sin -> conditioned 1x1 GEMM -> Sin -> thin
+ * 3x3; then the K = n + 2 (training, neumann_logdet_estimator :264-273) or n + 20 (eval, basic_logdet_estimator
+ * :253-261) vector-Jacobian iterations on the back-to-back chain kernel) on `stream` -- ~25-40 kernels -- instead of one
+ * host call per kernel.  The kernels are the ones the op-level entry points above launch; only the SEQUENCING lives
+ * here, so results are bit-identical to the op-level composition.
+ * Geometry covered (return 1 otherwise, nothing enqueued; the caller composes the op-level calls): C <= 3 with
+ * W | 128 and H*W % 128 == 0, or C % 4 == 0 with 9C <= 128; idim == 512; N*H*W % 64 == 0 and >= 1024.
+ * All tensors NHWC fp32; weights are the Lop-NORMALISED ones (lipschitz.py:350-359), in the layouts named below.
+ * `coeffs` is a HOST array.  ws: device scratch of indm_iresblock_ws_floats() floats; splitk_ws: the dense engine's
+ * split-K scratch (may be shared with other calls on the same stream). */
+typedef struct {
+  int N, H, W, C, idim; /* block input [N,H,W,C]; width of the g-net (512) */
+  int preact;           /* the block starts with a Sin activation (every block but the flow's first) */
+  int training;         /* 1: Neumann surrogate + tensors saved for indm_iresblock_bwd; 0: power series, nothing saved */
+  int bf16;             /* 0: exact fp32 MFMA; 1: MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate) */
+  const float* x;       /* [N,H,W,C] */
+  const float* cb;      /* [N, idim] folded conditioning bias Linear(h) W2 (lipschitz.py:429-435) */
+  const float* W1;      /* [3,3,C,idim] RSCK == [(tap,c), idim] */
+  const float* W2T;     /* [idim, idim] = W2^T stored row-major */
+  const void* W2T_bf16w; /* bf16 mode: W2T in indm_ires_chain_bf16w's fragment order, or NULL */
+  const float* W3_ci_tapco; /* [idim, (tap, c)] : W3 [3,3,idim,C] re-laid-out for the skinny-output conv */
+  const float* W3_tapco_ci; /* [(tap, c), idim] : W3 re-laid-out for the transposed conv */
+  const float* panel;   /* [idim, 32 | 128] zero-padded W1 as [idim, (tap,c)]: the chain kernel's second stage */
+  const float *b1, *b2, *b3;
+  const float* eps;     /* [N,H,W,C] Hutchinson probe (iresblock.py:137) */
+  const float* coeffs;  /* HOST: training: (-1)^k c_k, k = 1..K; eval: (-1)^(k+1) c_k / k */
+  int ncoeff;           /* K */
+  float* y;             /* [N,H,W,C] = x + g(x) */
+  float* logdet;        /* [N] */
+  /* training = 1: saved for the backward, caller-allocated ([N,H,W,idim] unless stated); eval: ignored */
+  float *a0, *d0;       /* [N,H,W,C], preact only */
+  float *a1, *d1, *a2, *d2, *t3, *t2;
+  float* c1;            /* [N,H,W,C], preact only */
+  float* w;             /* [N,H,W,C] eps + sum_k coeffs[k] v_k */
+  float* ws; long ws_floats;
+  float* splitk_ws; long splitk_ws_floats;
+  void* timer;          /* optional indm_timer handle: HIP events around the chain-kernel launches (bench roofline) */
+} indm_iresblock_fwd_args;
+
+/* Backward of the training-mode block (replaces autograd's double backward through iresblock.py:264-273 and g's own
+ * backward): gradients w.r.t. x, cb, the normalised weights and the biases.  dW layouts: dW1 [3,3,C,idim],
+ * dW2 [idim,idim], dW3 [3,3,idim,C], dW2T [idim,idim] (gradient w.r.t. the stored W2^T; the caller adds its transpose
+ * to dW2), db* [idim|C], dcb [N, idim]. */
+typedef struct {
+  int N, H, W, C, idim, preact, bf16;
+  const float* gy;      /* [N,H,W,C] cotangent of y */
+  const float* gld;     /* [N] cotangent of logdet */
+  const float *a0, *d0, *a1, *d1, *a2, *d2, *t3, *t2, *c1, *w, *eps; /* as saved by the forward (a0 = x without preact) */
+  const float *W1, *W2, *W2T, *W3_tapco_ci; /* W2 [idim, idim] row-major (= [Cin, Cout]) */
+  float *dx, *dcb, *dW1, *dW2, *dW3, *dW2T, *db1, *db2, *db3;
+  float* ws; long ws_floats;
+  float* splitk_ws; long splitk_ws_floats;
+} indm_iresblock_bwd_args;
+
+/* Fixed-point inverse x <- y - g(x) (iresblock.py:78-88): iterates until every element passes
+ * (dx)^2 / (atol + |y| rtol) < 1 or 1000 iterations; reads ONE device scalar per iteration (the reference's torch.all).
+ * Uses the forward argument block: x = y (input), y = x_out (output); eps / coeffs / logdet / saved tensors unused. */
+long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int which /* 0 fwd train, 1 fwd eval, 2 bwd, 3 inverse */);
+int indm_iresblock_fwd_logdet(const indm_iresblock_fwd_args* a, void* stream);
+int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream);
+int indm_iresblock_inverse(const indm_iresblock_fwd_args* a, float atol, float rtol, int* iterations, void* stream);
+
+/* Launch timer used by the block drivers (they own the launches bench.py's roofline line prices): HIP events on the
+ * launch stream around every chain-kernel launch whose class bit is set in cls_mask (bit 0: J <= 32; 1: J <= 32 + stored
+ * intermediate; 2: J <= 128; 3: J <= 128 + stored intermediate).  create/destroy allocate and free the events. */
+int indm_timer_create(int capacity, void** handle);
+int indm_timer_destroy(void* handle);
+int indm_timer_reset(void* handle, int cls_mask);
+int indm_timer_read(void* handle, float* total_ms, int* launches, double* flops);
+
 #ifdef __cplusplus
 }
 #endif

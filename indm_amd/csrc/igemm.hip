@@ -991,6 +991,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // (an inline-asm v_pk_mul_f32 here is unsafe: the hazard recogniser does not see its VGPR writes next to in-flight MFMAs)
 __device__ __forceinline__ f32x2 pk_mul_f32(f32x2 a, f32x2 b) { return a * b; }
 
+// One direct-to-LDS copy (64 lanes x 16 bytes) in the `voffset, s[base:base+1]` form: a wave-uniform base in an SGPR pair
+// that the SCALAR unit advances from slab to slab + a per-lane 32-bit byte offset that never changes.  hipcc lowers
+// __builtin_amdgcn_global_load_lds on a loop-carried pointer to a 64-bit VALU add per copy, and non-MFMA VALU
+// instructions do not overlap with the MFMAs on this part: tools/probe/mfma_model.hip prices that arithmetic at
+// 9-11 % of a 32-MFMA slab (125 -> 141 TF in the model).  Opaque to the compiler: the callers order it with their own
+// s_waitcnt vmcnt + barriers, exactly as they order the builtin.
+__device__ __forceinline__ void dma_saddr(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // 16 bytes of zeros in device memory: the source of a padded tap's DMA copy
 __device__ __attribute__((aligned(16))) float indm_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -1061,40 +1075,43 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   // A_ROW / B_COL / B_ROW: every DMA of this lane reads the same row (or k-row) in every slab -> per-lane source
   // pointers advanced by one slab per stage() call (one v_lshl_add_u64 each) instead of re-deriving 64-bit offsets
   // from k0 (the non-MFMA VALU work of the loop does not overlap with the MFMAs: PMC SQ_VALU_MFMA_COEXEC_CYCLES = 0)
-  const float* pa[16 / NW];
-  const float* pg[16 / NW];
-  const float* pb[8 / NW];
+  // (round 3: wave-uniform running bases in SGPRs + fixed per-lane 32-bit byte offsets, dma_saddr above)
+  const char *ua = nullptr, *ug = nullptr, *ub = nullptr;
+  unsigned aoff[16 / NW], boff[8 / NW];
   if constexpr (AM == A_ROW) {
+    ua = (const char*)(A + (long)m0 * p.lda + kbeg);
+    ug = HAS_G ? (const char*)(G + (long)m0 * p.lda + kbeg) : nullptr;
 #pragma unroll
     for (int q = 0; q < 16 / NW; ++q) {
       const int row = wave * (256 / NW) + q * 16 + (lane >> 2);
       const int c = (lane & 3) ^ ((row >> 2) & 3);
-      const long off = (long)min(m0 + row, p.M - 1) * p.lda + kbeg + 4 * c;
-      pa[q] = A + off;
-      pg[q] = HAS_G ? G + off : nullptr;
+      aoff[q] = ((unsigned)(min(m0 + row, p.M - 1) - m0) * (unsigned)p.lda + 4u * c) * 4u;
     }
   }
   if constexpr (AM == A_COL) {  // A stored [K][M]: LDS image [16 k][256 m], one k-row (1 KB) per wave-instruction
+    ua = (const char*)(A + (long)kbeg * p.lda + m0);
+    ug = HAS_G ? (const char*)(G + (long)kbeg * p.lda + m0) : nullptr;
 #pragma unroll
-    for (int q = 0; q < 16 / NW; ++q) {
-      const long off = (long)(kbeg + wave * (16 / NW) + q) * p.lda + min(m0 + 4 * lane, p.M - 4);
-      pa[q] = A + off;
-      pg[q] = HAS_G ? G + off : nullptr;
-    }
+    for (int q = 0; q < 16 / NW; ++q)
+      aoff[q] = ((unsigned)(wave * (16 / NW) + q) * (unsigned)p.lda + (unsigned)(min(m0 + 4 * lane, p.M - 4) - m0)) * 4u;
   }
   if constexpr (BMODE == B_COL) {
+    ub = (const char*)(B + (long)n0 * p.ldb + kbeg);
 #pragma unroll
     for (int q = 0; q < 8 / NW; ++q) {
       const int row = wave * (128 / NW) + q * 16 + (lane >> 2);
       const int c = (lane & 3) ^ ((row >> 2) & 3);
-      pb[q] = B + (long)min(n0 + row, p.N - 1) * p.ldb + kbeg + 4 * c;
+      boff[q] = ((unsigned)(min(n0 + row, p.N - 1) - n0) * (unsigned)p.ldb + 4u * c) * 4u;
     }
   } else if constexpr (BMODE == B_ROW) {
+    ub = (const char*)(B + (long)kbeg * p.ldb + n0);
 #pragma unroll
     for (int q = 0; q < 8 / NW; ++q)
-      pb[q] = B + (long)(kbeg + wave * (16 / NW) + q * 2 + (lane >> 5)) * p.ldb + min(n0 + 4 * (lane & 31), p.N - 4);
+      boff[q] = ((unsigned)(wave * (16 / NW) + q * 2 + (lane >> 5)) * (unsigned)p.ldb +
+                 (unsigned)(min(n0 + 4 * (lane & 31), p.N - 4) - n0)) * 4u;
   }
-  const long b_step = BMODE == B_ROW ? (long)BK * p.ldb : BK;
+  const long b_step = (BMODE == B_ROW ? (long)BK * p.ldb : BK) * (long)sizeof(float);   // bytes per slab
+  const long a_step = (AM == A_COL ? (long)BK * p.lda : BK) * (long)sizeof(float);
   long bdg[8 / NW];  // B_DGRAD: this lane's row of the packed weight (fixed over the K loop)
   if constexpr (BMODE == B_DGRAD) {
 #pragma unroll
@@ -1123,20 +1140,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       const int row = r0 + (lane >> 2);
       const int c = (lane & 3) ^ ((row >> 2) & 3);  // the k-chunk that belongs in LDS slot (row, lane&3)
       if constexpr (AM == A_ROW) {
-        dma(pa[q], base + r0 * BK);
-        pa[q] += BK;
-        if constexpr (HAS_G) {
-          dma(pg[q], base + A_SZ + r0 * BK);
-          pg[q] += BK;
-        }
+        dma_saddr(lds_byte_addr(base + r0 * BK), aoff[q], ua);
+        if constexpr (HAS_G) dma_saddr(lds_byte_addr(base + A_SZ + r0 * BK), aoff[q], ug);
       } else if constexpr (AM == A_COL) {
         const int kr = wave * (16 / NW) + q;
-        dma(pa[q], base + kr * TM);
-        pa[q] += (long)BK * p.lda;
-        if constexpr (HAS_G) {
-          dma(pg[q], base + A_SZ + kr * TM);
-          pg[q] += (long)BK * p.lda;
-        }
+        dma_saddr(lds_byte_addr(base + kr * TM), aoff[q], ua);
+        if constexpr (HAS_G) dma_saddr(lds_byte_addr(base + A_SZ + kr * TM), aoff[q], ug);
       } else if (p.dil == 1) {  // block-uniform branch
         const bool ok = (unsigned)(ih0[q] + kh) < (unsigned)p.H && (unsigned)(iw0[q] + kw) < (unsigned)p.W;
         const float* src = A + pbase[q] + tap_off;
@@ -1152,6 +1161,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         dma(ok ? src : indm_zero16, base + r0 * BK);
       }
     }
+    if constexpr (AM == A_ROW || AM == A_COL) {   // the uniform bases move on by one slab (scalar adds)
+      ua += a_step;
+      if constexpr (HAS_G) ug += a_step;
+    }
     float* bb = base + A_SZ + G_SZ;
 #pragma unroll
     for (int q = 0; q < 8 / NW; ++q) {
@@ -1160,8 +1173,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         const int row = r0 + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         if constexpr (BMODE == B_COL) {
-          dma(pb[q], bb + r0 * BK);
-          pb[q] += b_step;
+          dma_saddr(lds_byte_addr(bb + r0 * BK), boff[q], ub);
         } else {  // B_DGRAD: packed weight [T][N][Cout], taps flipped; one tap per slab
           const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
           const long toff = (long)(p.KH * p.KW - 1 - tap) * p.N * p.Cout + co0;  // uniform
@@ -1169,10 +1181,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         }
       } else {              // [16 k][128 n]: two k-rows per instruction, 16 / NW k-rows per wave
         const int kr0 = wave * (16 / NW) + q * 2;
-        dma(pb[q], bb + kr0 * TN);
-        pb[q] += b_step;
+        dma_saddr(lds_byte_addr(bb + kr0 * TN), boff[q], ub);
       }
     }
+    if constexpr (BMODE == B_COL || BMODE == B_ROW) ub += b_step;
   };
 
   const int wm = wave >> 1, wn = wave & 1;

@@ -37,6 +37,34 @@ struct ChainArgs {
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// One direct-to-LDS copy (64 lanes x 16 bytes) in the `voffset, s[base:base+1] offset:imm` form: the wave-uniform base
+// lives in an SGPR pair that the SCALAR unit advances from slab to slab, the per-lane 32-bit byte offset never changes,
+// and the immediate is added to the global AND the LDS address (M0).  hipcc lowers __builtin_amdgcn_global_load_lds on a
+// loop-carried pointer to a 64-bit VALU add per copy; tools/probe/mfma_model.hip prices that arithmetic at 9-11 % of
+// a 32-MFMA slab (non-MFMA VALU instructions do not overlap with the MFMAs on this part): 125 -> 141 TF in the model.
+// The asm is opaque to the compiler: the callers order it with their own s_waitcnt vmcnt + barriers, as before.
+template <int IMM>
+__device__ __forceinline__ void dma_s(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+// four copies 1 KB apart in global memory and in LDS: one M0 value, one address, four immediates (ONE asm statement: nothing
+// can come between the M0 write and its readers)
+__device__ __forceinline__ void dma_s_x4(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void dma_s_x2(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 
 // Everything after the first contraction, shared by the kernels below: optional store of the intermediate, the d1
@@ -167,17 +195,23 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   // every wave stages two k-rows of B (2 KB each = two wave-instructions)
   const int arow = (wave & 3) * 16 + (lane >> 2);
   const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
-  const float* pa = (wave < 4 ? p.A : p.G) + (long)(m0 + arow) * p.K + 4 * achunk;
+  // source addresses = wave-uniform running base (SGPR pair, advanced by scalar adds) + a per-lane 32-bit byte offset
+  // that never changes: the copies then use the `voffset, s[base]` form and the loop issues NO vector address arithmetic
+  const char* pa = (const char*)((wave < 4 ? p.A : p.G) + (long)m0 * p.K);
+  const unsigned a_off = ((unsigned)arow * (unsigned)p.K + 4u * achunk) * 4u;
   const int a_dst = (wave < 4 ? 0 : A_SZ) + (wave & 3) * 16 * BK;
-  const float* pb = p.B + (long)(wave * 2) * TN + 4 * lane;
+  const char* pb = (const char*)(p.B + (long)(wave * 2) * TN);
+  const unsigned b_off = 16u * lane;
+  // The wave's four B copies (k-row 2w: [0,256) [256,512); k-row 2w+1: ...) are 1 KB apart in global memory AND in LDS:
+  // ONE address register and ONE M0 value, the rest is the instruction's immediate offset (it is added to both
+  // addresses).  A loop model (tools/probe/mfma_model.hip) priced the per-copy address arithmetic -- a 64-bit VALU add,
+  // an M0 write and its hazard wait each -- at 9 % of this loop: non-MFMA VALU work does NOT overlap with the MFMAs.
   auto stage = [&](int buf) {
     float* base = smem + buf * BUF;
-    dma(pa, base + a_dst);
-    pa += BK;
-    float* bb = base + A_SZ + G_SZ + wave * 2 * TN;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma(pb + q * 256, bb + q * 256);  // k-row 2w: [0,256) [256,512); k-row 2w+1: ...
-    pb += (long)BK * TN;
+    dma_s<0>(lds_addr(base + a_dst), a_off, pa);
+    pa += BK * sizeof(float);
+    dma_s_x4(lds_addr(base + A_SZ + G_SZ + wave * 2 * TN), b_off, pb);
+    pb += (long)BK * TN * sizeof(float);
   };
 
   auto frags = [&](int buf, int sg, float4 (&fm)[2], float4 (&fn)[2]) {
@@ -317,21 +351,18 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_pw_kernel(ChainArgsPW q
   // 32-column blocks of the packed W2T slab (1 KB each: lane l of the copy lands at byte 16 l, fragment order)
   const int arow = (wave & 3) * 16 + (lane >> 2);
   const int achunk = (lane & 3) ^ ((arow >> 2) & 3);
-  const float* pa = (wave < 4 ? p.A : p.G) + (long)(m0 + arow) * p.K + 4 * achunk;
+  const char* pa = (const char*)((wave < 4 ? p.A : p.G) + (long)m0 * p.K);        // wave-uniform running bases (SGPRs) ...
+  const unsigned a_off = ((unsigned)arow * (unsigned)p.K + 4u * achunk) * 4u;      // ... + fixed per-lane byte offsets
   const int a_dst = (wave < 4 ? 0 : A_SZ) + (wave & 3) * 16 * BK;
-  const float* pb = (const float*)q.Bp + ((long)(wave * 2) * 64 + lane) * 4;
+  const char* pb = (const char*)((const float*)q.Bp + (long)(wave * 2) * 64 * 4);
+  const unsigned b_off = 16u * lane;
   const int b_dst = A_SZ + G_SZ + wave * 2 * 256;
-  auto dma = [&](const float* src, float* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
   auto stage = [&](int buf) {
     float* base = smem + buf * PW_BUF;
-    dma(pa, base + a_dst);
-    dma(pb, base + b_dst);
-    dma(pb + 256, base + b_dst + 256);
-    pa += BK;
-    pb += 16 * 256;
+    dma_s<0>(lds_addr(base + a_dst), a_off, pa);
+    dma_s_x2(lds_addr(base + b_dst), b_off, pb);   // the second block: +1 KB in global memory and in LDS
+    pa += BK * sizeof(float);
+    pb += 16 * 256 * sizeof(float);
   };
 
   const int pre = nk < PW_D ? nk : PW_D;

@@ -1,0 +1,386 @@
+// Block-level drivers of the residual flow: ONE C-ABI call per iResBlock and direction (include/indm_hip.h,
+// "block-level drivers").  Nothing here is a kernel of its own except one tiny re-layout: the drivers enqueue the
+// launch sequence that indm_amd/flow.py::_IResTrain composes from the op-level entry points -- same kernels, same
+// order, same arguments, hence bit-identical results -- so that a training step crosses the Python / ctypes boundary
+// 64 times for the flow instead of ~1 800 times (the 16- to 64-image per-rank shards of BASELINE configs #2-#5 are
+// launch-bound on the host otherwise).
+//
+// Reference: flows/resflow/layers/iresblock.py:14-174 (forward :60-76, _logdetgrad :90-174, estimators :253-273,
+// _inverse_fixed_point :78-88).
+#include "indm_common.h"
+
+#pragma GCC visibility push(default)
+#include "../../include/indm_hip.h"
+#pragma GCC visibility pop
+
+#include <vector>
+
+namespace {
+
+struct Bump {
+  float* base;
+  long cap, off;
+  float* get(long n) {
+    const long a = (n + 63) & ~63L;  // 256-byte granules: every tensor stays 16-byte aligned for the DMA kernels
+    if (!base || off + a > cap) return nullptr;
+    float* p = base + off;
+    off += a;
+    return p;
+  }
+};
+static long pad64(long n) { return (n + 63) & ~63L; }
+
+// ---- launch timer -------------------------------------------------------------------------------------------------
+struct Timer {
+  std::vector<hipEvent_t> ev;
+  int used = 0, mask = 0;
+  double flops = 0.0;
+};
+
+static bool covered(int N, int H, int W, int C, int idim) {
+  const long M = (long)N * H * W;
+  if (idim != 512 || C < 1 || M < 1024 || (M % 64) || ((long)H * W) % 64) return false;
+  if (M * 9 * C >= (1L << 31) || M * idim >= (1L << 40)) return false;
+  const bool flat = C <= 3 && W <= 128 && (128 % W) == 0 && ((H * W) % 128) == 0 && (M % 128) == 0;
+  const bool k128 = !(C & 3) && 9 * C <= 128;
+  return flat || k128;
+}
+
+#define TRY(call)            \
+  do {                       \
+    int st_ = (call);        \
+    if (st_ != 0) return st_ < 0 ? st_ : INDM_E_SHAPE; /* a sub-launch that declines a covered geometry is a bug */ \
+  } while (0)
+
+struct Ctx {
+  int N, H, W, C, Cw, bf16;
+  long M;
+  float* sk;
+  long sk_floats;
+  void* st;
+  Timer* timer;
+
+  int gemm(const float* A, const float* G, const float* B, float* Cout, int M_, int N_, int K_, int ta, int tb, long lda,
+           long ldb, const float* bias, const float* bias2, int rpg) const {
+    auto f = bf16 ? indm_gemm_bf16 : indm_gemm_f32;
+    return f(A, G, B, Cout, M_, N_, K_, ta, tb, lda, ldb, N_, 1, 0, 0, (long)M_ * N_, 1.0f, bias, bias2, rpg, nullptr, N_,
+             0, 1.0f, sk, sk_floats, st);
+  }
+  // 3x3 / pad 1 conv of a skinny NHWC tensor x [N,H,W,C] with w2d [9C, Cw]; sign -1 conv, +1 transposed conv
+  int thin(const float* x, const float* w2d, float* y, int sign, const float* bias) const {
+    auto f = bf16 ? indm_conv3x3_thin_bf16 : indm_conv3x3_thin_f32;
+    return f(x, w2d, y, N, H, W, C, Cw, sign, 1.0f, bias, nullptr, nullptr, 1.0f, st);
+  }
+  int chain(const float* t3, const float* d2, const float* W2T, const void* W2Tp, const float* d1, const float* panel,
+            float* P, float* t2) const {
+    const int J = 9 * C;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timer) {
+      const int cls = (J <= 32 ? 0 : 2) + (t2 ? 1 : 0);
+      if (((timer->mask >> cls) & 1) && timer->used + 2 <= (int)timer->ev.size()) {
+        e0 = timer->ev[timer->used];
+        e1 = timer->ev[timer->used + 1];
+      }
+    }
+    if (e0) (void)hipEventRecord(e0, (hipStream_t)st);
+    int r;
+    if (bf16 && W2Tp) r = indm_ires_chain_bf16w(t3, d2, W2Tp, d1, panel, P, t2, (int)M, Cw, Cw, J, st);
+    else r = (bf16 ? indm_ires_chain_bf16 : indm_ires_chain_f32)(t3, d2, W2T, d1, panel, P, t2, (int)M, Cw, Cw, J, st);
+    if (e0) {
+      (void)hipEventRecord(e1, (hipStream_t)st);
+      timer->used += 2;
+      timer->flops += 2.0 * (double)M * Cw * (Cw + J);
+    }
+    return r;
+  }
+};
+
+// g(x, h) of the block (iresblock.py:60-76 / nnet): fills a0,d0 (preact), a1,d1,a2,d2 and returns g in `g`
+// (p = [M, Cw] scratch for the two pre-activations, Pn = [M, 9C] scratch).  want_d = 0: gates are not produced.
+static int g_pass(const Ctx& c, int preact, const float* x, const float* cb, const float* W1, const float* W2T,
+                  const float* W3ct, const float* b1, const float* b2, const float* b3, float* a0, float* d0, float* a1,
+                  float* d1, float* a2, float* d2, float* p, float* Pn, float* g) {
+  const long nC = c.M * c.C, nW = c.M * c.Cw;
+  const float* in = x;
+  if (preact) {
+    TRY(indm_sincos_act_fwd_f32(x, a0, d0, nC, c.st));
+    in = a0;
+  }
+  TRY(c.thin(in, W1, p, -1, b1));                                                   // p1 = conv(a0, W1) + b1
+  TRY(indm_sincos_act_fwd_f32(p, a1, d1, nW, c.st));
+  TRY(c.gemm(a1, nullptr, W2T, p, (int)c.M, c.Cw, c.Cw, 0, 1, c.Cw, c.Cw, b2, cb, c.H * c.W));   // p2 = a1 W2 + b2 + cb[n]
+  TRY(indm_sincos_act_fwd_f32(p, a2, d2, nW, c.st));
+  TRY(c.gemm(a2, nullptr, W3ct, Pn, (int)c.M, 9 * c.C, c.Cw, 0, 0, c.Cw, 9 * c.C, nullptr, nullptr, 1));   // skinny-output conv: GEMM + 9-tap gather
+  TRY(indm_tap_gather_f32(Pn, b3, g, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
+  return 0;
+}
+
+// out[b][a][c] = x[a][b][c] (+ x2[a][b][c]) (+ y[b][a][c]) : re-layout (and sum) of the small weight-gradient GEMM results
+__global__ __launch_bounds__(256) void permute021_add_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                             const float* __restrict__ y, float* __restrict__ out, int A,
+                                                             int B, int C) {
+  const int total = A * B * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c = i % C, ab = i / C;
+    const int a = ab % A, b = ab / A;        // i indexes out[b][a][c]
+    const int src = (a * B + b) * C + c;
+    float v = x[src];
+    if (x2) v = v + x2[src];
+    if (y) v = v + y[i];
+    out[i] = v;
+  }
+}
+static int permute021_add(const float* x, const float* x2, const float* y, float* out, int A, int B, int C, void* st) {
+  const int total = A * B * C;
+  hipLaunchKernelGGL(permute021_add_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)st, x, x2, y, out, A, B, C);
+  INDM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int which) {
+  const long M = (long)N * H * W, nC = pad64(M * C), nW = pad64(M * idim), nP = pad64(M * 9 * C);
+  const long red = pad64(indm_rowreduce_ws_floats(N, (long)H * W * C)) + pad64(N);
+  switch (which) {
+    case 0:  // forward, training: p, Pn, g, v, wtmp, vj + reductions
+      return nW + nP + 4 * nC + red + 64;
+    case 1:  // forward, eval: + a0,d0,a1,d1,a2,d2,t3 live here
+      return nW + nP + 3 * nC + red + 2 * nC + 5 * nW + 64;
+    case 2: {  // backward
+      const long small = 6 * pad64((long)idim * 9 * C) + pad64((long)N * idim) + pad64(idim);
+      const long redb = pad64(indm_colreduce_ws_floats(M, idim)) + pad64(indm_ires_bwd_act_ws_floats(M, idim)) +
+                        pad64(indm_colreduce_ws_floats(M, C)) + pad64(indm_colreduce_ws_floats(N, idim));
+      return 4 * nW + 2 * nP + 5 * nC + small + redb + 64;
+    }
+    default:  // inverse: a0, a1, a2, p, Pn, g, x ping-pong, check scalar
+      return 3 * nW + nP + 4 * nC + 128;
+  }
+}
+
+INDM_API int indm_iresblock_fwd_logdet(const indm_iresblock_fwd_args* a, void* stream) {
+  if (!a) return INDM_E_ARG;
+  if (a->N <= 0) return INDM_OK;
+  if (!covered(a->N, a->H, a->W, a->C, a->idim) || !a->panel) return 1;
+  if (!a->x || !a->cb || !a->W1 || !a->W2T || !a->W3_ci_tapco || !a->W3_tapco_ci || !a->b1 || !a->b2 || !a->b3 ||
+      !a->eps || !a->y || !a->logdet || (a->ncoeff > 0 && !a->coeffs) || a->ncoeff < 0)
+    return INDM_E_ARG;
+  Ctx c = {a->N, a->H, a->W, a->C, a->idim, a->bf16, (long)a->N * a->H * a->W, a->splitk_ws, a->splitk_ws_floats, stream,
+           (Timer*)a->timer};
+  const long nC = c.M * c.C, nW = c.M * c.Cw, nP = c.M * 9 * c.C;
+  Bump ws = {a->ws, a->ws_floats, 0};
+  float *a0 = a->a0, *d0 = a->d0, *a1 = a->a1, *d1 = a->d1, *a2 = a->a2, *d2 = a->d2, *t3 = a->t3;
+  if (a->training) {
+    if (!a1 || !d1 || !a2 || !d2 || !t3 || !a->t2 || !a->w || (a->preact && (!a0 || !d0 || !a->c1))) return INDM_E_ARG;
+  } else {
+    if (a->preact) { a0 = ws.get(nC); d0 = ws.get(nC); }
+    a1 = ws.get(nW); d1 = ws.get(nW); a2 = ws.get(nW); d2 = ws.get(nW); t3 = ws.get(nW);
+  }
+  float *p = ws.get(nW), *Pn = ws.get(nP), *g = ws.get(nC), *v = ws.get(nC);
+  float* rws = ws.get(indm_rowreduce_ws_floats(c.N, (long)c.H * c.W * c.C));
+  if (!p || !Pn || !g || !v || !rws || (!a->training && (!a1 || !t3 || (a->preact && !d0)))) return INDM_E_ARG;
+  const int K = a->ncoeff;
+
+  TRY(g_pass(c, a->preact, a->x, a->cb, a->W1, a->W2T, a->W3_ci_tapco, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2, p, Pn, g));
+  TRY(indm_axpby_f32(a->x, g, a->y, 1.0f, 1.0f, 0.0f, nC, stream));                  // y = x + g
+  const float* gate0 = a->preact ? d0 : nullptr;
+
+  if (a->training) {
+    // neumann_logdet_estimator (iresblock.py:264-273): v_k = J^T v_{k-1}, w = eps + sum (-1)^k c_k v_k, no graph
+    float* wtmp = ws.get(nC);
+    if (!wtmp) return INDM_E_ARG;
+    const float *vin = a->eps, *win = a->eps;
+    for (int k = 0; k < K; ++k) {
+      float* wout = ((K - 1 - k) & 1) ? wtmp : a->w;          // the last iteration lands in the saved tensor
+      TRY(c.thin(vin, a->W3_tapco_ci, t3, 1, nullptr));       // t3 = C3^T v
+      TRY(c.chain(t3, d2, a->W2T, a->W2T_bf16w, d1, a->panel, Pn, nullptr));
+      TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, win, wout, a->coeffs[k], c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+      vin = v;
+      win = wout;
+    }
+    if (K == 0 && hipMemcpyAsync(a->w, a->eps, nC * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+      return INDM_E_LAUNCH;
+    // the gradient-carrying last link: vj = d0 .* C1^T(d1 .* ((d2 .* C3^T w) W2^T)), logdet = <vj, eps>
+    TRY(c.thin(a->w, a->W3_tapco_ci, t3, 1, nullptr));
+    TRY(c.chain(t3, d2, a->W2T, a->W2T_bf16w, d1, a->panel, Pn, a->t2));
+    const float* vj;
+    if (a->preact) {
+      TRY(indm_tap_gather_f32(Pn, nullptr, a->c1, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+      TRY(indm_mul_f32(a->c1, d0, g, 1.0f, nC, stream));     // g is dead: reuse it for vj
+      vj = g;
+    } else {
+      TRY(indm_tap_gather_f32(Pn, nullptr, g, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+      vj = g;
+    }
+    TRY(indm_rowreduce_f32(vj, a->eps, a->logdet, c.N, (long)c.H * c.W * c.C, 0, 1.0f, rws, stream));
+    return INDM_OK;
+  }
+  // basic_logdet_estimator (iresblock.py:253-261): logdet = sum_k (-1)^(k+1)/k c_k <J^k-fold vjp, eps>
+  float* tr = ws.get(c.N);
+  if (!tr) return INDM_E_ARG;
+  const float* vin = a->eps;
+  for (int k = 0; k < K; ++k) {
+    TRY(c.thin(vin, a->W3_tapco_ci, t3, 1, nullptr));
+    TRY(c.chain(t3, d2, a->W2T, a->W2T_bf16w, d1, a->panel, Pn, nullptr));
+    TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, nullptr, nullptr, 0.0f, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+    vin = v;
+    TRY(indm_rowreduce_f32(v, a->eps, k == 0 ? a->logdet : tr, c.N, (long)c.H * c.W * c.C, 0, a->coeffs[k], rws, stream));
+    if (k > 0) TRY(indm_axpby_f32(a->logdet, tr, a->logdet, 1.0f, 1.0f, 0.0f, c.N, stream));
+  }
+  if (K == 0 && hipMemsetAsync(a->logdet, 0, c.N * sizeof(float), (hipStream_t)stream) != hipSuccess) return INDM_E_LAUNCH;
+  return INDM_OK;
+}
+
+INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) {
+  if (!a) return INDM_E_ARG;
+  if (a->N <= 0) return INDM_OK;
+  if (!covered(a->N, a->H, a->W, a->C, a->idim) || !a->gld) return 1;
+  if (!a->gy || !a->a0 || !a->a1 || !a->d1 || !a->a2 || !a->d2 || !a->t3 || !a->t2 || !a->w || !a->eps || !a->W1 ||
+      !a->W2 || !a->W2T || !a->W3_tapco_ci || (a->preact && (!a->d0 || !a->c1)) || !a->dx || !a->dcb || !a->dW1 ||
+      !a->dW2 || !a->dW3 || !a->dW2T || !a->db1 || !a->db2 || !a->db3)
+    return INDM_E_ARG;
+  Ctx c = {a->N, a->H, a->W, a->C, a->idim, a->bf16, (long)a->N * a->H * a->W, a->splitk_ws, a->splitk_ws_floats, stream,
+           nullptr};
+  const int C = c.C, Cw = c.Cw, Mi = (int)c.M, rps = c.H * c.W;
+  const long nC = c.M * C, nW = c.M * Cw, nP = c.M * 9 * C;
+  Bump ws = {a->ws, a->ws_floats, 0};
+  float *bufA = ws.get(nW), *bufB = ws.get(nW), *bufC = ws.get(nW), *bufD = ws.get(nW);
+  float *col = ws.get(nP), *Pn = ws.get(nP);
+  float *dvj = ws.get(nC), *q0 = ws.get(nC), *dd0 = ws.get(nC), *da0 = ws.get(nC), *tmpc = ws.get(nC);
+  float *qa = ws.get((long)Cw * 9 * C), *qb = ws.get((long)Cw * 9 * C), *qc = ws.get((long)Cw * 9 * C),
+        *qd = ws.get((long)Cw * 9 * C);
+  float *seg1 = ws.get((long)c.N * Cw);
+  float *cr_w = ws.get(indm_colreduce_ws_floats(c.M, Cw)), *act_w = ws.get(indm_ires_bwd_act_ws_floats(c.M, Cw)),
+        *cr_c = ws.get(indm_colreduce_ws_floats(c.M, C)), *cr_n = ws.get(indm_colreduce_ws_floats(c.N, Cw));
+  if (!bufA || !bufB || !bufC || !bufD || !col || !Pn || !dvj || !q0 || !dd0 || !da0 || !tmpc || !qa || !qb || !qc || !qd ||
+      !seg1 || !cr_w || !act_w || !cr_c || !cr_n)
+    return INDM_E_ARG;
+
+  // ---- g path, level 3:  g = conv(a2, W3) + b3 ----
+  float* da2 = bufA;
+  TRY(c.thin(a->gy, a->W3_tapco_ci, da2, 1, nullptr));                                           // da2 = C3^T gy
+  TRY(indm_tap_spread_f32(a->gy, col, c.N, c.H, c.W, C, 1, 1.0f, stream));                      // dW3 (g part) = a2^T spread(gy)
+  TRY(c.gemm(a->a2, nullptr, col, qa, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
+  TRY(indm_colreduce_f32(a->gy, nullptr, a->db3, c.M, C, 0, 1.0f, 0.0f, cr_c, stream));
+  // ---- reverse sweep of the last VJP chain: logdet = <d0 .* C1^T(d1 .* t2), eps>, t2 = (t3 .* d2) W2^T, t3 = C3^T w ----
+  TRY(indm_scale_rows_f32(a->eps, a->gld, dvj, c.N, (long)rps * C, stream));
+  const float* q0p = dvj;
+  if (a->preact) {
+    TRY(indm_mul2_f32(dvj, a->d0, a->c1, q0, dd0, nC, stream));
+    q0p = q0;
+  }
+  float* q1 = bufB;
+  TRY(c.thin(q0p, a->W1, q1, -1, nullptr));                                                      // q1 = conv(q0, W1) = dL/d(t2 .* d1)
+  TRY(indm_tap_spread_f32(q0p, col, c.N, c.H, c.W, C, -1, 1.0f, stream));                        // dW1 (chain part)^T = (t2 .* d1)^T spread(q0)
+  TRY(c.gemm(a->t2, a->d1, col, qb, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
+  float* du2 = bufC;
+  TRY(c.gemm(q1, a->d1, a->W2, du2, Mi, Cw, Cw, 0, 0, Cw, Cw, nullptr, nullptr, 1));              // du2 = (q1 .* d1) W2 = dL/d(t3 .* d2)
+  TRY(indm_tap_spread_f32(a->w, col, c.N, c.H, c.W, C, 1, 1.0f, stream));                        // dW3 (chain part) = (du2 .* d2)^T spread(w)
+  TRY(c.gemm(du2, a->d2, col, qc, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
+  TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream));                                // [Cw, tap, c] -> [tap, Cw, c], both parts summed
+  float* dp2 = bufD;
+  TRY(indm_ires_bwd_act_f32(da2, du2, a->d2, a->a2, a->t3, dp2, nullptr, a->dcb, c.M, Cw, rps, act_w, stream));
+  TRY(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  // ---- level 2:  p2 = a1 W2 + b2 + cb[image] ----
+  float* da1 = bufA;                                                                               // da2 is dead
+  TRY(c.gemm(dp2, nullptr, a->W2, da1, Mi, Cw, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));           // da1 = dp2 W2^T
+  TRY(c.gemm(a->a1, nullptr, dp2, a->dW2, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));       // dW2 = a1^T dp2
+  float *dp1 = bufC, *dt2 = bufD;                                                                  // du2, dp2 are dead
+  TRY(indm_ires_bwd_act_f32(da1, q1, a->d1, a->a1, a->t2, dp1, dt2, seg1, c.M, Cw, rps, act_w, stream));
+  TRY(c.gemm(a->t3, a->d2, dt2, a->dW2T, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));        // dW2T = (t3 .* d2)^T (q1 .* d1)
+  TRY(indm_colreduce_f32(seg1, nullptr, a->db1, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  // ---- level 1:  p1 = conv(a0, W1) + b1 ----
+  TRY(c.gemm(dp1, nullptr, a->W1, Pn, Mi, 9 * C, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));         // da0 = C1^T dp1: GEMM + gather
+  TRY(indm_tap_gather_f32(Pn, nullptr, da0, c.N, c.H, c.W, C, -1, 1.0f, stream));
+  TRY(indm_tap_spread_f32(a->a0, col, c.N, c.H, c.W, C, -1, 1.0f, stream));                      // dW1 (g part) = spread(a0)^T dp1
+  TRY(c.gemm(col, nullptr, dp1, qd, 9 * C, Cw, Mi, 1, 0, 9 * C, Cw, nullptr, nullptr, 1));
+  TRY(permute021_add(qb, nullptr, qd, a->dW1, Cw, 9 * C, 1, stream));                             // qb^T + qd
+  if (a->preact) {
+    TRY(indm_sincos_act_bwd_f32(da0, dd0, a->a0, a->d0, tmpc, nC, stream));
+    TRY(indm_axpby_f32(a->gy, tmpc, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+  } else {
+    TRY(indm_axpby_f32(a->gy, da0, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+  }
+  return INDM_OK;
+}
+
+INDM_API int indm_iresblock_inverse(const indm_iresblock_fwd_args* a, float atol, float rtol, int* iterations,
+                                    void* stream) {
+  if (!a) return INDM_E_ARG;
+  if (a->N <= 0) return INDM_OK;
+  if (!covered(a->N, a->H, a->W, a->C, a->idim)) return 1;
+  if (!a->x || !a->cb || !a->W1 || !a->W2T || !a->W3_ci_tapco || !a->b1 || !a->b2 || !a->b3 || !a->y) return INDM_E_ARG;
+  Ctx c = {a->N, a->H, a->W, a->C, a->idim, a->bf16, (long)a->N * a->H * a->W, a->splitk_ws, a->splitk_ws_floats, stream,
+           nullptr};
+  const long nC = c.M * c.C, nW = c.M * c.Cw, nP = c.M * 9 * c.C;
+  Bump ws = {a->ws, a->ws_floats, 0};
+  float *a0 = ws.get(nC), *a1 = ws.get(nW), *a2 = ws.get(nW), *p = ws.get(nW), *Pn = ws.get(nP), *g = ws.get(nC);
+  float *xa = ws.get(nC), *xb = ws.get(nC), *cnt = ws.get(64);
+  if (!a0 || !a1 || !a2 || !p || !Pn || !g || !xa || !xb || !cnt) return INDM_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const float* y = a->x;   // the block's OUTPUT is the input of the inverse
+  // x <- y - g(x), starting from x = y (iresblock.py:78-88)
+  TRY(g_pass(c, a->preact, y, a->cb, a->W1, a->W2T, a->W3_ci_tapco, a->b1, a->b2, a->b3, a0, nullptr, a1, nullptr, a2,
+             nullptr, p, Pn, g));
+  float *x = xa, *other = xb;
+  TRY(indm_axpby_f32(y, g, x, 1.0f, -1.0f, 0.0f, nC, stream));
+  const float* x_prev = y;
+  int i = 0;
+  for (;;) {
+    TRY(indm_fixed_point_check_f32(x, x_prev, y, nC, atol, rtol, cnt, stream));
+    float h = 0.f;
+    if (hipMemcpyAsync(&h, cnt, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) return INDM_E_LAUNCH;
+    if (hipStreamSynchronize(st) != hipSuccess) return INDM_E_LAUNCH;
+    if (h == 0.f) break;
+    TRY(g_pass(c, a->preact, x, a->cb, a->W1, a->W2T, a->W3_ci_tapco, a->b1, a->b2, a->b3, a0, nullptr, a1, nullptr, a2,
+               nullptr, p, Pn, g));
+    TRY(indm_axpby_f32(y, g, other, 1.0f, -1.0f, 0.0f, nC, stream));
+    x_prev = x;
+    float* t = x; x = other; other = t;
+    if (++i > 1000) break;
+  }
+  if (hipMemcpyAsync(a->y, x, nC * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return INDM_E_LAUNCH;
+  if (iterations) *iterations = i;
+  return INDM_OK;
+}
+
+// ---- launch timer ------------------------------------------------------------------------------------------------
+INDM_API int indm_timer_create(int capacity, void** handle) {
+  if (!handle || capacity <= 0) return INDM_E_ARG;
+  Timer* t = new Timer();
+  t->ev.resize(2 * (size_t)capacity);
+  for (auto& e : t->ev)
+    if (hipEventCreate(&e) != hipSuccess) return INDM_E_LAUNCH;
+  *handle = t;
+  return INDM_OK;
+}
+INDM_API int indm_timer_destroy(void* handle) {
+  Timer* t = (Timer*)handle;
+  if (!t) return INDM_OK;
+  for (auto& e : t->ev) (void)hipEventDestroy(e);
+  delete t;
+  return INDM_OK;
+}
+INDM_API int indm_timer_reset(void* handle, int cls_mask) {
+  Timer* t = (Timer*)handle;
+  if (!t) return INDM_E_ARG;
+  t->used = 0;
+  t->mask = cls_mask;
+  t->flops = 0.0;
+  return INDM_OK;
+}
+INDM_API int indm_timer_read(void* handle, float* total_ms, int* launches, double* flops) {
+  Timer* t = (Timer*)handle;
+  if (!t || !total_ms || !launches) return INDM_E_ARG;
+  float sum = 0.f;
+  for (int i = 0; i + 1 < t->used; i += 2) {
+    if (hipEventSynchronize(t->ev[i + 1]) != hipSuccess) return INDM_E_LAUNCH;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]) != hipSuccess) return INDM_E_LAUNCH;
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = t->used / 2;
+  if (flops) *flops = t->flops;
+  return INDM_OK;
+}

@@ -175,6 +175,13 @@ class IResBlock(nn.Module):
             if stats is not None:
                 stats.append((self, n, logdet.detach()))
             return y, logdet
+        if (hip.block_drivers() and x.is_cuda and not torch.is_grad_enabled() and len(W) > 4 and W[4] is not None):
+            # the whole block as ONE C-ABI call (indm_iresblock_fwd_logdet, eval mode); same kernels as below
+            c1, c2, c3 = self.convs
+            out = hip.iresblock_fwd(_cc(x), _cc(cb), _cc(W[0]), _cc(W[3]), W[2], W[4], c1.bias, c2.bias, c3.bias, eps,
+                                    [(-1) ** (k + 1) / k * coeff(k) for k in range(1, K + 1)], self.preact, False)
+            if out is not None:
+                return out[0], out[1]
         g, gates = self.g(x, cb, W, True)
         with torch.no_grad():  # basic_logdet_estimator :253-261 (create_graph=False)
             vjp = eps
@@ -187,6 +194,14 @@ class IResBlock(nn.Module):
 
     def inverse(self, y, cb, W, atol=1e-5, rtol=1e-5, iters=None):
         """_inverse_fixed_point iresblock.py:78-88"""
+        if hip.block_drivers() and y.is_cuda and not torch.is_grad_enabled():
+            c1, c2, c3 = self.convs
+            out = hip.iresblock_inverse(_cc(y), _cc(cb), _cc(W[0]), _cc(W[3]), W[2], c1.bias, c2.bias, c3.bias,
+                                        self.preact, atol, rtol)
+            if out is not None:
+                if iters is not None:
+                    iters.append(out[1])
+                return out[0]
         g, _ = self.g(y, cb, W, False)
         x, x_prev = ops.axpby(y, g, 1.0, -1.0), y
         i = 0
@@ -200,6 +215,10 @@ class IResBlock(nn.Module):
             iters.append(i)
         return x
 
+
+
+def _cc(t):
+    return t if t.is_contiguous() else t.contiguous()
 
 
 class _IResTrain(torch.autograd.Function):
@@ -223,6 +242,16 @@ class _IResTrain(torch.autograd.Function):
         N, H, Wd, C = x.shape
         hw = (H, Wd)
         Cw = W2.shape[0]
+        ctx.driver = False
+        if hip.block_drivers() and x.is_cuda and panel is not None:
+            # the whole block as ONE C-ABI call (indm_iresblock_fwd_logdet): the launch sequence below, enqueued from C++
+            out = hip.iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, blk.preact, True)
+            if out is not None:
+                y, logdet, (a0, d0, a1, d1, a2, d2, t3, t2, c1, w) = out
+                ctx.save_for_backward(a0, d0, a1, d1, a2, d2, t3, t2, c1, w, eps, W1, W2, W3, W2T)
+                ctx.cfg = (blk.preact, hw)
+                ctx.driver = True
+                return y, logdet
         a0, d0 = hip.sincos_fwd(x, True) if blk.preact else (x, None)
         p1 = hip.conv2d(a0, W1, bias=b1)
         a1, d1 = hip.sincos_fwd(p1, True)
@@ -267,6 +296,11 @@ class _IResTrain(torch.autograd.Function):
         seg_ok = rps % 64 == 0
         f2 = lambda t: t.view(-1, Cw)  # noqa: E731
         gy = torch.zeros_like(eps) if gy is None else (gy if gy.is_contiguous() else gy.contiguous())
+        if ctx.driver and gld is not None and hip.block_drivers():
+            out = hip.iresblock_bwd(gy, _cc(gld), (a0, d0, a1, d1, a2, d2, t3, t2, c1, w), eps, W1, W2, W2T, W3, preact)
+            if out is not None:
+                dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3 = out
+                return dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3, None, None, None, None
         # ---- g path, level 3 ----
         da2 = hip.conv2d_dgrad(gy, W3, hw)
         dW3 = hip.conv2d_wgrad(a2, gy, 3, 3)

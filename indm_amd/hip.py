@@ -109,9 +109,17 @@ _SIGS = {
     "indm_upfirdn2d_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                            c_p],
     "indm_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
+    "indm_iresblock_ws_floats": [c_i, c_i, c_i, c_i, c_i, c_i],
+    "indm_iresblock_fwd_logdet": [c_p, c_p],
+    "indm_iresblock_bwd": [c_p, c_p],
+    "indm_iresblock_inverse": [c_p, c_f, c_f, c_p, c_p],
+    "indm_timer_create": [c_i, c_p],
+    "indm_timer_destroy": [c_p],
+    "indm_timer_reset": [c_p, c_i],
+    "indm_timer_read": [c_p, c_p, c_p, c_p],
 }
 _LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_segreduce_ws_floats", "indm_rowreduce_ws_floats",
-             "indm_dsm_ws_floats", "indm_sqnorm_ws_floats", "indm_ires_bwd_act_ws_floats"}
+             "indm_dsm_ws_floats", "indm_sqnorm_ws_floats", "indm_ires_bwd_act_ws_floats", "indm_iresblock_ws_floats"}
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 
@@ -1131,3 +1139,185 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
                                        _ptr(ref) if ref is not None and ref.numel() > 0 else None, _ptr(y), x.numel(),
                                        step_b, size_b, act, grad, alpha, scale, _stream()), "indm_fused_bias_act_f32")
     return y
+
+
+# --------------------------------------------------------------------------- block-level drivers (csrc/iresblock.hip)
+class _IResFwdArgs(ctypes.Structure):
+    """indm_iresblock_fwd_args (include/indm_hip.h)"""
+    _fields_ = ([(n, c_i) for n in ("N", "H", "W", "C", "idim", "preact", "training", "bf16")]
+                + [(n, c_p) for n in ("x", "cb", "W1", "W2T", "W2T_bf16w", "W3_ci_tapco", "W3_tapco_ci", "panel", "b1", "b2",
+                                      "b3", "eps", "coeffs")]
+                + [("ncoeff", c_i)]
+                + [(n, c_p) for n in ("y", "logdet", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w")]
+                + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("timer", c_p)])
+
+
+class _IResBwdArgs(ctypes.Structure):
+    """indm_iresblock_bwd_args (include/indm_hip.h)"""
+    _fields_ = ([(n, c_i) for n in ("N", "H", "W", "C", "idim", "preact", "bf16")]
+                + [(n, c_p) for n in ("gy", "gld", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w", "eps", "W1", "W2",
+                                      "W2T", "W3_tapco_ci", "dx", "dcb", "dW1", "dW2", "dW3", "dW2T", "db1", "db2", "db3")]
+                + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l)])
+
+
+BLOCK_DRIVERS = {"on": os.environ.get("INDM_BLOCK_DRIVERS", "1") != "0"}   # tools / tests switch to the op-level composition
+
+
+def block_drivers(on=None):
+    """query / set whether flow.py runs an iResBlock through ONE C-ABI call per direction (indm_iresblock_*) or composes
+    the op-level calls in Python (same kernels and results; ~55 host calls per block instead of 2)"""
+    if on is not None:
+        BLOCK_DRIVERS["on"] = bool(on)
+    return BLOCK_DRIVERS["on"]
+
+
+_ires_ws_sizes = {}
+
+
+def _ires_ws(N, H, W, C, idim, which, device):
+    key = (N, H, W, C, idim, which)
+    n = _ires_ws_sizes.get(key)
+    if n is None:
+        n = _ires_ws_sizes[key] = int(lib().indm_iresblock_ws_floats(N, H, W, C, idim, which))
+    # per-call scratch from torch's caching allocator (stream-ordered reuse; the block's working set, not the
+    # process-wide split-K buffer: two blocks of different scales are in flight on the GPU back to back)
+    return torch.empty(n, dtype=torch.float32, device=device), n
+
+
+class ChainTimer:
+    """HIP events around the chain-kernel launches the block drivers enqueue (bench.py's roofline line)."""
+    CLASSES = {"ires_chain64x512x32,gated": 1, "ires_chain64x512x32,gated,t2out": 2,
+               "ires_chain64x512x128,gated": 4, "ires_chain64x512x128,gated,t2out": 8}
+
+    def __init__(self, capacity=4096):
+        self.h = ctypes.c_void_p()
+        _chk(lib().indm_timer_create(int(capacity), ctypes.byref(self.h)), "indm_timer_create")
+
+    def reset(self, variant):
+        """variant: an ires_chain class name (bf16 suffix ignored) -> True if the drivers can time it"""
+        mask = self.CLASSES.get(variant.replace(",bf16", ""), 0)
+        _chk(lib().indm_timer_reset(self.h, mask), "indm_timer_reset")
+        return mask != 0
+
+    def read(self):
+        ms, n, fl = ctypes.c_float(), ctypes.c_int(), ctypes.c_double()
+        _chk(lib().indm_timer_read(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "indm_timer_read")
+        return dict(ms=ms.value, launches=n.value, flops=fl.value)
+
+    def __del__(self):
+        try:
+            lib().indm_timer_destroy(self.h)
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_active_timer = [None]
+
+
+def set_chain_timer(t):
+    _active_timer[0] = t
+
+
+def _w2t_bf16w(w2t):
+    hit = _w2t_packed.get(id(w2t)) if _MFMA["dtype"] == "bf16" else None
+    if hit is not None and hit[0]() is w2t and hit[1] == w2t._version:
+        return hit[2].data_ptr()
+    return None
+
+
+def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, training):
+    """One iResBlock forward + log-det estimate through indm_iresblock_fwd_logdet.
+    -> None if the geometry is not covered, else (y, logdet, saved) with saved = the tensors the backward needs
+    (training) or None (eval)."""
+    N, H, W, C = x.shape
+    idim = W2T.shape[0]
+    if panel is None:
+        return None
+    dev = x.device
+    M = N * H * W
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    a = _IResFwdArgs()
+    a.N, a.H, a.W, a.C, a.idim, a.preact, a.training = N, H, W, C, idim, int(preact), int(training)
+    a.bf16 = int(_MFMA["dtype"] == "bf16")
+    a.x, a.cb, a.W1, a.W2T = _ptr(x), _ptr(cb), _ptr(W1), _ptr(W2T)
+    a.W2T_bf16w = _w2t_bf16w(W2T)
+    a.W3_ci_tapco, a.W3_tapco_ci = _ptr(_packed_weight(W3, "ci_tapco")), _ptr(_packed_weight(W3, "tapco_ci"))
+    a.panel, a.b1, a.b2, a.b3, a.eps = _ptr(panel), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(eps)
+    cf = (ctypes.c_float * max(1, len(coeffs)))(*coeffs)
+    a.coeffs, a.ncoeff = ctypes.cast(cf, c_p), len(coeffs)
+    y, logdet = new(N, H, W, C), new(N)
+    a.y, a.logdet = y.data_ptr(), logdet.data_ptr()
+    saved = None
+    if training:
+        a0, d0, c1 = (new(N, H, W, C), new(N, H, W, C), new(N, H, W, C)) if preact else (x, None, None)
+        a1, d1, a2, d2, t3, t2 = (new(N, H, W, idim) for _ in range(6))
+        w = new(N, H, W, C)
+        if preact:
+            a.a0, a.d0, a.c1 = a0.data_ptr(), d0.data_ptr(), c1.data_ptr()
+        a.a1, a.d1, a.a2, a.d2, a.t3, a.t2, a.w = (t.data_ptr() for t in (a1, d1, a2, d2, t3, t2, w))
+        saved = (a0, d0, a1, d1, a2, d2, t3, t2, c1, w)
+    ws, n = _ires_ws(N, H, W, C, idim, 0 if training else 1, dev)
+    a.ws, a.ws_floats = ws.data_ptr(), n
+    sk = _ws(SPLITK_WS_FLOATS, dev)
+    a.splitk_ws, a.splitk_ws_floats = sk.data_ptr(), SPLITK_WS_FLOATS
+    t = _active_timer[0]
+    a.timer = t.h if t is not None else None
+    st = lib().indm_iresblock_fwd_logdet(ctypes.byref(a), _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_iresblock_fwd_logdet")
+    return y, logdet, saved
+
+
+def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact):
+    """Backward of the training-mode block through indm_iresblock_bwd -> (dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3)
+    or None if not covered."""
+    a0, d0, a1, d1, a2, d2, t3, t2, c1, w = saved
+    N, H, W, C = eps.shape
+    idim = a1.shape[-1]
+    dev = eps.device
+    new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    a = _IResBwdArgs()
+    a.N, a.H, a.W, a.C, a.idim, a.preact = N, H, W, C, idim, int(preact)
+    a.bf16 = int(_MFMA["dtype"] == "bf16")
+    a.gy, a.gld = _ptr(gy), _ptr(gld)
+    a.a0, a.d0, a.c1 = _ptr(a0), _ptr(d0), _ptr(c1)
+    a.a1, a.d1, a.a2, a.d2, a.t3, a.t2, a.w, a.eps = (_ptr(t) for t in (a1, d1, a2, d2, t3, t2, w, eps))
+    a.W1, a.W2, a.W2T, a.W3_tapco_ci = _ptr(W1), _ptr(W2), _ptr(W2T), _ptr(_packed_weight(W3, "tapco_ci"))
+    out = (new(N, H, W, C), new(N, idim), new(3, 3, C, idim), new(idim, idim), new(3, 3, idim, C), new(idim, idim),
+           new(idim), new(idim), new(C))
+    a.dx, a.dcb, a.dW1, a.dW2, a.dW3, a.dW2T, a.db1, a.db2, a.db3 = (t.data_ptr() for t in out)
+    ws, n = _ires_ws(N, H, W, C, idim, 2, dev)
+    a.ws, a.ws_floats = ws.data_ptr(), n
+    sk = _ws(SPLITK_WS_FLOATS, dev)
+    a.splitk_ws, a.splitk_ws_floats = sk.data_ptr(), SPLITK_WS_FLOATS
+    st = lib().indm_iresblock_bwd(ctypes.byref(a), _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_iresblock_bwd")
+    return out
+
+
+def iresblock_inverse(y, cb, W1, W2T, W3, b1, b2, b3, preact, atol, rtol):
+    """Fixed-point inverse of one block through indm_iresblock_inverse -> (x, iterations) or None if not covered."""
+    N, H, W, C = y.shape
+    idim = W2T.shape[0]
+    dev = y.device
+    a = _IResFwdArgs()
+    a.N, a.H, a.W, a.C, a.idim, a.preact, a.training = N, H, W, C, idim, int(preact), 0
+    a.bf16 = int(_MFMA["dtype"] == "bf16")
+    a.x, a.cb, a.W1, a.W2T = _ptr(y), _ptr(cb), _ptr(W1), _ptr(W2T)
+    a.W3_ci_tapco = _ptr(_packed_weight(W3, "ci_tapco"))
+    a.b1, a.b2, a.b3 = _ptr(b1), _ptr(b2), _ptr(b3)
+    x = torch.empty_like(y)
+    a.y = x.data_ptr()
+    ws, n = _ires_ws(N, H, W, C, idim, 3, dev)
+    a.ws, a.ws_floats = ws.data_ptr(), n
+    sk = _ws(SPLITK_WS_FLOATS, dev)
+    a.splitk_ws, a.splitk_ws_floats = sk.data_ptr(), SPLITK_WS_FLOATS
+    it = ctypes.c_int(0)
+    st = lib().indm_iresblock_inverse(ctypes.byref(a), atol, rtol, ctypes.byref(it), _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_iresblock_inverse")
+    return x, it.value

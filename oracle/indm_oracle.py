@@ -871,6 +871,61 @@ def flow_step_fn_nll(cfg, sde, state, flow_state, batch, rng, stats=None):
     return tuple(torch.cat([p[i] for p in parts]) for i in range(4))
 
 
+def flow_step_fn_nll_chunked(cfg, sde, state, flow_state, batch, events, chunk=16):
+    """flow_step_fn_nll (losses.py:258-320, num_micro_batch = 1) evaluated in a bounded amount of host memory: the same
+    step, image chunks at a time.  Images are independent units of the objective (losses.py:303-304) except through the
+    train-mode BatchNorm statistics of the flow's encoder (resnet_batchnorm.py:23,31), so the encoder + prior flow run
+    ONCE on the whole batch, the residual flow / score network / prior terms run per chunk on the matching rows of h,
+    KL and of every recorded noise draw (`events`: the whole-batch draws in the reference's call order; the Poisson
+    series lengths are per block, not per image, and are replayed unchanged for every chunk), and the gradients of
+    mean(losses) accumulate over the chunks -- through h and KL back into the encoder at the end.  Pinned against the
+    unchunked form on the mini golden configuration (tests/test_oracle_golden.py).  The eager double-backward graph of
+    a whole batch-128 step needs ~100 GB of host memory; a 16-image chunk ~13 GB."""
+    assert int(cfg.optim.num_micro_batch) == 1
+    state.zero_grad()
+    flow_state.zero_grad()
+    B = batch.shape[0]
+    P = flow_state.P
+    bn = {}
+    x_in = squeeze(batch, 2) if cfg.flow.squeeze else batch
+    enc_rng = ReplayRng(events[:1])                       # the posterior noise [B, 1, 64] (gaussian.py:70)
+    zh, kl = sampling_and_kl(P, x_in, True, enc_rng, bn)
+    assert enc_rng.done()
+    h_leaf = zh.view(-1, zh.size(2)).detach().requires_grad_(True)
+    kl_leaf = kl.detach().requires_grad_(True)
+    rest = events[1:]
+    D = np.prod(batch.shape[1:])
+    parts = []
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        rng = ReplayRng([(k, v if k == "poisson" else v[lo:hi]) for k, v in rest])
+        e, logpx = residual_flow_fwd(P, x_in[lo:hi], h_leaf[lo:hi], True, True, rng)
+        z, lf = e, -logpx - kl_leaf[lo:hi]                # wolf_forward returns (eps, -logpx - KL)  (wolf.py:81-130)
+        if cfg.flow.squeeze:
+            z = torch.pixel_shuffle(z, 2)
+        ls = sde_loss(state.P, cfg, sde, z, True, rng)
+        lp = calculate_logp(sde, z, rng)
+        assert rng.done()
+        if cfg.training.reduce_mean:
+            lf, lp = -lf / D, -lp / D
+        else:
+            lf, lp = -lf, -lp
+        losses = ls + lf + lp
+        (losses.sum() / B).backward()                     # = this chunk's share of torch.mean(losses).backward()
+        parts.append((losses.detach(), ls.detach(), lf.detach(), lp.detach()))
+    torch.autograd.backward([zh.view(-1, zh.size(2)), kl], [h_leaf.grad, kl_leaf.grad])
+    with torch.no_grad():
+        for k, v in bn.items():
+            P[k] = v
+    state.optimize()
+    flow_state.optimize()
+    state.step += 1
+    state.ema_update()
+    flow_state.step += 1
+    flow_state.ema_update()
+    return tuple(torch.cat([p[i] for p in parts]) for i in range(4))
+
+
 def flow_step_fn_fid(cfg, sde, state, flow_state, batch, rng, stats=None):
     """losses.py:322-406 (training.st=False)"""
     state.zero_grad()

@@ -397,3 +397,31 @@ def test_step_after_reference_checkpoint():
         for k, s_ in zip(st.trainable, st.ema):
             gu.assert_close(gu.stat(s_), d[f"ckpt/after/{pre}/emastat/{k}"], 1e-5, 1e-6, "ema " + k)
     assert [state.step, fstate.step, state.num_updates] == list(d["ckpt/steps"])
+
+
+def test_chunked_step_matches_reference_goldens():
+    """flow_step_fn_nll_chunked (the bounded-memory evaluation of the same step that the batch-128 GPU parity test
+    uses) against the reference's own two-step golden: whole-batch encoder statistics, one image per chunk."""
+    fx = "mini_vp_nll"
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    sde = O.get_sde(cfg)
+    state = O.OracleState(gu.state_dict(d, "score"), cfg.optim.lr, cfg.model.ema_rate, cfg)
+    fstate = O.OracleState(gu.state_dict(d, "flow"), cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    for it in range(2):
+        out = O.flow_step_fn_nll_chunked(cfg, sde, state, fstate, torch.from_numpy(d[f"step{it}/x"]),
+                                         gu.events(d, f"step{it}"), chunk=1)
+        for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+            gu.assert_close(v, d[f"step{it}/{nm}"], 2e-4, 1e-5, f"chunked step{it} {nm}")
+        if it == 0:
+            for pre, st in (("score", state), ("flow", fstate)):
+                for k in st.trainable:
+                    key = f"step0/gradstat/{pre}/{k}"
+                    if key in d:
+                        gu.assert_close(gu.stat(st.P[k].grad), d[key], 1e-3, 1e-7, "chunked gradstat " + k)
+    for pre, st in (("score", state), ("flow", fstate)):
+        for k in st.trainable:
+            gu.assert_close(gu.stat(st.P[k]), d[f"after2/{pre}/stat/{k}"], 1e-5, 1e-6, "chunked param " + k)
+        for k, v in gu.sub(d, f"after2/{pre}/full").items():
+            gu.assert_close(st.P[k], v, 1e-4, 2e-6, "chunked full " + k)
+    for k, v in gu.sub(d, "after2/flow/buffers").items():
+        gu.assert_close(fstate.P[k].float(), v.float(), 1e-5, 1e-6, "chunked " + k)

@@ -126,3 +126,29 @@ def test_thin_conv3x3_at_full_M(hw, c):
     want = F.conv_transpose2d((xw[imgs] * gate[imgs]).permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(),
                               padding=1).permute(0, 2, 3, 1)
     _check(t[imgs], want, 9 * co, f"gated transposed conv 512->{c}")
+
+
+@pytest.mark.parametrize("M,J", [(131072, 27), (32768, 108)])
+@pytest.mark.parametrize("want_t2", [False, True])
+def test_ires_chain_fp32_at_benchmark_size(M, J, want_t2):
+    """The benchmark's dominant kernel at its benchmark size: the fp32 back-to-back chain kernel
+    `ires_chain_kernel<1|4,false,want_t2>` at M = 131072 / J = 27 (scale 0 at batch 128, 2048 workgroups) and
+    M = 32768 / J = 108 (scale 1), with and without the stored 512-wide intermediate.  >= 4096 sampled rows (both ends,
+    workgroup edges) x all columns against ((t3 .* d2) W2T .* d1) W1p evaluated in fp64 on the host."""
+    K = N = 512
+    JP = 32 if J <= 32 else 128
+    t3, d2, d1 = _rnd(M, K, seed=21), torch.cos(_rnd(M, K, seed=22)), torch.cos(_rnd(M, N, seed=23))
+    w2t = _rnd(K, N, seed=24, scale=K ** -0.5)
+    w1p = torch.zeros(N, JP)
+    w1p[:, :J] = _rnd(N, J, seed=25, scale=N ** -0.5)
+    assert hip.compute_dtype() == "f32"
+    out = hip.ires_chain(t3.to(DEV), d2.to(DEV), w2t.to(DEV), d1.to(DEV), w1p.to(DEV), J, want_t2=want_t2)
+    assert out is not None, "the chain kernel declined its own benchmark geometry"
+    P, t2 = out if want_t2 else (out, None)
+    assert P.shape == (M, J)
+    r = torch.unique(torch.cat([_rows(M), torch.arange(63, M, M // 512), torch.arange(64, M, M // 512)]))
+    assert r.numel() >= 4096
+    t2_ref = (t3[r].double() * d2[r].double()) @ w2t.double()
+    if want_t2:
+        _check(t2[r.to(DEV)], t2_ref, K, f"chain t2 M={M}")
+    _check(P[r.to(DEV)], (t2_ref * d1[r].double()) @ w1p[:, :J].double(), K + N, f"chain panel M={M} J={J}")
