@@ -58,6 +58,7 @@ struct IgemmParams {
   int a_tap_uniform, b_tap_uniform;  // reduction slab of BK never straddles a tap (Cin % BK == 0)
   int wg_inc;                        // A_WGRAD: pixel decode advanced incrementally (needs OH*OW >= BK)
   int ow_sh, ohw_sh;                 // log2(OW), log2(OH*OW) when both are powers of two, else -1
+  int a_buf;                         // A_CONV on the direct-to-LDS kernel: buffer-addressed copies (dma_buffer)
   int bf16;                          // MFMA inputs rounded to bf16 (RNE), fp32 accumulate (BASELINE configs #3-#5)
 };
 
@@ -1001,6 +1002,16 @@ __device__ __forceinline__ void dma_saddr(unsigned lds_byte_addr, unsigned voff,
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
 }
+// The same copy through a raw BUFFER resource (`buffer_load_dwordx4 voffset, s[rsrc], soffset offen lds`, gfx950):
+// address = resource base + soffset (SGPR: the slab's uniform tap offset) + the lane's fixed 32-bit offset, and a lane
+// whose offset is out of range (bit 31 set) copies ZEROS -- a padded tap of an implicit-GEMM convolution costs two VALU
+// instructions (shift + and-or of a per-lane tap mask) instead of two compares, a 64-bit add and a two-register
+// select of a zero page's address (tools/probe/buffer_lds.hip checks the semantics on the part).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_buffer(unsigned lds_byte_addr, unsigned voff, i32x4 rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 __device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
@@ -1061,7 +1072,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   // loop's VALU work does not overlap with the MFMAs)
   int ih0[16 / NW], iw0[16 / NW];
   long pbase[16 / NW];
+  // buffer form (p.a_buf: undilated input smaller than 2 GB, at most 31 taps): the resource starts `shift` elements
+  // BEFORE the tensor so that the offset of a pixel's top-left tap is never negative; cvoff = the lane's fixed byte
+  // offset, cbad = bit t set if tap t falls into the padding for this lane's pixel
+  unsigned cvoff[16 / NW], cbad[16 / NW];
+  i32x4 arsrc = {0, 0, 0, 0};
   if constexpr (AM == A_CONV) {
+    const long shift = ((long)p.pad * p.W + p.pad) * p.Cin;
+    if (p.a_buf) {
+      const unsigned long long ab = (unsigned long long)(A - shift);
+      arsrc[0] = (int)(unsigned)(ab & 0xffffffffu);
+      arsrc[1] = (int)(unsigned)((ab >> 32) & 0xffffu);                 // stride 0: raw buffer
+      arsrc[2] = (int)(((long)(p.M / (p.OH * p.OW)) * p.H * p.W * p.Cin + shift) * 4);
+      arsrc[3] = 0x00020000;                                            // DATA_FORMAT_32 (gfx90a / gfx94x / gfx950)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) arsrc[i] = __builtin_amdgcn_readfirstlane(arsrc[i]);
+    }
 #pragma unroll
     for (int q = 0; q < 16 / NW; ++q) {
       const int row = wave * (256 / NW) + q * 16 + (lane >> 2);
@@ -1070,6 +1096,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       iw0[q] = pix[q].ow * p.stride - p.pad;
       const int c = (lane & 3) ^ ((row >> 2) & 3);
       pbase[q] = (((long)pix[q].img * p.H + ih0[q]) * p.W + iw0[q]) * p.Cin + 4 * c;
+      cvoff[q] = (unsigned)((pbase[q] + shift) * 4);
+      unsigned bad = 0;
+      if (p.a_buf) {
+        for (int t = 0; t < p.KH * p.KW; ++t) {
+          const int kh = t / p.KW, kw = t - kh * p.KW;
+          const bool ok = (unsigned)(ih0[q] + kh) < (unsigned)p.H && (unsigned)(iw0[q] + kw) < (unsigned)p.W;
+          bad |= ok ? 0u : (1u << t);
+        }
+      }
+      cbad[q] = bad;
     }
   }
   // A_ROW / B_COL / B_ROW: every DMA of this lane reads the same row (or k-row) in every slab -> per-lane source
@@ -1125,10 +1161,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   auto stage = [&](int buf, int kt) {
     float* base = glds_smem + buf * BUF;
     const int k0 = kbeg + kt * BK;
-    int kh = 0, kw = 0, ci0 = 0;
+    int kh = 0, kw = 0, ci0 = 0, tap_idx = 0;
     long tap_off = 0;
     if constexpr (AM == A_CONV) {  // one tap per slab (host checks Cin % 16 == 0)
       const int tap = k0 / p.Cin;
+      tap_idx = tap;
       ci0 = k0 - tap * p.Cin;
       kh = tap / p.KW;
       kw = tap - kh * p.KW;
@@ -1146,6 +1183,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         const int kr = wave * (16 / NW) + q;
         dma_saddr(lds_byte_addr(base + kr * TM), aoff[q], ua);
         if constexpr (HAS_G) dma_saddr(lds_byte_addr(base + A_SZ + kr * TM), aoff[q], ug);
+      } else if (p.a_buf) {     // block-uniform branch: buffer form, see dma_buffer
+        const unsigned oob = (cbad[q] << (31 - tap_idx)) & 0x80000000u;
+        dma_buffer(lds_byte_addr(base + r0 * BK), cvoff[q] | oob, arsrc, (unsigned)(tap_off * 4));
       } else if (p.dil == 1) {  // block-uniform branch
         const bool ok = (unsigned)(ih0[q] + kh) < (unsigned)p.H && (unsigned)(iw0[q] + kw) < (unsigned)p.W;
         const float* src = A + pbase[q] + tap_off;
@@ -1177,7 +1217,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         } else {  // B_DGRAD: packed weight [T][N][Cout], taps flipped; one tap per slab
           const int tap = k0 / p.Cout, co0 = k0 - tap * p.Cout;
           const long toff = (long)(p.KH * p.KW - 1 - tap) * p.N * p.Cout + co0;  // uniform
-          dma(B + toff + bdg[q], bb + r0 * BK);
+          dma_saddr(lds_byte_addr(bb + r0 * BK), (unsigned)(bdg[q] * 4), B + toff);
         }
       } else {              // [16 k][128 n]: two k-rows per instruction, 16 / NW k-rows per wave
         const int kr0 = wave * (16 / NW) + q * 2;
@@ -1806,6 +1846,7 @@ static int conv2d_fwd_f32_impl(int bf16, const float* x, const float* w, float* 
   p.a_vec = al16(x) && (Cin % 4 == 0);
   p.b_vec = al16(w) && (Cout % 4 == 0);
   p.a_tap_uniform = (Cin % BK == 0);
+  p.a_buf = p.dil == 1 && pad >= 0 && KH * KW <= 31 && ((long)Nimg * H * W + (long)pad * (W + 1)) * Cin * 4 < (1L << 31);
   return run(p, A_CONV, B_ROW, ws, ws_floats, (hipStream_t)stream);
 }
 INDM_API int indm_conv2d_fwd_f32(const float* x, const float* w, float* y, int Nimg, int H, int W,
@@ -1841,6 +1882,7 @@ static int conv2d_dgrad_f32_impl(int bf16, const float* dy, const float* w, floa
   p.a_vec = al16(dy) && (Cout % 4 == 0);
   p.b_vec = al16(w) && (Cout % 4 == 0);
   p.a_tap_uniform = p.b_tap_uniform = (Cout % BK == 0);
+  p.a_buf = p.dil == 1 && pad_t >= 0 && KH * KW <= 31 && ((long)Nimg * H * W + (long)pad_t * (W + 1)) * Cout * 4 < (1L << 31);
   return run(p, A_CONV, B_DGRAD, ws, ws_floats, (hipStream_t)stream);
 }
 INDM_API int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, int H, int W,

@@ -277,7 +277,12 @@ def coupling(x, prm, split, up, inverse):
 
 
 class _Attention(Function):
-    """h = softmax(q k^T * scale) v, fused (the [T,T] logits never reach HBM; recomputed in registers in the backward)."""
+    """h = softmax(q k^T * scale) v: fused forward (the [T,T] logits never reach HBM).  Backward = recompute the
+    probabilities with one batched MFMA GEMM + the wavefront softmax and run the five batched GEMMs of the textbook
+    gradient: on this part that composition takes ~330 us per block at batch 128 against 575 us for the fully fused
+    recompute-in-registers backward (indm_attn_bwd_f32: 7 GEMM units at one wave per SIMD) -- the
+    transient [B,T,T] tensors (33.5 MB each at T = 256) live only inside this call.  INDM_ATTN_FUSED_BWD=1 selects the
+    fused backward (kept, tested: it is the memory-lean variant)."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
@@ -293,8 +298,21 @@ class _Attention(Function):
     @staticmethod
     def backward(ctx, dh):
         q, k, v, h, lse = ctx.saved_tensors
-        dq, dk, dv = hip.attn_bwd(q, k, v, h, _c(dh), lse, ctx.scale)
+        dh = _c(dh)
+        if FUSED_ATTN_BWD["on"]:
+            dq, dk, dv = hip.attn_bwd(q, k, v, h, dh, lse, ctx.scale)
+            return dq, dk, dv, None
+        p = hip.softmax_fwd(hip.gemm(q, k, trans_b=True), ctx.scale)          # [B,T,T] probabilities, recomputed
+        dv = hip.gemm(p, dh, trans_a=True)                                    # P^T dh
+        ds = hip.softmax_bwd(hip.gemm(dh, v, trans_b=True), p, ctx.scale)     # dL/d(logits)
+        del p
+        dq = hip.gemm(ds, k)                                                  # dS K
+        dk = hip.gemm(ds, q, trans_a=True)                                    # dS^T Q
         return dq, dk, dv, None
+
+
+import os as _os
+FUSED_ATTN_BWD = {"on": _os.environ.get("INDM_ATTN_FUSED_BWD", "0") == "1"}
 
 
 def attention(q, k, v, scale):

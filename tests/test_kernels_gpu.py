@@ -700,14 +700,20 @@ def test_fused_attention(B, T, C):
     from indm_amd import ops
     qs = (q * 6).to(DEV).requires_grad_(True)
     ks, vs = k.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
-    out = ops.attention(qs, ks, vs, scale)
-    gq, gk, gv = torch.autograd.grad(out, [qs, ks, vs], dh.to(DEV))
     qd, kd, vd = (t.detach().cpu().double().requires_grad_(True) for t in (qs, ks, vs))
     oref = torch.softmax(qd @ kd.transpose(1, 2) * scale, -1) @ vd
     rq, rk, rv = torch.autograd.grad(oref, [qd, kd, vd], dh.double())
-    close(out, oref, rtol=2e-5, atol=2e-6, name="sharp attn h")
-    for g, r, nm in zip((gq, gk, gv), (rq, rk, rv), ("dq", "dk", "dv")):
-        close(g, r, rtol=5e-5, atol=5e-6, name="sharp attn " + nm)
+    was = ops.FUSED_ATTN_BWD["on"]
+    try:
+        for fused_bwd in (False, True):   # the default composed backward (recomputed probabilities + 5 GEMMs) and the fused one
+            ops.FUSED_ATTN_BWD["on"] = fused_bwd
+            out = ops.attention(qs, ks, vs, scale)
+            gq, gk, gv = torch.autograd.grad(out, [qs, ks, vs], dh.to(DEV))
+            close(out, oref, rtol=2e-5, atol=2e-6, name="sharp attn h")
+            for g, r, nm in zip((gq, gk, gv), (rq, rk, rv), ("dq", "dk", "dv")):
+                close(g, r, rtol=5e-5, atol=5e-6, name=f"sharp attn {nm} (fused bwd {fused_bwd})")
+    finally:
+        ops.FUSED_ATTN_BWD["on"] = was
 
 
 def test_attention_fallback_geometry():
