@@ -23,6 +23,9 @@ namespace {
 
 constexpr int BK = 16, TM = 64, TN = 512, NW = 8;
 constexpr int A_SZ = TM * BK, G_SZ = TM * BK, B_SZ = BK * TN, BUF = A_SZ + G_SZ + B_SZ;  // floats per LDS buffer
+// (ires_chain_kernel is templated on its row count TMV = 64 | 32: the 32-row form doubles the workgroup count when M is
+// too small to give every CU its two 64-row workgroups -- the per-rank shards of BASELINE configs #2 - #5; the LDS
+// layout keeps the 64-row offsets, the upper halves of the A / gate images simply stay unused)
 
 struct ChainArgs {
   const float* A;    // t3  [M, K]
@@ -71,12 +74,13 @@ __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; 
 // gate, the second contraction against the W1 panel and the 8-way cross-wave reduction (see the header comment).
 // acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi] on entry; every wave has passed a
 // workgroup barrier after its last read of the operand buffers (`red` overlays them).
-template <int JB, bool BF16, bool T2OUT>
-__device__ __forceinline__ void chain_epilogue(const ChainArgs& p, f32x16 (&acc)[2][2], float* smem, int tid, int wave,
+template <int JB, bool BF16, bool T2OUT, int TMV = 64>
+__device__ __forceinline__ void chain_epilogue(const ChainArgs& p, f32x16 (&acc)[2][TMV / 32], float* smem, int tid, int wave,
                                                int m0, int nw, int l31, int lhi) {
+  constexpr int MB = TMV / 32;   // 32-row m-blocks per workgroup
   if constexpr (T2OUT) {  // 16-byte pieces, a 128-byte row segment is completed by four stores of the same wave
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < MB; ++j) {
       float* trow = p.T2 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -88,7 +92,7 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& p, f32x16 (&acc)
   }
   // ---- gate: acc[i][j][r] = t2[m = m0 + 32j + l31][n = nw + 32i + 8(r>>2) + (r&3) + 4 lhi]  *=  d1[m][n] ----
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < MB; ++j) {
     const float* drow = p.D1 + (long)(m0 + j * 32 + l31) * TN + nw + 4 * lhi;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -111,12 +115,12 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& p, f32x16 (&acc)
 
   // ---- stage 2: out[m][j] = sum over this wave's 64 n's of u1[m][n] * W1p[n][j]; 8-way reduce through LDS ----
   const int JP = 32 * JB;
-  float* red = smem;  // [8 waves][64 m][32 j] = 64 KB (the operand buffers are dead)
+  float* red = smem;  // [8 waves][TMV m][32 j] <= 64 KB (the operand buffers are dead)
 #pragma unroll 1
   for (int jb = 0; jb < JB; ++jb) {
-    f32x16 out[2];
+    f32x16 out[MB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[j][r] = 0.f;
 #pragma unroll
@@ -132,25 +136,25 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& p, f32x16 (&acc)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MB; ++j)
           out[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[i][j][r], w[r], out[j], 0, 0, 0);  // D'[m][j]
     }
     if (jb > 0) __syncthreads();  // the previous round's reduction has read `red`
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = j * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi;
-        red[(wave * 64 + m) * 32 + l31] = out[j][r];
+        red[(wave * TMV + m) * 32 + l31] = out[j][r];
       }
     __syncthreads();
-    // 64 x 32 outputs, 4 per thread: thread -> (m = tid / 8, j = (tid % 8) * 4 .. +3)
-    {
+    // TMV x 32 outputs, 4 per thread: thread -> (m = tid / 8, j = (tid % 8) * 4 .. +3)
+    if (tid < TMV * 8) {
       const int m = tid >> 3, j0 = (tid & 7) * 4;
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int wv = 0; wv < NW; ++wv) {
-        const float4 v = *(const float4*)(red + (wv * 64 + m) * 32 + j0);
+        const float4 v = *(const float4*)(red + (wv * TMV + m) * 32 + j0);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
       float* dst = p.P + (long)(m0 + m) * p.J + jb * 32 + j0;
@@ -168,22 +172,23 @@ __device__ __forceinline__ void chain_epilogue(const ChainArgs& p, f32x16 (&acc)
 // MFMA (products of bf16 values are exact in fp32: identical to a bf16 MFMA).
 // T2OUT: the launch also stores the intermediate (its own instantiation: a distinct kernel name in profiles, and no
 // run-time branch around the store).
-template <int JB, bool BF16, bool T2OUT>
+template <int JB, bool BF16, bool T2OUT, int TMV = 64>
 __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
+  constexpr int MB = TMV / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * TM;
+  const int m0 = blockIdx.x * TMV;
   const int nk = p.K / BK;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int swz = (l31 >> 2) & 3;
   const int nw = wave * 64;
 
-  f32x16 acc[2][2];  // [n-block][m-block]
+  f32x16 acc[2][MB];  // [n-block][m-block]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -208,18 +213,18 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   // an M0 write and its hazard wait each -- at 9 % of this loop: non-MFMA VALU work does NOT overlap with the MFMAs.
   auto stage = [&](int buf) {
     float* base = smem + buf * BUF;
-    dma_s<0>(lds_addr(base + a_dst), a_off, pa);
+    if ((wave & 3) < TMV / 16) dma_s<0>(lds_addr(base + a_dst), a_off, pa);   // 16 rows of A / of the gate per wave
     pa += BK * sizeof(float);
     dma_s_x4(lds_addr(base + A_SZ + G_SZ + wave * 2 * TN), b_off, pb);
     pb += (long)BK * TN * sizeof(float);
   };
 
-  auto frags = [&](int buf, int sg, float4 (&fm)[2], float4 (&fn)[2]) {
+  auto frags = [&](int buf, int sg, float4 (&fm)[MB], float4 (&fn)[2]) {
     const float* as = smem + buf * BUF;
     const float* bs = as + A_SZ + G_SZ;
     const int ch = ((sg * 2 + lhi) ^ swz) << 2;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {  // m side: (t3 .* d2)[m = 32j + l31][k = 8sg + 4lhi + t]
+    for (int j = 0; j < MB; ++j) {  // m side: (t3 .* d2)[m = 32j + l31][k = 8sg + 4lhi + t]
       const int o = (j * 32 + l31) * BK + ch;
       const f32x4 av = *(const f32x4*)(as + o), gv = *(const f32x4*)(as + A_SZ + o);
       const f32x4 u = av * gv;
@@ -231,20 +236,20 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
       fn[i] = make_float4(q[0], q[TN], q[2 * TN], q[3 * TN]);
     }
   };
-  auto mfmas = [&](const float4 (&fm)[2], const float4 (&fn)[2]) {
+  auto mfmas = [&](const float4 (&fm)[MB], const float4 (&fn)[2]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < MB; ++j) {
           const float a = t == 0 ? fn[i].x : t == 1 ? fn[i].y : t == 2 ? fn[i].z : fn[i].w;
           const float b = t == 0 ? fm[j].x : t == 1 ? fm[j].y : t == 2 ? fm[j].z : fm[j].w;
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);  // D[n][m]
         }
   };
 
-  float4 fm0[2], fn0[2], fm1[2], fn1[2];
+  float4 fm0[MB], fn0[2], fm1[MB], fn1[2];
   if constexpr (BF16) {
     auto pack = [](const float4& lo, const float4& hi) {
       bf16x8 v;
@@ -260,15 +265,15 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
       if (s + 1 < nk) stage(buf ^ 1);
       frags(buf, 0, fm0, fn0);
       frags(buf, 1, fm1, fn1);
-      bf16x8 hm[2], hn[2];
+      bf16x8 hm[MB], hn[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) hm[j] = pack(fm0[j], fm1[j]);
+      for (int j = 0; j < MB; ++j) hm[j] = pack(fm0[j], fm1[j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) hn[i] = pack(fn0[i], fn1[i]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MB; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hn[i], hm[j], acc[i][j], 0, 0, 0);  // D[n][m]
       __builtin_amdgcn_sched_barrier(0);  // (MFMAs stay above the barrier: no accumulator rotation, see igemm.hip)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   mfmas(fm1, fn1);
   }
 
-  chain_epilogue<JB, BF16, T2OUT>(p, acc, smem, tid, wave, m0, nw, l31, lhi);
+  chain_epilogue<JB, BF16, T2OUT, TMV>(p, acc, smem, tid, wave, m0, nw, l31, lhi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -421,18 +426,24 @@ int launch_chain_pw_t(const ChainArgsPW& q, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
-template <int JB, bool BF16, bool T2OUT>
-int launch_chain_t(const ChainArgs& p, hipStream_t st) {
+template <int JB, bool BF16, bool T2OUT, int TMV>
+int launch_chain_tm(const ChainArgs& p, hipStream_t st) {
   constexpr size_t bytes = 2 * BUF * sizeof(float);
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB, BF16, T2OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB, BF16, T2OUT, TMV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess)
       return INDM_E_LAUNCH;
     ready = true;
   }
-  hipLaunchKernelGGL((ires_chain_kernel<JB, BF16, T2OUT>), dim3(p.M / TM), dim3(NW * 64), bytes, st, p);
+  hipLaunchKernelGGL((ires_chain_kernel<JB, BF16, T2OUT, TMV>), dim3(p.M / TMV), dim3(NW * 64), bytes, st, p);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+template <int JB, bool BF16, bool T2OUT>
+int launch_chain_t(const ChainArgs& p, hipStream_t st) {
+  // fewer than two 64-row workgroups per CU (M < 32768 on this part): 32-row workgroups, twice as many
+  if (p.M / TM < 512) return launch_chain_tm<JB, BF16, T2OUT, 32>(p, st);
+  return launch_chain_tm<JB, BF16, T2OUT, 64>(p, st);
 }
 template <int JB, bool BF16>
 int launch_chain(const ChainArgs& p, hipStream_t st) {
