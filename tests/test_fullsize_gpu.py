@@ -370,6 +370,58 @@ def test_bf16_mode_full_size_step_within_tolerance(name):
         assert (sf[k].cpu() - ofst.P[k].detach()).abs().max().item() <= 2.2 * cfg.flow.lr + 1e-6, k
 
 
+@pytest.mark.timeout(1800)
+def test_bf16_mode_loss_curve_tracks_fp32_oracle():
+    """Drift over several steps in bf16 compute mode: EIGHT consecutive optimisation steps of the full-size
+    vp/CIFAR10/indm_nll networks with the MFMA inputs rounded to bf16, against the fp32 CPU oracle stepping its own fp32
+    weights on the same batches and noise.  Stated tolerance: the batch-mean loss of every step within 1 % of the oracle's,
+    every per-image loss within 4 % (+1e-2) -- the weights of the two runs differ by then by what 8 AdamW steps of
+    bf16-rounded gradients produce, so this bounds the accumulated effect, not a single step's rounding."""
+    from indm_amd import hip
+    torch.manual_seed(21)
+    np.random.seed(21)
+    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+    cfg.model.dropout = 0.0
+    cfg.training.batch_size = 2
+    dev = torch.device("cuda")
+    cfg.device = dev
+    score = utils.create_model(cfg, dev)
+    fl = create_flow_model(cfg).to(dev)
+    with torch.no_grad():
+        for n, p in score.named_parameters():
+            if p.dim() > 1 and p.abs().max() < 1e-6:
+                p.copy_(torch.randn_like(p) * 0.02)
+    sd_s = {k: v.cpu() for k, v in score.reference_state_dict(prefix="").items()}
+    sd_f = {k: v.cpu() for k, v in fl.reference_state_dict(prefix="").items()}
+    ost = O.OracleState(sd_s, cfg.optim.lr, cfg.model.ema_rate, cfg)
+    ofst = O.OracleState(sd_f, cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg.compute_dtype = "bf16"
+    worst_mean, worst_img = 0.0, 0.0
+    try:
+        state, fstate, _ = utils.build_states(cfg, score, fl, dev)
+        step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+        assert hip.compute_dtype() == "bf16"
+        score.train(); fl.train()
+        for it in range(8):
+            x = torch.rand(2, 3, 32, 32) * 2 - 1
+            rec = RecordingRng()
+            want = O.flow_step_fn_nll(cfg, O.get_sde(cfg), ost, ofst, x, rec)
+            rng = ReplayRng(rec.events, dev)
+            got = step_fn(state, fstate, x.to(dev), rng=rng)
+            assert rng.done()
+            a, b = got[0].double(), want[0].double()
+            assert torch.isfinite(a).all()
+            rel_mean = abs(float(a.mean() - b.mean())) / abs(float(b.mean()))
+            err_img = float(((a - b).abs() / (b.abs() + 0.25)).max())
+            worst_mean, worst_img = max(worst_mean, rel_mean), max(worst_img, err_img)
+            assert rel_mean <= 1e-2, (it, rel_mean, a, b)
+            assert err_img <= 4e-2, (it, err_img, a, b)
+    finally:
+        hip.set_compute_dtype("f32")
+    print(f"bf16 loss curve over 8 steps: worst batch-mean deviation {worst_mean:.2e}, worst per-image {worst_img:.2e}")
+
+
 @pytest.mark.timeout(1500)
 def test_bf16_mode_nelbo_relative_tolerance():
     """NELBO bits/dim of the full-size VP model in bf16 compute mode vs the fp32 CPU oracle on the same noise.  Stated
