@@ -16,6 +16,9 @@
 //   * XCD-aware tile order: the N-tiles that share an A row-panel land on one XCD's L2
 //   * optional split-K into a caller-provided workspace (deterministic reduce kernel)
 #include "indm_common.h"
+// the direct-to-LDS copy helpers write M0 from inline asm and say so in their clobber lists (M0 is a reserved register:
+// hipcc warns about the clobber, which is exactly the declaration its M0-initialisation merging needs to see)
+#pragma clang diagnostic ignored "-Winline-asm"
 #include "igemm_thin.h"
 #include <type_traits>
 #include <cstdlib>
@@ -1000,7 +1003,7 @@ __device__ __forceinline__ f32x2 pk_mul_f32(f32x2 a, f32x2 b) { return a * b; }
 // s_waitcnt vmcnt + barriers, exactly as they order the builtin.
 __device__ __forceinline__ void dma_saddr(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 // The same copy through a raw BUFFER resource (`buffer_load_dwordx4 voffset, s[rsrc], soffset offen lds`, gfx950):
 // address = resource base + soffset (SGPR: the slab's uniform tap offset) + the lane's fixed 32-bit offset, and a lane
@@ -1010,7 +1013,7 @@ __device__ __forceinline__ void dma_saddr(unsigned lds_byte_addr, unsigned voff,
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma_buffer(unsigned lds_byte_addr, unsigned voff, i32x4 rsrc, unsigned soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+               :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;

@@ -18,6 +18,9 @@
 // 256 x 128 tile (A + gate rows + B rows = 640 either way), A and its gate are read exactly once from HBM, W2T
 // (1 MB) stays in L2.  Saves, per iteration at batch 128: the 268 MB write, the 536 MB gated re-read and one launch.
 #include "indm_common.h"
+// the direct-to-LDS copy helpers write M0 from inline asm and say so in their clobber lists (M0 is a reserved register:
+// hipcc warns about the clobber, which is exactly the declaration its M0-initialisation merging needs to see)
+#pragma clang diagnostic ignored "-Winline-asm"
 
 namespace {
 
@@ -50,7 +53,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int IMM>
 __device__ __forceinline__ void dma_s(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
-               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase), "n"(IMM) : "memory", "m0");
 }
 // four copies 1 KB apart in global memory and in LDS: one M0 value, one address, four immediates (ONE asm statement: nothing
 // can come between the M0 write and its readers)
@@ -58,12 +61,12 @@ __device__ __forceinline__ void dma_s_x4(unsigned lds_byte_addr, unsigned voff, 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
-               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 __device__ __forceinline__ void dma_s_x2(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024"
-               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory");
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;

@@ -266,6 +266,238 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ---- fused single-pass GroupNorm (round 3) ---------------------------------------------------------------------------
+// The three-kernel passes above read x twice (stats, apply) and, in the backward, dy and x twice: 12 / 20 bytes per
+// element.  When one image's slab of a few adjacent groups -- CS = 12 or 16 channels x HW pixels -- fits the registers
+// of one workgroup (<= 16 float4 per thread: every map of the 32 x 32 configurations), ONE workgroup per (image, group
+// block) keeps the slab in registers between the reduction and the apply: 8 / 12 bytes per element, one launch
+// forward, one launch + a [N, C] column reduce backward.  Threads walk the slab in 16-byte chunks (a pixel's CS
+// channels are one 48- or 64-byte segment); blockDim is a multiple of CS4 = CS / 4, so a thread keeps its channel quad.
+// Same formulas as the three-kernel path (sum / sum-of-squares statistics; dropout mask from (seed, flat float4 index)).
+constexpr int GNF_MAXG = 8;   // groups per workgroup (GS <= 4 in practice)
+
+// 1-D grid, XCD-aware: the hardware deals workgroup b to XCD b % 8; the group blocks of ONE image share 128-byte lines
+// (a pixel's C channels are contiguous), so all of them go to the same XCD's L2: b -> (n, gb) with n % 8 == b % 8
+__device__ __forceinline__ void gnf_decode(int b, int GB, int N, int& n, int& gb) {
+  const int full = (N / 8) * 8 * GB;          // images beyond the last multiple of 8 keep the plain order
+  if (b < full) {
+    const int xcd = b & 7, t = b >> 3;
+    gb = t % GB;
+    n = (t / GB) * 8 + xcd;
+  } else {
+    const int r = b - full;
+    n = (N / 8) * 8 + r / GB;
+    gb = r % GB;
+  }
+}
+
+template <int NF4>
+__global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int N, int HW,
+                                                            int C, int G, int GS, float eps, int act, float drop_p,
+                                                            uint64_t seed) {
+  __shared__ float sh[2 * 256];
+  __shared__ float st[2 * GNF_MAXG];
+  const int bs = blockDim.x, tid = threadIdx.x;
+  int n, gb;
+  gnf_decode(blockIdx.x, G / GS, N, n, gb);
+  const int cpg = C / G, CS = GS * cpg, CS4 = CS >> 2, C4 = C >> 2;
+  const int q = tid % CS4;                       // this thread's channel quad inside the slab (bs % CS4 == 0)
+  const int gl = (q * 4) / cpg;                  // ... and its group inside the block
+  const int total = HW * CS4;
+  const long img4 = (long)n * HW * C4;           // float4 index of the image
+  const int c4_0 = gb * CS4;
+  float4 v[NF4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int f = tid + k * bs;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < total) {
+      const int pix = f / CS4;
+      v[k] = *(const float4*)(x + (img4 + (long)pix * C4 + c4_0 + q) * 4);
+      s1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      s2 += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+  }
+  sh[tid] = s1;
+  sh[256 + tid] = s2;
+  __syncthreads();
+  if (tid < GS) {   // fixed-order sum over the threads of this group (its cpg / 4 channel quads): deterministic
+    float a = 0.f, b = 0.f;
+    for (int qq = tid * (cpg >> 2); qq < (tid + 1) * (cpg >> 2); ++qq)
+      for (int t = qq; t < bs; t += CS4) { a += sh[t]; b += sh[256 + t]; }
+    const float inv_cnt = 1.f / ((float)HW * (float)cpg);
+    const float m = a * inv_cnt;
+    float var = b * inv_cnt - m * m;
+    var = fmaxf(var, 0.f);
+    const float r = rsqrtf(var + eps);
+    st[tid] = m;
+    st[GNF_MAXG + tid] = r;
+    mean[n * G + gb * GS + tid] = m;
+    rstd[n * G + gb * GS + tid] = r;
+  }
+  __syncthreads();
+  const float m = st[gl], r = st[GNF_MAXG + gl];
+  const float4 gm = *(const float4*)(gamma + (c4_0 + q) * 4);
+  const float4 bt = *(const float4*)(beta + (c4_0 + q) * 4);
+  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int f = tid + k * bs;
+    if (f < total) {
+      const int pix = f / CS4;
+      const long i4 = img4 + (long)pix * C4 + c4_0 + q;
+      const float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      float out[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = (in[j] - m) * r * gmv[j] + btv[j];
+        if (act == 1) u = silu_f(u);
+        if (drop_p > 0.f) u *= dropout_keep(seed, (uint64_t)i4, j, drop_p);
+        out[j] = u;
+      }
+      *(float4*)(y + i4 * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+  }
+}
+
+template <int NF4>
+__global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ dx, float* __restrict__ cpart, int N, int HW,
+                                                            int C, int G, int GS, int act, float drop_p, uint64_t seed) {
+  __shared__ float sh[8 * 256];           // per-thread channel partials: [j (4: sum d, 4: sum d*xh)][thread]
+  __shared__ float chs[2 * 32];           // channel sums of the slab (CS <= 32)
+  __shared__ float gs_[2 * GNF_MAXG];     // group sums
+  const int bs = blockDim.x, tid = threadIdx.x;
+  int n, gb;
+  gnf_decode(blockIdx.x, G / GS, N, n, gb);
+  const int cpg = C / G, CS = GS * cpg, CS4 = CS >> 2, C4 = C >> 2;
+  const int q = tid % CS4, gl = (q * 4) / cpg;
+  const int total = HW * CS4;
+  const long img4 = (long)n * HW * C4;
+  const int c4_0 = gb * CS4;
+  const float4 gm = *(const float4*)(gamma + (c4_0 + q) * 4);
+  const float4 bt = *(const float4*)(beta + (c4_0 + q) * 4);
+  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+  const float m = mean[n * G + gb * GS + gl], r = rstd[n * G + gb * GS + gl];
+  float4 xh[NF4], dd[NF4];                 // normalised input and dL/du of this thread's chunks
+  float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int f = tid + k * bs;
+    xh[k] = dd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < total) {
+      const int pix = f / CS4;
+      const long i4 = img4 + (long)pix * C4 + c4_0 + q;
+      const float4 xv = *(const float4*)(x + i4 * 4);
+      const float4 dv = *(const float4*)(dy + i4 * 4);
+      const float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+      float h[4], d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = (xi[j] - m) * r;
+        d[j] = di[j];
+        if (drop_p > 0.f) d[j] *= dropout_keep(seed, (uint64_t)i4, j, drop_p);
+        if (act == 1) d[j] *= silu_grad(h[j] * gmv[j] + btv[j]);
+        a1[j] += d[j];
+        a2[j] += d[j] * h[j];
+      }
+      xh[k] = make_float4(h[0], h[1], h[2], h[3]);
+      dd[k] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sh[j * 256 + tid] = a1[j];
+    sh[(4 + j) * 256 + tid] = a2[j];
+  }
+  __syncthreads();
+  if (tid < CS) {   // channel sums of the slab, fixed order over the threads that own the channel's quad
+    const int cq = tid >> 2, cj = tid & 3;
+    float a = 0.f, b = 0.f;
+    for (int t = cq; t < bs; t += CS4) { a += sh[cj * 256 + t]; b += sh[(4 + cj) * 256 + t]; }
+    chs[tid] = a;
+    chs[32 + tid] = b;
+    cpart[(long)n * 2 * C + gb * CS + tid] = a;          // dbeta partial of image n
+    cpart[(long)n * 2 * C + C + gb * CS + tid] = b;      // dgamma partial
+  }
+  __syncthreads();
+  if (tid < GS) {
+    float a = 0.f, b = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+      const float g = gamma[gb * CS + c];
+      a += chs[c] * g;
+      b += chs[32 + c] * g;
+    }
+    gs_[tid] = a;
+    gs_[GNF_MAXG + tid] = b;
+  }
+  __syncthreads();
+  const float inv_cnt = 1.f / ((float)HW * (float)cpg);
+  const float s1 = gs_[gl] * inv_cnt, s2 = gs_[GNF_MAXG + gl] * inv_cnt;
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int f = tid + k * bs;
+    if (f < total) {
+      const int pix = f / CS4;
+      const long i4 = img4 + (long)pix * C4 + c4_0 + q;
+      const float h[4] = {xh[k].x, xh[k].y, xh[k].z, xh[k].w}, d[4] = {dd[k].x, dd[k].y, dd[k].z, dd[k].w};
+      float out[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] = r * (gmv[j] * d[j] - s1 - h[j] * s2);
+      *(float4*)(dx + i4 * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+  }
+}
+
+// dbeta[c] = sum_n cpart[n][c], dgamma[c] = sum_n cpart[n][C + c]: one wavefront per channel (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void gn_cpart_reduce_kernel(const float* __restrict__ cpart, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int N, int C) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float db = 0.f, dg = 0.f;
+  for (int n = lane; n < N; n += 64) {
+    db += cpart[(long)n * 2 * C + c];
+    dg += cpart[(long)n * 2 * C + C + c];
+  }
+  db = wave_sum(db);
+  dg = wave_sum(dg);
+  if (lane == 0) {
+    dbeta[c] = db;
+    dgamma[c] = dg;
+  }
+}
+
+// geometry of the fused path: groups per workgroup, threads, float4 chunks per thread (0 = not covered)
+struct GnFused { int gs, bs, nf4; };
+static GnFused gn_fused_geom(int HW, int C, int G) {
+  GnFused f = {0, 0, 0};
+  const int cpg = C / G;
+  if (cpg < 4 || (cpg & 3)) return f;
+  int gs = cpg >= 12 ? 1 : (16 / cpg);
+  while (gs > 1 && (G % gs)) gs >>= 1;
+  // small maps (8 x 8, 4 x 4): wider group blocks -- up to 32 channels = one 128-byte line per pixel -- so that a workgroup
+  // has at least ~1024 chunks of work and the grid is not thousands of near-empty workgroups
+  while ((long)HW * (gs * cpg / 4) < 1024 && 2 * gs * cpg <= 32 && 2 * gs <= GNF_MAXG && (G % (2 * gs)) == 0) gs *= 2;
+  const int cs4 = gs * cpg / 4;
+  if (gs > GNF_MAXG || gs * cpg > 32 || (cs4 != 1 && cs4 != 2 && cs4 != 3 && cs4 != 4 && cs4 != 6 && cs4 != 8)) return f;
+  const long total = (long)HW * cs4;
+  const bool three = (cs4 % 3) == 0;                   // blockDim must be a multiple of cs4
+  int bs = three ? 192 : 256;
+  if (total <= 64) bs = three ? 48 : 64;               // 4 x 4 maps: one wavefront
+  else if (total <= 128) bs = three ? 96 : 128;
+  const int need = (int)((total + bs - 1) / bs);
+  const int nf4 = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 0;
+  if (!nf4) return f;
+  f.gs = gs; f.bs = bs; f.nf4 = nf4;
+  return f;
+}
+
 // ---- softmax over the last dim (T <= 1024), one wavefront per row -------------------
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                            long rows, int T, float scale) {
@@ -487,6 +719,22 @@ INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const fl
   if (N <= 0) return INDM_OK;
   if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / 4) > 256) return INDM_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const GnFused ff = gn_fused_geom(HW, C, G);
+  if (ff.nf4) {   // single pass: one workgroup per (image, group block) keeps its slab in registers
+    const dim3 grid((G / ff.gs) * N), block(ff.bs);
+#define GNF_FWD(NF) hipLaunchKernelGGL(gn_fused_fwd_kernel<NF>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, N, HW, C, G, \
+                                       ff.gs, eps, act, drop_p, (uint64_t)seed)
+    switch (ff.nf4) {
+      case 1: GNF_FWD(1); break;
+      case 2: GNF_FWD(2); break;
+      case 4: GNF_FWD(4); break;
+      case 8: GNF_FWD(8); break;
+      default: GNF_FWD(16); break;
+    }
+#undef GNF_FWD
+    INDM_CHECK_LAUNCH();
+    return INDM_OK;
+  }
   const int S = gn_split(N, HW);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(S, N), dim3(256), 2 * (256 / (C / 4)) * C * sizeof(float), st, x, ws, HW, C, G, S);
   INDM_CHECK_LAUNCH();
@@ -508,6 +756,24 @@ INDM_API int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float
   if (N <= 0) return INDM_OK;
   if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / 4) > 256) return INDM_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const GnFused ff = gn_fused_geom(HW, C, G);
+  if (ff.nf4) {   // single pass over dy and x + a [N, C] column reduce for dgamma / dbeta
+    const dim3 grid((G / ff.gs) * N), block(ff.bs);
+#define GNF_BWD(NF) hipLaunchKernelGGL(gn_fused_bwd_kernel<NF>, grid, block, 0, st, dy, x, gamma, beta, mean, rstd, dx, ws, N, HW, \
+                                       C, G, ff.gs, act, drop_p, (uint64_t)seed)
+    switch (ff.nf4) {
+      case 1: GNF_BWD(1); break;
+      case 2: GNF_BWD(2); break;
+      case 4: GNF_BWD(4); break;
+      case 8: GNF_BWD(8); break;
+      default: GNF_BWD(16); break;
+    }
+#undef GNF_BWD
+    INDM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_cpart_reduce_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, dgamma, dbeta, N, C);
+    INDM_CHECK_LAUNCH();
+    return INDM_OK;
+  }
   const int S = gn_split(N, HW);
   float* gpart = ws;
   float* cpart = gpart + (long)N * S * 2 * G;

@@ -320,7 +320,12 @@ def test_conv2d_wgrad_big_tile(N, H, Ci, Co, k, s, p):
 
 
 @pytest.mark.parametrize("N,HW,C", [(2, (32, 32), 128), (3, (16, 16), 256), (2, (16, 16), 384), (2, (4, 4), 512),
-                                    (4, (8, 8), 16), (2, (16, 16), 64)])
+                                    (4, (8, 8), 16), (2, (16, 16), 64),
+                                    # fused single-pass geometries and their edges: 12-channel groups at 32^2 (192 threads,
+                                    # 16 chunks per thread), 8-channel groups, a 6-group net (group block of 2), a slab that
+                                    # does not fill the workgroup, and 64^2 (too large for the fused path: three-kernel form)
+                                    (2, (32, 32), 384), (2, (32, 32), 256), (3, (8, 8), 24), (2, (2, 2), 128),
+                                    (1, (64, 64), 128), (5, (32, 32), 512)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_groupnorm(N, HW, C, act):
     G = min(C // 4, 32)
