@@ -6,6 +6,7 @@
 //            A tile is fetched as ONE contiguous run, the whole reduction sits in LDS at once, and the accumulators go
 //            back through LDS so that every store instruction writes two full 512-byte rows (float4 per lane).
 #include "igemm_thin.h"
+#pragma clang diagnostic ignored "-Winline-asm"   // M0 clobber declared on the copy helper (see igemm.hip)
 
 namespace {
 template <bool ON>
@@ -633,6 +634,136 @@ __global__ void thin_wgrad_reduce(const float* __restrict__ ws, float* __restric
   else out[(long)t * ldo + c] = v;
 }
 
+// ---- direct-to-LDS form of the thin weight grad (round 3) ---------------------------------------------------------
+// thin_wgrad_kernel above stages its operands through registers: per 32-pixel slab a thread stores 16 thin elements with
+// scalar LDS writes and carried (pixel, t) counters, multiplies the gate in, writes the wide rows -- about five non-MFMA
+// VALU instructions per MFMA on a part where those do not overlap with the MFMAs: 4.0 - 4.3 TB/s on a
+// launch that only has to stream 268 / 536 MB.  Here every operand goes global -> LDS by `global_load_lds_dwordx4
+// voffset, s[base]` copies: the wide (and gate) rows as a [32 pixels][128 columns] image, the thin slab as the flat
+// 128 T bytes it is in memory ([pixel][T], row stride T: fragment reads at t >= T pick up the next pixel's values, which
+// only reach output rows t >= T that are never stored).  The gate is multiplied at the fragment read.
+constexpr int TD_BK = 32;
+__device__ __forceinline__ void td_dma(unsigned lds_byte_addr, unsigned voff, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :: "s"(lds_byte_addr), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned td_lds(const float* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int TP, bool HAS_G, bool BF16 = false>
+__global__ __launch_bounds__(256, 2) void thin_wgrad_dma_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
+                                                                 const float* __restrict__ gate, float* __restrict__ ws, int T,
+                                                                 int N, long ldw, int chunk, int P) {
+  constexpr int RM = TP == 32 ? 1 : 2, RN = TP == 32 ? 1 : 2;
+  extern __shared__ __attribute__((aligned(16))) float td_smem[];
+  // per buffer: wide [32][128], gate [32][128] (gated), thin [32 T] (+ TP floats of slack for the t >= T reads)
+  const int thin_floats = ((TD_BK * T + TP + 3) & ~3);
+  const int buf_floats = TD_BK * 128 * (HAS_G ? 2 : 1) + thin_floats;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n0 = blockIdx.x * 128;
+  const int p_beg = blockIdx.y * chunk, p_end = min(P, p_beg + chunk);
+  const int nslab = (p_end - p_beg) / TD_BK;
+  const int mw = TP == 32 ? 0 : (wave >> 1) * 64, nw = TP == 32 ? wave * 32 : (wave & 1) * 64;
+
+  // copies of one slab: wide / gate rows 8 w .. 8 w + 7 of the slab (two 512-byte row pieces per instruction), and this
+  // wave's share of the thin slab's 16-byte chunks
+  const unsigned w_voff = (unsigned)((lane >> 5) * ldw * 4 + (lane & 31) * 16);
+  const char* w_ub = (const char*)(wide + (long)(p_beg + 8 * wave) * ldw + n0);
+  const char* g_ub = HAS_G ? (const char*)(gate + (long)(p_beg + 8 * wave) * ldw + n0) : nullptr;
+  const long w_step = (long)TD_BK * ldw * 4, w_pair = 2 * ldw * 4;
+  const int tchunks = (TD_BK * T) >> 2;                       // 16-byte chunks of a thin slab (128 T bytes)
+  const int tinstr = (tchunks + 63) >> 6;                     // wave-instructions to copy it
+  const char* t_ub = (const char*)(thin + (long)p_beg * T);
+  const long t_step = (long)TD_BK * T * 4;
+  auto stage = [&](int buf) {
+    float* base = td_smem + buf * buf_floats;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      td_dma(__builtin_amdgcn_readfirstlane(td_lds(base + (8 * wave + 2 * i) * 128)), w_voff, w_ub + i * w_pair);
+      if constexpr (HAS_G)
+        td_dma(__builtin_amdgcn_readfirstlane(td_lds(base + TD_BK * 128 + (8 * wave + 2 * i) * 128)), w_voff, g_ub + i * w_pair);
+    }
+    float* tb = base + TD_BK * 128 * (HAS_G ? 2 : 1);
+    for (int i = wave; i < tinstr; i += 4) {
+      const int c = i * 64 + lane;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(td_lds(tb + i * 256));   // wave-uniform: keep it scalar for M0
+      if (c < tchunks) td_dma(dst, (unsigned)(c * 16), t_ub);
+    }
+    w_ub += w_step;
+    if constexpr (HAS_G) g_ub += w_step;
+    t_ub += t_step;
+  };
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nslab > 0) stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int buf = sl & 1;
+    if (sl + 1 < nslab) stage(buf ^ 1);
+    const float* bw = td_smem + buf * buf_floats + nw + l31;
+    const float* af = td_smem + buf * buf_floats + TD_BK * 128 * (HAS_G ? 2 : 1) + mw + l31;
+#pragma unroll
+    for (int kk = 0; kk < TD_BK / 2; ++kk) {
+      const int k = 2 * kk + lhi;
+      float a[RM], b[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) a[i] = rb16<BF16>(af[k * T + i * 32]);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        float v = bw[k * 128 + j * 32];
+        if constexpr (HAS_G) v *= bw[TD_BK * 128 + k * 128 + j * 32];
+        b[j] = rb16<BF16>(v);
+      }
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  float* out = ws + (long)blockIdx.y * T * N;
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int c = n0 + nw + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int t = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (t < T && c < N) out[(long)t * N + c] = acc[i][j][r];
+      }
+    }
+}
+
+template <int TP, bool HAS_G, bool BF16>
+int launch_thin_wgrad_dma(const float* thin, const float* wide, const float* gate, float* ws, int T, int N, long ldw, int chunk,
+                          int P, dim3 grid, hipStream_t st) {
+  const int thin_floats = ((TD_BK * T + TP + 3) & ~3);
+  const size_t bytes = 2 * (size_t)(TD_BK * 128 * (HAS_G ? 2 : 1) + thin_floats) * sizeof(float);
+  static size_t ready = 0;  // > 64 KB of LDS needs the opt-in (per instantiation; T changes the size)
+  if (bytes > ready) {
+    if (hipFuncSetAttribute((const void*)thin_wgrad_dma_kernel<TP, HAS_G, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+      return INDM_E_LAUNCH;
+    ready = bytes;
+  }
+  hipLaunchKernelGGL((thin_wgrad_dma_kernel<TP, HAS_G, BF16>), grid, dim3(256), bytes, st, thin, wide, gate, ws, T, N, ldw, chunk, P);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
 // thin: [P, T] contiguous; wide (+gate): [P, N] with row stride ldw; out: [T, N] (ldo) or, transposed, [N, T] (ldo)
 int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, float* out, int T, int N, long P, long ldw,
                       float alpha, int transpose, long ldo, float* ws, long ws_floats, hipStream_t st, int bf16) {
@@ -645,6 +776,23 @@ int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, f
   S = cdiv(P, chunk);
   if (S * T * N > ws_floats || S > 65535) return THIN_NA;
   dim3 grid(tiles_n, (unsigned)S);
+  // direct-to-LDS form for the UNGATED launches: full 128-column tiles, 16-byte aligned rows (every production shape).
+  // Measured at M = 131072 / 32768 (kernel + reduce): 77 -> 69 us and 65 -> 57 us ungated; the gated form reads three LDS
+  // words per MFMA at two workgroups per CU and ran 119 / 73 us against 114 / 68 us register-staged, so it stays there.
+  if (!gate && !(N & 127) && !(ldw & 3) && (long)P * ldw * 4 < (1L << 32) && (long)P * T * 4 < (1L << 32)) {
+    int r;
+    if (T <= 32) r = gate ? (bf16 ? launch_thin_wgrad_dma<32, true, true>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st)
+                                  : launch_thin_wgrad_dma<32, true, false>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st))
+                         : (bf16 ? launch_thin_wgrad_dma<32, false, true>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st)
+                                  : launch_thin_wgrad_dma<32, false, false>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st));
+    else r = gate ? (bf16 ? launch_thin_wgrad_dma<128, true, true>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st)
+                          : launch_thin_wgrad_dma<128, true, false>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st))
+                  : (bf16 ? launch_thin_wgrad_dma<128, false, true>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st)
+                          : launch_thin_wgrad_dma<128, false, false>(thin, wide, gate, ws, T, N, ldw, chunk, (int)P, grid, st));
+    if (r != INDM_OK) return r;
+    hipLaunchKernelGGL(thin_wgrad_reduce, dim3(cdiv((long)T * N, 256)), dim3(256), 0, st, ws, out, (int)S, T, N, alpha, transpose, ldo);
+    return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+  }
   if (T <= 32) {
     if (gate) { if (bf16) hipLaunchKernelGGL((thin_wgrad_kernel<32, true, true>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P);
       else hipLaunchKernelGGL((thin_wgrad_kernel<32, true, false>), grid, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, chunk, (int)P); }

@@ -9,6 +9,10 @@
 //   bit 4: the copies share ONE address register and M0 value (instruction offsets 0 / 1024 / 2048 / 3072 / 4096 bytes)
 //   bit 5: wait with vmcnt(5): only for the PREVIOUS slab's copies (a three-buffer rotation)
 //   bit 6: gate multiplies as 2-wide packed math
+//   bit 8: TILES of 32 slabs: after every 32nd slab the 64 accumulators of a lane are stored to HBM (a 256 x 128 fp32 tile per
+//          workgroup, 16 dword stores of 128-byte rows per lane and block) and cleared, and the next tile's first copy is NOT
+//          in flight yet (its latency is exposed, as in a kernel launched per tile)
+//   bit 9: with bit 8: the next tile's first slab is requested during the last slab of the current one (persistent kernel)
 //   bit 7: five copies with five DIFFERENT source rows (as the 256 x 128 tile kernels need), addressed as
 //          `voffset, s[base:base+1]` through inline asm: per-lane offsets fixed, the uniform bases advance on the scalar unit
 // build: hipcc --offload-arch=gfx950 -O3 -o mfma_model mfma_model.hip      run: ./mfma_model
@@ -39,8 +43,17 @@ __global__ __launch_bounds__(512, 4) void model(const float* __restrict__ src, f
   for (int i = tid; i < 2 * BUF; i += 512) smem[i] = 1.0f + (i & 15) * 0.01f;
   __syncthreads();
   const float* ps = src + ((long)blockIdx.x * 512 + tid) * 4;
+  // the workgroup's [256][128] fp32 tile image: wave (wm, wn) owns rows 64 wm.., columns 64 wn..; a store instruction writes
+  // two 128-byte row segments (lanes 0-31 / 32-63), as the kernels' epilogue does
+  float* tile_out = out + 64 + (long)blockIdx.x * 256 * 128 + ((wave >> 1) * 64 + 4 * (lane >> 5)) * 128 + (wave & 1) * 64 + (lane & 31);
   for (int s = 0; s < nslab; ++s) {
     const int buf = s & 1;
+    if constexpr ((F & 8) && (F & 256)) {
+      if (!(F & 512) && (s & 31) == 0 && s > 0) {   // tile start without prefetch: this slab's copy was not issued ahead
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
     if constexpr (F & 8) {
       float* dst = smem + (buf ^ 1) * BUF + wave * 1280;   // 5 x 1 KB per wave
       if constexpr (F & 128) {
@@ -106,6 +119,22 @@ __global__ __launch_bounds__(512, 4) void model(const float* __restrict__ src, f
     if constexpr ((F & 8) && (F & 32)) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (F & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (F & 2) __syncthreads();
+    if constexpr (F & 256) {
+      if ((s & 31) == 31) {   // tile epilogue: 4 blocks x 16 row stores per lane, then clear
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            tile_out[((i >> 1) * 32 + 8 * (j >> 2) + (j & 3)) * 128 + (i & 1) * 32] = acc[i][j];
+            acc[i][j] = 0.f;
+          }
+        if constexpr (!(F & 512)) {   // per-tile launch: the next tile's first copy starts only now
+          if constexpr (F & 8) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+      }
+    }
   }
   float r = 0.f;
 #pragma unroll
@@ -140,7 +169,7 @@ int main() {
   const int blocks = 2 * p.multiProcessorCount, nslab = 128;   // 4 tiles' worth of 32 slabs per workgroup
   float *src, *out;
   const size_t n = ((size_t)blocks * 512 * 4 + (size_t)nslab * 16 + 5 * 2048 + 64);
-  CK(hipMalloc(&src, n * 4)); CK(hipMemset(src, 0, n * 4)); CK(hipMalloc(&out, 64));
+  CK(hipMalloc(&src, n * 4)); CK(hipMemset(src, 0, n * 4)); CK(hipMalloc(&out, (size_t)(64 + (size_t)blocks * 256 * 128 + 4096) * 4));
   run<0>("MFMA only (8 waves/WG, 2 WG/CU, 32 MFMA/slab)", src, out, blocks, nslab);
   run<1>("+ 40 VALU per slab", src, out, blocks, nslab);
   run<2>("+ barrier per slab", src, out, blocks, nslab);
@@ -157,6 +186,8 @@ int main() {
   run<14 + 16 + 32 + 64>("real loop, all three", src, out, blocks, nslab);
   run<14 + 128>("real loop, five distinct rows through `voffset, s[base]` asm copies", src, out, blocks, nslab);
   run<8 + 2 + 128>("copies (asm saddr form) + vmcnt(0) + barrier", src, out, blocks, nslab);
+  run<14 + 128 + 256>("real loop (asm copies) in TILES of 32 slabs: stores + exposed first copy", src, out, blocks, nslab);
+  run<14 + 128 + 256 + 512>("same, next tile's first slab prefetched (persistent)", src, out, blocks, nslab);
   run<8 + 16>("copies only (instruction offsets) + vmcnt(0)", src, out, blocks, nslab);
   run<8 + 2 + 16 + 32>("copies (instruction offsets) + vmcnt(5) + barrier", src, out, blocks, nslab);
   return 0;
