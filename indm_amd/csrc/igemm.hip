@@ -1029,7 +1029,9 @@ __device__ __attribute__((aligned(16))) float indm_zero16[4] = {0.f, 0.f, 0.f, 0
 // bijection (lane-half, position) -> k is valid for an MFMA as long as both operands use the same one.)
 template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
-  static_assert(AM == A_ROW || AM == A_CONV || AM == A_COL, "A_ROW / A_CONV: k-contiguous; A_COL: row-contiguous");
+  static_assert(AM == A_ROW || AM == A_CONV || AM == A_COL || AM == A_WGRAD,
+                "A_ROW / A_CONV: k-contiguous; A_COL / A_WGRAD: row-contiguous ([16 k][256 m] image)");
+  constexpr bool A_RC = (AM == A_COL || AM == A_WGRAD);   // row-contiguous A image
   static_assert(BK == 16, "written for 16-deep slabs");
   // NW = 4: waves 2 x 2 of 128 x 64;  NW = 8: waves 4 x 2 of 64 x 64 (four waves per SIMD with two blocks per CU)
   constexpr int TM = 256, TN = 128, WM = (NW == 8 ? 64 : 128), WN = 64, RM = WM / 32, RN = 2;
@@ -1134,6 +1136,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     for (int q = 0; q < 16 / NW; ++q)
       aoff[q] = ((unsigned)(wave * (16 / NW) + q) * (unsigned)p.lda + (unsigned)(min(m0 + 4 * lane, p.M - 4) - m0)) * 4u;
   }
+  // A_WGRAD (round 3): weight-gradient gather A[m = (tap, ci)][k = output pixel] = x[pixel shifted by tap][ci] as a
+  // [16 k][256 m] image.  One k-row is one copy instruction: the pixel's top-left input offset is wave-uniform (soffset of a
+  // buffer copy, scalar arithmetic), the lane's (tap, ci) offset never changes, and a lane whose tap falls into the padding
+  // for this pixel sets bit 31 of its offset and copies zeros (see dma_buffer).  Needs OW and OH*OW powers of two, Cin % 4 == 0.
+  unsigned wg_voff = 0;
+  int wg_kh = 0, wg_kw = 0;
+  bool wg_dead = false;
+  i32x4 wrsrc = {0, 0, 0, 0};
+  if constexpr (AM == A_WGRAD) {
+    const long shift = ((long)p.pad * p.W + p.pad) * p.Cin;
+    const unsigned long long ab = (unsigned long long)(A - shift);
+    wrsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(ab & 0xffffffffu));
+    wrsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((ab >> 32) & 0xffffu));
+    wrsrc[2] = __builtin_amdgcn_readfirstlane((int)(((long)(p.K >> p.ohw_sh) * p.H * p.W * p.Cin + shift) * 4));
+    wrsrc[3] = 0x00020000;
+    const int m = m0 + 4 * lane;                      // this lane's four rows (tap, ci .. ci + 3): one 16-byte chunk
+    wg_dead = m >= p.M;
+    const int tap = min(m, p.M - 4) / p.Cin, ci = min(m, p.M - 4) - tap * p.Cin;
+    wg_kh = tap / p.KW;
+    wg_kw = tap - wg_kh * p.KW;
+    wg_voff = (unsigned)((((long)wg_kh * p.W + wg_kw) * p.Cin + ci) * 4);
+  }
   if constexpr (BMODE == B_COL) {
     ub = (const char*)(B + (long)n0 * p.ldb + kbeg);
 #pragma unroll
@@ -1186,6 +1210,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         const int kr = wave * (16 / NW) + q;
         dma_saddr(lds_byte_addr(base + kr * TM), aoff[q], ua);
         if constexpr (HAS_G) dma_saddr(lds_byte_addr(base + A_SZ + kr * TM), aoff[q], ug);
+      } else if constexpr (AM == A_WGRAD) {
+        const int kr = wave * (16 / NW) + q;
+        const int kp = k0 + kr;                                        // output pixel of this k-row (wave-uniform)
+        const int img = kp >> p.ohw_sh, rem = kp & ((1 << p.ohw_sh) - 1);
+        const int ih0w = (rem >> p.ow_sh) * p.stride - p.pad, iw0w = (rem & ((1 << p.ow_sh) - 1)) * p.stride - p.pad;
+        // (the host checked that the whole input + the shift stays below 2 GB: 32-bit scalar arithmetic)
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(
+            (((img * p.H + ih0w) * p.W + iw0w) * p.Cin + (p.pad * p.W + p.pad) * p.Cin) * 4);
+        const bool bad = wg_dead || (unsigned)(ih0w + wg_kh) >= (unsigned)p.H || (unsigned)(iw0w + wg_kw) >= (unsigned)p.W;
+        dma_buffer(lds_byte_addr(base + kr * TM), bad ? 0x80000000u : wg_voff, wrsrc, soff);
       } else if (p.a_buf) {     // block-uniform branch: buffer form, see dma_buffer
         const unsigned oob = (cbad[q] << (31 - tap_idx)) & 0x80000000u;
         dma_buffer(lds_byte_addr(base + r0 * BK), cvoff[q] | oob, arsrc, (unsigned)(tap_off * 4));
@@ -1241,7 +1275,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     const int ch = ((sg * 2 + lhi) ^ swz) << 2;
 #pragma unroll
     for (int i = 0; i < RM; ++i) {
-      if constexpr (AM == A_COL) {  // [16 k][256 m]: k = 8 sg + 4 lhi + t, rows of TM floats
+      if constexpr (A_RC) {  // [16 k][256 m]: k = 8 sg + 4 lhi + t, rows of TM floats
         const float* q = as + (sg * 8 + lhi * 4) * TM + mw + i * 32 + l31;
         float4 v = make_float4(q[0], q[TM], q[2 * TM], q[3 * TM]);
         if constexpr (HAS_G) {
@@ -1308,7 +1342,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
         for (int i = 0; i < RM; ++i) {
           const float* as = glds_smem + buf * BUF;
           float4 lo, hi;
-          if constexpr (AM == A_COL) {
+          if constexpr (A_RC) {
             const float* q = as + (lhi * 4) * TM + mw + i * 32 + l31;
             lo = make_float4(q[0], q[TM], q[2 * TM], q[3 * TM]);
             hi = make_float4(q[8 * TM], q[9 * TM], q[10 * TM], q[11 * TM]);
@@ -1510,6 +1544,11 @@ inline int big_tile_n(const IgemmParams& p) {
   return 0;
 }
 
+static bool wgrad_glds_enabled() {
+  static const int v = getenv("INDM_WGRAD_GLDS") ? atoi(getenv("INDM_WGRAD_GLDS")) : 1;
+  return v != 0;
+}
+
 template <int AM, int BMODE>
 int launch_tiles(const IgemmParams& p, hipStream_t st) {
   // tile choice: skinny N (flow 3/12-channel edges, last score conv) -> 128x32;
@@ -1677,6 +1716,19 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
         return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
       }
     }
+  }
+  if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 64 && !(p.N & 3) && p.M >= 256 &&
+      !(p.Cin & 3) && p.ow_sh >= 0 && p.ohw_sh >= 0 && p.dil == 1 && p.K >= 1024 &&
+      ((long)(p.K >> p.ohw_sh) * p.H * p.W + (long)p.pad * (p.W + 1)) * p.Cin * 4 < (1L << 31) && wgrad_glds_enabled()) {
+    // convolution weight grads on the direct-to-LDS kernel (round 3, A_WGRAD image): 256 x 128 tiles, split-K over the
+    // output pixels so that every CU gets its two workgroups, chunks of at least 8 slabs
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
+    long want = 512 / tiles;
+    if (want < 1) want = 1;
+    while (want > 1 && (p.K / want < 8 * BK || want * p.M * p.N > ws_floats)) --want;
+    p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
+    p.splitk = cdiv(p.K, p.kps);
+    return launch_glds<A_WGRAD, B_ROW, false, 8>(p, st);
   }
   if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 128 && p.M >= 256 &&
       (p.K >= 16384 || (p.K >= 8192 && p.M >= 4096))) {  // (8x8 maps: 512-channel inputs only -- measured 245 -> 192 us)

@@ -89,13 +89,14 @@ def test_wgrad_gemm_big256x256():
         _check(out[rows.to(DEV)], ag.t() @ dc.double(), M, "wgrad GEMM big256x256" + (" gated" if gate is not None else ""))
 
 
-def test_conv_wgrad_big256x256():
-    """3x3 weight grad of a 16x16 256->256 score-net conv at batch 128 (A_WGRAD, big tiles + split-K): 8 input channels
-    x all taps x all output channels in fp64"""
+def test_conv_wgrad_production_variant():
+    """3x3 weight grad of a 16x16 256->256 score-net conv at batch 128 (A_WGRAD; round 3: the direct-to-LDS kernel's
+    [16 k][256 m] weight-gradient image + split-K, before that big tiles + split-K): 8 input channels x all taps x all
+    output channels in fp64"""
     Nb, hw, ci, co = 128, 16, 256, 256
     x, dy = _rnd(Nb, hw, hw, ci, seed=10), _rnd(Nb, hw, hw, co, seed=11)
     dw = hip.conv2d_wgrad(x.to(DEV), dy.to(DEV), 3, 3)
-    assert _variant() in ("big256x256", "big256x128"), _variant()
+    assert _variant() in ("glds256x128,splitk", "big256x256", "big256x128"), _variant()
     sub = [0, 3, 64, 127, 128, 200, 254, 255]
     want = torch.nn.grad.conv2d_weight(x[..., sub].permute(0, 3, 1, 2).double(), (co, len(sub), 3, 3),
                                        dy.permute(0, 3, 1, 2).double(), padding=1)       # [co, sub, 3, 3]
