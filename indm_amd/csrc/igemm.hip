@@ -1717,6 +1717,19 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
       }
     }
   }
+  if (am == A_COL && bm == B_ROW && ws && !p.bf16 && p.batch == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.K >= 16384 &&
+      p.M >= 256 && p.N >= 128 && !(p.M & 3) && !(p.N & 3) && wgrad_glds_enabled()) {
+    // fp32 weight-grad GEMMs that are too small for the big tile (e.g. the attention NIN grads [256, 32768]^T x [32768, 256]):
+    // the direct-to-LDS kernel's row-contiguous A image with split-K instead of the generic 128 x 128 tile (round 3;
+    // 72.9 -> 63.4 us; shorter K or 128-row outputs measured slower and stay on the generic tile)
+    const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
+    long want = 512 / tiles;
+    if (want < 1) want = 1;
+    while (want > 1 && (p.K / want < 8 * BK || want * p.M * p.N > ws_floats)) --want;
+    p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
+    p.splitk = cdiv(p.K, p.kps);
+    return p.G ? launch_glds<A_COL, B_ROW, true, 8>(p, st) : launch_glds<A_COL, B_ROW, false, 8>(p, st);
+  }
   if (am == A_WGRAD && bm == B_ROW && ws && p.a_vec && p.b_vec && !(p.K & 15) && p.N >= 64 && !(p.N & 3) && p.M >= 256 &&
       !(p.Cin & 3) && p.ow_sh >= 0 && p.ohw_sh >= 0 && p.dil == 1 && p.K >= 1024 &&
       ((long)(p.K >> p.ohw_sh) * p.H * p.W + (long)p.pad * (p.W + 1)) * p.Cin * 4 < (1L << 31) && wgrad_glds_enabled()) {
