@@ -1565,10 +1565,10 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     }
   }
   if constexpr (AM == A_CONV && (BMODE == B_ROW || BMODE == B_DGRAD)) {
-    // long convolutions (forward and data-grad): the same direct-to-LDS kernel on the implicit-GEMM A operand;
-    // data-grads that fill 256 x 256 tiles stay on the big-tile kernel (118-123 TF)
-    const bool big256 = BMODE == B_DGRAD && p.a_tap_uniform && p.b_tap_uniform && big_tile_n(p) == 256;
-    if ((!big256 || p.bf16) && !p.G && p.splitk == 1 && p.a_vec && p.b_vec && p.a_tap_uniform &&
+    // long convolutions (forward and data-grad): the same direct-to-LDS kernel on the implicit-GEMM A operand.
+    // (Round 2 kept the data-grads that fill 256 x 256 tiles on the big-tile kernel, 118-123 TF; with the buffer-addressed
+    // copies of round 3 the 8-wave kernel is ahead there too: 16x16 512->256 630 -> 576 us, 32x32 256->128 684 -> 605 us.)
+    if (!p.G && p.splitk == 1 && p.a_vec && p.b_vec && p.a_tap_uniform &&
         (BMODE == B_ROW ? !(p.N & 3) : p.b_tap_uniform != 0) && p.M >= 1024 && p.N >= 64 &&
         (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224)
       return launch_glds<A_CONV, BMODE, false, 8>(p, st);
