@@ -57,8 +57,9 @@ __global__ void rowreduce_final_kernel(const float* __restrict__ part, float* __
 }
 
 // Lop normalisation over RSCK weight viewed as [R, Co]: per-column L1 norm.  grid (Co/64, RB): each workgroup
-// owns 64 columns x one row-block (4 row lanes inside) and adds its partial with ONE atomic per column.
-// (<= 16 partials per column; fp32 add order may vary by 1 ulp between runs.)
+// owns 64 columns x one row-block (4 row lanes inside).  The hosts below launch ONE row-block (gridDim.y == 1): the add
+// onto the zeroed column is then exact and the result has a fixed summation order (the training path normalises all
+// weights through lop_multi_*; this single-weight form serves stand-alone InducedNormConv2d calls).
 __global__ __launch_bounds__(256) void lop_colnorm_kernel(const float* __restrict__ w, float* __restrict__ l1, int R,
                                                           int Co) {
   __shared__ float sh[4][64];
@@ -509,7 +510,7 @@ INDM_API int indm_weightnorm_bwd_f32(const float* dw, const float* v, const floa
 INDM_API int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, int R, int Co, float coeff,
                                         void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const int RB = R >= 1024 ? 16 : (R >= 64 ? 4 : 1);  // row-blocks: more workgroups for tall, skinny weights
+  const int RB = 1;  // one row-block per column group: fixed summation order
   if (hipMemsetAsync(l1, 0, sizeof(float) * Co, st) != hipSuccess) return INDM_E_LAUNCH;
   hipLaunchKernelGGL(lop_colnorm_kernel, dim3(cdiv(Co, 64), RB), dim3(256), 0, st, w, l1, R, Co);
   INDM_CHECK_LAUNCH();
@@ -522,7 +523,7 @@ INDM_API int indm_lop_normalize_fwd_f32(const float* w, float* wn, float* l1, in
 INDM_API int indm_lop_normalize_bwd_f32(const float* dwn, const float* w, const float* l1, float* dw, float* dot,
                                         int R, int Co, float coeff, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const int RB = R >= 1024 ? 16 : (R >= 64 ? 4 : 1);
+  const int RB = 1;
   if (hipMemsetAsync(dot, 0, sizeof(float) * Co, st) != hipSuccess) return INDM_E_LAUNCH;
   hipLaunchKernelGGL(lop_coldot_kernel, dim3(cdiv(Co, 64), RB), dim3(256), 0, st, dwn, w, dot, R, Co);
   INDM_CHECK_LAUNCH();

@@ -99,7 +99,7 @@ struct Ctx {
 // (p = [M, Cw] scratch for the two pre-activations, Pn = [M, 9C] scratch).  want_d = 0: gates are not produced.
 static int g_pass(const Ctx& c, int preact, const float* x, const float* cb, const float* W1, const float* W2T,
                   const float* W3ct, const float* b1, const float* b2, const float* b3, float* a0, float* d0, float* a1,
-                  float* d1, float* a2, float* d2, float* p, float* Pn, float* g) {
+                  float* d1, float* a2, float* d2, float* p, float* Pn, float* g, float* y_res = nullptr) {
   const long nC = c.M * c.C, nW = c.M * c.Cw;
   const float* in = x;
   if (preact) {
@@ -111,7 +111,10 @@ static int g_pass(const Ctx& c, int preact, const float* x, const float* cb, con
   TRY(c.gemm(a1, nullptr, W2T, p, (int)c.M, c.Cw, c.Cw, 0, 1, c.Cw, c.Cw, b2, cb, c.H * c.W));   // p2 = a1 W2 + b2 + cb[n]
   TRY(indm_sincos_act_fwd_f32(p, a2, d2, nW, c.st));
   TRY(c.gemm(a2, nullptr, W3ct, Pn, (int)c.M, 9 * c.C, c.Cw, 0, 0, c.Cw, 9 * c.C, nullptr, nullptr, 1));   // skinny-output conv: GEMM + 9-tap gather
-  TRY(indm_tap_gather_f32(Pn, b3, g, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
+  if (y_res)   // the block's output y = x + g in the gather's own pass (x + 1.0f * g: the same sum axpby would form)
+    TRY(indm_tap_gather_acc_f32(Pn, b3, nullptr, g, x, y_res, 1.0f, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
+  else
+    TRY(indm_tap_gather_f32(Pn, b3, g, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
   return 0;
 }
 
@@ -181,8 +184,8 @@ INDM_API int indm_iresblock_fwd_logdet(const indm_iresblock_fwd_args* a, void* s
   if (!p || !Pn || !g || !v || !rws || (!a->training && (!a1 || !t3 || (a->preact && !d0)))) return INDM_E_ARG;
   const int K = a->ncoeff;
 
-  TRY(g_pass(c, a->preact, a->x, a->cb, a->W1, a->W2T, a->W3_ci_tapco, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2, p, Pn, g));
-  TRY(indm_axpby_f32(a->x, g, a->y, 1.0f, 1.0f, 0.0f, nC, stream));                  // y = x + g
+  TRY(g_pass(c, a->preact, a->x, a->cb, a->W1, a->W2T, a->W3_ci_tapco, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2, p, Pn, g,
+             a->y));                                                                // ... and y = x + g
   const float* gate0 = a->preact ? d0 : nullptr;
 
   if (a->training) {

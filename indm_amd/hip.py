@@ -185,13 +185,21 @@ def to_device(t, device):
 _ws_cache = {}
 
 
+POISON_WS = {"on": os.environ.get("INDM_POISON_WS", "0") == "1"}
+
+
 def _ws(nfloats, device):
-    """Grow-only scratch buffer per device (stream-ordered reuse)."""
+    """Grow-only scratch buffer per device (stream-ordered reuse).  Every kernel pair that goes through it (partials +
+    reduce) must write what it reads: the buffer holds whatever the previous op left.  POISON_WS (env INDM_POISON_WS=1)
+    fills the buffer with NaN on every request -- a debugging mode in which a read of stale scratch turns
+    the result into NaN instead of a run-to-run difference in the last bits (tests/test_properties_gpu.py)."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(int(nfloats), 1 << 22), dtype=torch.float32, device=device)
         _ws_cache[key] = buf
+    if POISON_WS["on"]:
+        buf.fill_(float("nan"))   # the whole buffer: a kernel reading past the extent it asked for is a bug as well
     return buf
 
 

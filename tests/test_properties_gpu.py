@@ -219,16 +219,46 @@ def test_training_is_bit_reproducible(dtype):
         score.train(); flow.train()
         rng = DeviceRng(dev, seed=21, poisson_seed=22)
         g = torch.Generator().manual_seed(23)
-        outs = []
+        rec = []
         for _ in range(3):
             x = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(dev)
-            outs.append(torch.stack(step_fn(state, fstate, x, rng=rng)))
-        torch.cuda.synchronize()
-        return torch.stack(outs), state["optimizer"].flat.p.clone(), fstate["optimizer"].flat.p.clone()
+            out = torch.stack(step_fn(state, fstate, x, rng=rng))
+            torch.cuda.synchronize()
+            # the flat gradient buffers still hold this step's gradients: kept so that a failure names the first
+            # parameter whose gradient differed, not just "the losses differ"
+            rec.append({"loss": out, "score grad": state["optimizer"].flat.g.clone(),
+                        "flow grad": fstate["optimizer"].flat.g.clone(),
+                        "score params": state["optimizer"].flat.p.clone(),
+                        "flow params": fstate["optimizer"].flat.p.clone()})
+        names = {}
+        for key, st in (("score grad", state), ("flow grad", fstate)):
+            o, lst = 0, []
+            for n, p in st["optimizer"].flat.named:
+                lst.append((n, o, p.numel()))
+                o += (p.numel() + 3) // 4 * 4
+            names[key] = lst
+        return rec, names
+
+    def first_difference(a, b, names):
+        for s in range(3):
+            for key in a[s]:
+                x, y = a[s][key], b[s][key]
+                if not torch.equal(x, y):
+                    msg = f"step {s}: {key} differs, max |d| {(x - y).abs().max().item():.3e}"
+                    if key == "loss":
+                        msg += f", rows {sorted(set((x != y).nonzero()[:, 0].tolist()))} of (total, score, flow, logp)"
+                    if key in names:
+                        d = x != y
+                        hit = [(n, int(d[o:o + k].sum()), k) for n, o, k in names[key] if d[o:o + k].any()]
+                        same = [n for n, o, k in names[key] if not d[o:o + k].any()]
+                        msg += (f"; {len(hit)} of {len(names[key])} parameters differ (name, differing, numel): {hit[:8]} ... "
+                                f"{hit[-8:]}; identical: {same[:40]}")
+                    return msg
+        return None
 
     try:
-        a, b = run(), run()
+        (a, names), (b, _) = run(), run()
     finally:
         hip.set_compute_dtype("f32")
-    assert torch.equal(a[0], b[0]), (a[0] - b[0]).abs().max()
-    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    diff = first_difference(a, b, names)
+    assert diff is None, diff
