@@ -188,11 +188,7 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
     with torch.no_grad():
         x = st.rng.randn_image(batch, 3, cfg.data.image_size, cfg.data.image_size)
         ts = torch.linspace(sde.T, cfg.sampling.truncation_time, 1000)
-        rows = []
-        for i in range(steps + 2):
-            vt = torch.ones(batch) * ts[i]
-            rows.append(torch.stack([sde.model_labels(vt).float()] + [v.float() for v in st.em_coeffs(vt)]))
-        table = torch.stack(rows).to(dev)
+        table = sampling.predictor_table(st, "euler_maruyama", ts[:steps + 2], batch).to(dev)
         for mode in ("graph", "eager"):
             gp = sampling._GraphedPredictor(st, x, table, use_graph=(mode == "graph"))
             gp.step(0); gp.step(1)

@@ -270,6 +270,28 @@ int indm_affine_update_f32(const float* x, const float* s, const float* z, const
 /* Langevin step size from batch-mean norms, sampling.py:284-288 */
 int indm_langevin_step_f32(const float* grad_sq, const float* noise_sq, const float* alpha, float* step,
                            float* noise_coef, int B, float snr, void* stream);
+/* ---- block-level sampler / likelihood entry points (csrc/pc_step.hip): one call = one reference update_fn after the
+ * score network ran.  x, net_out, z, x_new, x_mean: [B, D] fp32, D % 4 == 0, 16-byte aligned; f_lin, g|G, k, alpha: [B].
+ * Noise: explicit z XOR the device-resident Philox state {seed, offset} of indm_philox_randn_f32 (drawn inside the update
+ * kernel with the same counter -> value map and advanced by B D / 4); both NULL only for a probability-flow step. */
+/* EulerMaruyamaPredictor.update_fn sampling.py:191-197 with RSDE.sde sde_lib.py:96-103; forward drift f = f_lin x,
+ * diffusion g, score = k net_out (models/utils.py:167-177), dt = -1 / N */
+int indm_pc_step_em_f32(const float* x, const float* net_out, const float* f_lin, const float* g, const float* k,
+                        double dt, int probability_flow, const float* z, void* philox, float* x_new, float* x_mean,
+                        long B, long D, void* stream);
+/* ReverseDiffusionPredictor.update_fn sampling.py:205-210 with RSDE.discretize sde_lib.py:105-118; discretised forward
+ * step f = f_lin x, G */
+int indm_pc_step_rd_f32(const float* x, const float* net_out, const float* f_lin, const float* G, const float* k,
+                        int probability_flow, const float* z, void* philox, float* x_new, float* x_mean, long B, long D,
+                        void* stream);
+/* LangevinCorrector.update_fn, one iteration, sampling.py:279-290 (batch-mean norms :286-288) */
+long indm_pc_step_ws_floats(long B, long D);
+int indm_pc_step_langevin_f32(const float* x, const float* net_out, const float* k, const float* alpha, float snr,
+                              const float* z, void* philox, float* x_new, float* x_mean, float* ws, long B, long D,
+                              void* stream);
+/* get_div_fn likelihood.py:27-38: div[b] = sum_i grad_fn_eps[b,i] eps[b,i] (Hutchinson) */
+long indm_hutch_div_ws_floats(long B, long D);
+int indm_hutch_div_f32(const float* grad_fn_eps, const float* eps, float* div, long B, long D, float* ws, void* stream);
 /* sum g^2 -> device scalar (torch.nn.utils.clip_grad_norm_, losses.py:58-59) */
 long indm_sqnorm_ws_floats(void);
 int indm_sqnorm_f32(const float* g, long n, float* out, float* ws, void* stream);

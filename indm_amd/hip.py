@@ -94,6 +94,12 @@ _SIGS = {
     "indm_dsm_loss_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_p],
     "indm_affine_update_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
     "indm_langevin_step_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p],
+    "indm_pc_step_em_f32": [c_p, c_p, c_p, c_p, c_p, ctypes.c_double, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
+    "indm_pc_step_rd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
+    "indm_pc_step_langevin_f32": [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
+    "indm_hutch_div_f32": [c_p, c_p, c_p, c_l, c_l, c_p, c_p],
+    "indm_pc_step_ws_floats": [c_l, c_l],
+    "indm_hutch_div_ws_floats": [c_l, c_l],
     "indm_sqnorm_ws_floats": [],
     "indm_sqnorm_f32": [c_p, c_l, c_p, c_p, c_p],
     "indm_adamw_ema_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p, c_f, c_f, c_p],
@@ -119,7 +125,8 @@ _SIGS = {
     "indm_timer_read": [c_p, c_p, c_p, c_p],
 }
 _LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_segreduce_ws_floats", "indm_rowreduce_ws_floats",
-             "indm_dsm_ws_floats", "indm_sqnorm_ws_floats", "indm_ires_bwd_act_ws_floats", "indm_iresblock_ws_floats"}
+             "indm_dsm_ws_floats", "indm_sqnorm_ws_floats", "indm_ires_bwd_act_ws_floats", "indm_iresblock_ws_floats",
+             "indm_pc_step_ws_floats", "indm_hutch_div_ws_floats"}
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 
@@ -1083,6 +1090,62 @@ def langevin_step(grad_sq, noise_sq, alpha, snr):
     _chk(lib().indm_langevin_step_f32(_ptr(grad_sq), _ptr(noise_sq), _ptr(alpha), _ptr(step), _ptr(ncoef),
                                       grad_sq.numel(), snr, _stream()), "indm_langevin_step_f32")
     return step, ncoef
+
+
+def _noise_args(z, philox):
+    """(z pointer, Philox state pointer) of a sampler update: exactly one noise source (None, None = no noise)"""
+    if z is not None and philox is not None:
+        raise RuntimeError("pc_step: pass z or philox, not both")
+    if philox is not None and (not philox.is_cuda or philox.dtype != torch.int64):
+        raise RuntimeError("pc_step: philox must be an int64[2] tensor on the GPU")
+    return _ptr(z), (philox.data_ptr() if philox is not None else None)
+
+
+def pc_step_em(x, net_out, f_lin, g, k, dt, probability_flow=False, z=None, philox=None, want_mean=True):
+    """EulerMaruyamaPredictor.update_fn (sampling.py:191-197 with RSDE.sde sde_lib.py:96-103) -> (x_new, x_mean).
+    f_lin, g, k: [B] device vectors (forward drift f = f_lin x, diffusion, score = k net_out); noise from z or drawn
+    inside the kernel from the device Philox state."""
+    B = x.shape[0]
+    x_new, x_mean = torch.empty_like(x), (torch.empty_like(x) if want_mean else None)
+    zp, pp = _noise_args(z, philox)
+    _chk(lib().indm_pc_step_em_f32(_ptr(x), _ptr(net_out), _ptr(f_lin), _ptr(g), _ptr(k), float(dt),
+                                   int(bool(probability_flow)), zp, pp, _ptr(x_new), _ptr(x_mean), B, x.numel() // B,
+                                   _stream()), "indm_pc_step_em_f32")
+    return x_new, x_mean
+
+
+def pc_step_rd(x, net_out, f_lin, G, k, probability_flow=False, z=None, philox=None, want_mean=True):
+    """ReverseDiffusionPredictor.update_fn (sampling.py:205-210 with RSDE.discretize sde_lib.py:105-118)"""
+    B = x.shape[0]
+    x_new, x_mean = torch.empty_like(x), (torch.empty_like(x) if want_mean else None)
+    zp, pp = _noise_args(z, philox)
+    _chk(lib().indm_pc_step_rd_f32(_ptr(x), _ptr(net_out), _ptr(f_lin), _ptr(G), _ptr(k), int(bool(probability_flow)),
+                                   zp, pp, _ptr(x_new), _ptr(x_mean), B, x.numel() // B, _stream()),
+         "indm_pc_step_rd_f32")
+    return x_new, x_mean
+
+
+def pc_step_langevin(x, net_out, k, alpha, snr, z=None, philox=None):
+    """One LangevinCorrector iteration (sampling.py:279-290) -> (x_new, x_mean)"""
+    B = x.shape[0]
+    D = x.numel() // B
+    x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
+    ws = _ws(lib().indm_pc_step_ws_floats(B, D), x.device)
+    zp, pp = _noise_args(z, philox)
+    _chk(lib().indm_pc_step_langevin_f32(_ptr(x), _ptr(net_out), _ptr(k), _ptr(alpha), float(snr), zp, pp, _ptr(x_new),
+                                         _ptr(x_mean), _ptr(ws), B, D, _stream()), "indm_pc_step_langevin_f32")
+    return x_new, x_mean
+
+
+def hutch_div(grad_fn_eps, eps):
+    """Hutchinson divergence estimate (likelihood.py:27-38): [B] = sum over the image of grad_fn_eps * eps"""
+    B = eps.shape[0]
+    D = eps.numel() // B
+    div = torch.empty((B,), dtype=torch.float32, device=eps.device)
+    ws = _ws(lib().indm_hutch_div_ws_floats(B, D), eps.device)
+    _chk(lib().indm_hutch_div_f32(_ptr(grad_fn_eps), _ptr(eps), _ptr(div), B, D, _ptr(ws), _stream()),
+         "indm_hutch_div_f32")
+    return div
 
 
 def sqnorm(g):

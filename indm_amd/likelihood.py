@@ -90,7 +90,7 @@ def get_elbo_fn(config, sde, inverse_scaler=None, hutchinson_type="Rademacher"):
             c_x = -(std ** 2) / (g ** 2) * fcoef
             # <mu, eps> = sum c_out*out*eps + c_x*x*eps  ->  d/dx gives c_out * J^T eps + c_x * eps
             (vjp,) = torch.autograd.grad(out, xt, ops.scale_rows(epsilon, _d(c_out, xt)).detach())
-        tr = hip.rowreduce(vjp.contiguous(), epsilon, 0).cpu() + c_x * hip.rowreduce(epsilon, None, 1).cpu()
+        tr = hip.hutch_div(vjp.contiguous(), epsilon).cpu() + c_x * hip.rowreduce(epsilon, None, 1).cpu()
         Mu = -tr * Z / qt
         a_sq = hip.rowreduce(out.detach(), None, 1).cpu() * (std * k) ** 2
         Nu = -a_sq * Z / 2 / qt
@@ -124,8 +124,8 @@ def get_div_fn(stepper, sde, on_device=False):
             (vjp,) = torch.autograd.grad(out, xg, ops.scale_rows(epsilon, _d(b, xg)).detach())
         drift = hip.affine_update(x, out.detach(), None, _d(a, x), _d(b, x), _d(b, x), want_mean=False)[0]
         if on_device:
-            return drift, hip.rowreduce(vjp.contiguous(), epsilon, 0) + _d(a, x) * hip.rowreduce(epsilon, None, 1)
-        div = hip.rowreduce(vjp.contiguous(), epsilon, 0).cpu() + a * hip.rowreduce(epsilon, None, 1).cpu()
+            return drift, hip.hutch_div(vjp.contiguous(), epsilon) + _d(a, x) * hip.rowreduce(epsilon, None, 1)
+        div = hip.hutch_div(vjp.contiguous(), epsilon).cpu() + a * hip.rowreduce(epsilon, None, 1).cpu()
         return drift, div
 
     return drift_div

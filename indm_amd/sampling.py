@@ -38,45 +38,48 @@ class _Stepper:
         out = self.net(x, labels.to(x.device), nhwc=True)
         return out, self.score_factor(t)
 
-    def em_coeffs(self, t):
-        """EulerMaruyamaPredictor.update_fn sampling.py:191-197 with RSDE.sde sde_lib.py:96-103 as per-image
-        coefficients of  x' = a x + b net_out + c z  ([B] host vectors)."""
+    def em_terms(self, t):
+        """The reference's quantities of EulerMaruyamaPredictor.update_fn (sampling.py:191-197, RSDE.sde
+        sde_lib.py:96-103) as [B] host vectors: forward drift f = f_lin x, diffusion g, score = k net_out."""
         sde = self.sde
-        dt = -1.0 / sde.N
-        g = sde.diffusion(t)
-        if self.vp:
-            a = 1.0 + (-0.5 * sde.beta_t(t)) * dt
-        else:
-            a = torch.ones_like(t)
-        return a, -(g ** 2) * self.score_factor(t) * dt, g * np.sqrt(-dt)
+        f_lin = -0.5 * sde.beta_t(t) if self.vp else torch.zeros_like(t)
+        return f_lin, sde.diffusion(t), self.score_factor(t)
 
-    def rd_coeffs(self, t, next_t=None, probability_flow=False):
-        """ReverseDiffusionPredictor.update_fn sampling.py:205-210 with RSDE.discretize sde_lib.py:105-118"""
+    def rd_terms(self, t, next_t=None):
+        """ReverseDiffusionPredictor.update_fn (sampling.py:205-210, RSDE.discretize sde_lib.py:105-118): discretised
+        forward step f = f_lin x, G; and the denoising step to next_t <= 0 of this repo's reference (sampling.py:402-408)"""
         sde = self.sde
-        pf = 0.5 if probability_flow else 1.0
         if next_t is None or next_t[0].item() > 0:
             a_f, G = sde.discretize_coeffs(t, next_t)      # f = (a_f - 1) x
-            a = 2.0 - a_f                                   # x - f
+            f_lin = a_f - 1.0
         else:
-            a = torch.ones_like(t)
+            f_lin = torch.zeros_like(t)
             G = sde.diffusion(t) * torch.sqrt(t - next_t)
-        return a, (G ** 2) * self.score_factor(t) * pf, (torch.zeros_like(G) if probability_flow else G)
+        return f_lin, G, self.score_factor(t)
 
     def score_factor(self, t):
         """k[b] with score = k * raw network output (models/utils.py:167-177)"""
         return -1.0 / self.sde.marginal_coeffs(t)[1] if self.ddpm else torch.ones_like(t)
 
+    def _noise(self, x):
+        """-> (z, philox): the device-resident Philox state when the source has one (the update kernel draws the noise
+        itself), else an explicit tensor from the source (replayed / CPU-generated noise)"""
+        ph = getattr(self.rng, "philox", None)
+        if ph is not None and x.is_cuda:
+            return None, ph
+        return self.rng.randn_image(*_nchw(x)), None
+
     def em(self, x, t):
         out, _ = self.net_out(x, t)
-        a, b, c = self.em_coeffs(t)
-        z = self.rng.randn_image(*_nchw(x))
-        return hip.affine_update(x, out, z, _d(a, x), _d(b, x), _d(c, x))
+        f_lin, g, k = self.em_terms(t)
+        z, ph = self._noise(x)
+        return hip.pc_step_em(x, out, _d(f_lin, x), _d(g, x), _d(k, x), -1.0 / self.sde.N, False, z, ph)
 
     def rd(self, x, t, next_t=None, probability_flow=False):
         out, _ = self.net_out(x, t)
-        a, b, c = self.rd_coeffs(t, next_t, probability_flow)
-        z = self.rng.randn_image(*_nchw(x))
-        return hip.affine_update(x, out, z, _d(a, x), _d(b, x), _d(c, x))
+        f_lin, G, k = self.rd_terms(t, next_t)
+        z, ph = self._noise(x)   # drawn (and discarded, G = 0) by the reference's probability-flow step too
+        return hip.pc_step_rd(x, out, _d(f_lin, x), _d(G, x), _d(k, x), probability_flow, z, ph)
 
     def langevin(self, x, t, snr, n_steps):
         """LangevinCorrector.update_fn sampling.py:272-292"""
@@ -89,16 +92,24 @@ class _Stepper:
         x_mean = x
         for _ in range(n_steps):
             out, k = self.net_out(x, t)
-            grad = out if not self.ddpm else hip.scale_rows(out, _d(k, x))
-            noise = self.rng.randn_image(*_nchw(x))
-            gsq, nsq = hip.rowreduce(grad, None, 1), hip.rowreduce(noise, None, 1)
-            step, ncoef = hip.langevin_step(gsq, nsq, alpha, float(snr))
-            x, x_mean = hip.affine_update(x, grad, noise, torch.ones_like(step), step, ncoef)
+            z, ph = self._noise(x)
+            x, x_mean = hip.pc_step_langevin(x, out, _d(k, x), alpha, float(snr), z, ph)
         return x, x_mean
 
 
+def predictor_table(st, predictor, timesteps, B):
+    """Everything the predictor steps need from the host, for ALL steps, as one [steps, 4, B] tensor: network labels and
+    the three per-image vectors of the update (f_lin, g | G, k)."""
+    rows = []
+    for tt in timesteps:
+        vec_t = torch.ones(B) * tt
+        terms = st.em_terms(vec_t) if predictor == "euler_maruyama" else st.rd_terms(vec_t, None)
+        rows.append(torch.stack([st.sde.model_labels(vec_t).float()] + [v.float() for v in terms]))
+    return torch.stack(rows)
+
+
 class _GraphedPredictor:
-    """The predictor-only sampler step (score network forward + Philox noise + fused affine update) captured ONCE as a
+    """The predictor-only sampler step (score network forward + one indm_pc_step_* launch that draws its own Philox noise) captured ONCE as a
     hipGraph and replayed for every step: its launch sequence is static (unlike the training step, whose Poisson
     series lengths change per block per step).  Everything a step needs from the host -- network labels and the three
     coefficient vectors -- is precomputed for ALL steps into one device table [steps, 4, B]; a replay is preceded only
@@ -107,8 +118,9 @@ class _GraphedPredictor:
     launch advances itself.  The first step runs eagerly (it readies workspaces / kernel attributes), the second is
     captured, all later ones are replays: the kernels and their order are exactly the eager path's."""
 
-    def __init__(self, st, x, table, use_graph=True):
+    def __init__(self, st, x, table, use_graph=True, predictor="euler_maruyama", probability_flow=False):
         self.st, self.table, self.use_graph = st, table, use_graph
+        self.predictor, self.pf = predictor, probability_flow
         self.x = x.clone()
         self.row = torch.empty_like(table[0])
         self.graph, self.x_mean, self.steps_done = None, None, 0
@@ -116,8 +128,12 @@ class _GraphedPredictor:
 
     def _body(self):
         out = self.st.net(self.x, self.row[0], nhwc=True)
-        z = self.st.rng.randn_image(*_nchw(self.x))
-        x_new, self.x_mean = hip.affine_update(self.x, out, z, self.row[1], self.row[2], self.row[3])
+        ph = self.st.rng.philox
+        if self.predictor == "euler_maruyama":
+            x_new, self.x_mean = hip.pc_step_em(self.x, out, self.row[1], self.row[2], self.row[3], -1.0 / self.st.sde.N,
+                                                False, None, ph)
+        else:
+            x_new, self.x_mean = hip.pc_step_rd(self.x, out, self.row[1], self.row[2], self.row[3], self.pf, None, ph)
         self.x.copy_(x_new)
 
     def step(self, i):
@@ -205,13 +221,8 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
                 raise RuntimeError("pc_sampler(graph=True) needs a predictor-only sampler on the GPU with a DeviceRng")
             gp = None
             if graph:
-                rows = []
-                for i in range(num_scales):
-                    vec_t = torch.ones(B) * timesteps[i]
-                    abc = st.em_coeffs(vec_t) if predictor == "euler_maruyama" else st.rd_coeffs(vec_t, None,
-                                                                                                   probability_flow)
-                    rows.append(torch.stack([sde.model_labels(vec_t).float()] + [v.float() for v in abc]))
-                gp = _GraphedPredictor(st, x, torch.stack(rows).to(x.device))
+                gp = _GraphedPredictor(st, x, predictor_table(st, predictor, timesteps, B).to(x.device),
+                                       predictor=predictor, probability_flow=probability_flow)
             for i in range(num_scales):
                 vec_t = torch.ones(B) * timesteps[i]
                 if config.sampling.snr_scheduling == "none":

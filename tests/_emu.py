@@ -432,6 +432,47 @@ def sqnorm(g):
     return (g.double() ** 2).sum().float().reshape(1)
 
 
+def _need_z(z, philox):
+    assert philox is None, "the emulation has no device Philox state: pass the noise tensor"
+    return z
+
+
+def pc_step_em(x, net_out, f_lin, g, k, dt, probability_flow=False, z=None, philox=None, want_mean=True):
+    """sampling.py:191-197 with RSDE.sde sde_lib.py:96-103"""
+    z = _need_z(z, philox)
+    score = _b(k, x) * net_out
+    drift = _b(f_lin, x) * x - _b(g, x) ** 2 * score * (0.5 if probability_flow else 1.0)
+    m = x + drift * dt
+    xn = m if probability_flow else m + _b(g, x) * math.sqrt(-dt) * z
+    return xn, (m if want_mean else None)
+
+
+def pc_step_rd(x, net_out, f_lin, G, k, probability_flow=False, z=None, philox=None, want_mean=True):
+    """sampling.py:205-210 with RSDE.discretize sde_lib.py:105-118"""
+    z = _need_z(z, philox)
+    rev_f = _b(f_lin, x) * x - _b(G, x) ** 2 * (_b(k, x) * net_out) * (0.5 if probability_flow else 1.0)
+    m = x - rev_f
+    xn = m if probability_flow else m + _b(G, x) * z
+    return xn, (m if want_mean else None)
+
+
+def pc_step_langevin(x, net_out, k, alpha, snr, z=None, philox=None):
+    """sampling.py:279-290"""
+    z = _need_z(z, philox)
+    grad = _b(k, x) * net_out
+    B = x.shape[0]
+    gn = grad.reshape(B, -1).norm(dim=-1).mean()
+    nn_ = z.reshape(B, -1).norm(dim=-1).mean()
+    step = (snr * nn_ / gn) ** 2 * 2 * alpha
+    m = x + _b(step, x) * grad
+    return m + torch.sqrt(_b(step, x) * 2) * z, m
+
+
+def hutch_div(grad_fn_eps, eps):
+    """likelihood.py:27-38"""
+    return (grad_fn_eps * eps).reshape(eps.shape[0], -1).sum(1)
+
+
 def adamw_ema(p, g, m, v, ema, lr, beta1, beta2, eps, wd, step, clip, gnorm_sq, gscale, ema_one_minus_decay):
     coef = gscale
     if clip >= 0 and gnorm_sq is not None:

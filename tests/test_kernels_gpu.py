@@ -495,6 +495,67 @@ def test_sde_loss_sampler_kernels():
     close(nc, ncr, name="langevin coef")
 
 
+@pytest.mark.parametrize("shape", [(5, 32, 32, 3), (3, 64, 64, 3), (1, 8, 8, 4)])
+def test_pc_step_entry_points_match_the_reference_formulas(shape):
+    """indm_pc_step_{em,rd,langevin} / indm_hutch_div against the fp64 statement of the reference's update_fn
+    (tests/_emu.py: sampling.py:191-197, 205-210, 279-290; likelihood.py:27-38) with explicit noise"""
+    B = shape[0]
+    x, out, z = rnd(*shape), rnd(*shape, seed=1), rnd(*shape, seed=2)
+    f_lin, g, k = -rnd(B, seed=3).abs() * 5, rnd(B, seed=4).abs() + 0.3, -1.0 / (rnd(B, seed=5).abs() + 0.2)
+    for pf in (False, True):
+        (xn, xm), (xnr, xmr) = run_both("pc_step_em", x, out, f_lin, g, k, -1e-3, pf, z=z)
+        close(xn, xnr, rtol=1e-5, atol=1e-5, name=f"em new pf={pf}")
+        close(xm, xmr, rtol=1e-5, atol=1e-5, name=f"em mean pf={pf}")
+        (xn, xm), (xnr, xmr) = run_both("pc_step_rd", x, out, f_lin * 1e-3, g, k, pf, z=z)
+        close(xn, xnr, rtol=1e-5, atol=1e-5, name=f"rd new pf={pf}")
+        close(xm, xmr, rtol=1e-5, atol=1e-5, name=f"rd mean pf={pf}")
+    alpha = rnd(B, seed=6).abs() + 0.5
+    (xn, xm), (xnr, xmr) = run_both("pc_step_langevin", x, out, k, alpha, 0.16, z=z)
+    close(xn, xnr, rtol=2e-5, atol=1e-5, name="langevin new")
+    close(xm, xmr, rtol=2e-5, atol=1e-5, name="langevin mean")
+    d, dr = run_both("hutch_div", out, z)
+    close(d, dr, rtol=1e-5, atol=1e-3, name="hutch div")
+    # the composed op-level path (scale_rows + rowreduce + langevin_step + affine_update) gives the same update
+    xg, og, zg, kg = x.to(DEV), out.to(DEV), z.to(DEV), k.to(DEV)
+    grad = hip.scale_rows(og, kg)
+    step, ncoef = hip.langevin_step(hip.rowreduce(grad, None, 1), hip.rowreduce(zg, None, 1), alpha.to(DEV), 0.16)
+    cn, cm = hip.affine_update(xg, grad, zg, torch.ones_like(step), step, ncoef)
+    close(xn, cn.cpu(), rtol=1e-5, atol=1e-6, name="langevin vs composed")
+    close(xm, cm.cpu(), rtol=1e-5, atol=1e-6, name="langevin mean vs composed")
+
+
+def test_pc_step_draws_the_same_noise_as_philox_randn():
+    """noise drawn inside the update kernel == indm_philox_randn_f32 followed by the explicit-noise update, bit for
+    bit, and the device state advances by the same amount (probability-flow steps included)"""
+    shape, B = (6, 32, 32, 3), 6
+    x, out = rnd(*shape).to(DEV), rnd(*shape, seed=1).to(DEV)
+    f_lin, g, k = (-rnd(B, seed=3).abs()).to(DEV), (rnd(B, seed=4).abs() + 0.3).to(DEV), (-1.0 / (rnd(B, seed=5).abs() + 0.2)).to(DEV)
+    alpha = (rnd(B, seed=6).abs() + 0.5).to(DEV)
+
+    def state():
+        return hip.to_device(torch.tensor([12345, 7], dtype=torch.int64), torch.device(DEV))
+
+    calls = {
+        "em": lambda z, ph: hip.pc_step_em(x, out, f_lin, g, k, -1e-3, False, z, ph),
+        "rd": lambda z, ph: hip.pc_step_rd(x, out, f_lin * 1e-3, g, k, False, z, ph),
+        "rd_pf": lambda z, ph: hip.pc_step_rd(x, out, f_lin * 1e-3, g, k, True, z, ph),
+        "langevin": lambda z, ph: hip.pc_step_langevin(x, out, k, alpha, 0.16, z, ph),
+    }
+    for name, fn in calls.items():
+        s1, s2 = state(), state()
+        z = hip.philox_randn(shape, s1)
+        a_new, a_mean = fn(z, None)
+        b_new, b_mean = fn(None, s2)
+        assert torch.equal(a_new, b_new) and torch.equal(a_mean, b_mean), name
+        assert torch.equal(s1, s2) and int(s2[1]) == 7 + x.numel() // 4, (name, s1, s2)
+    with pytest.raises(RuntimeError):
+        hip.pc_step_em(x, out, f_lin, g, k, -1e-3, False, None, None)           # a stochastic step needs a noise source
+    with pytest.raises(RuntimeError):
+        hip.pc_step_em(x, out, f_lin, g, k, 1e-3, False, hip.philox_randn(shape, state()), None)   # dt must be < 0
+    with pytest.raises(RuntimeError):
+        hip.pc_step_langevin(x, out, k, alpha, 0.16, None, None)
+
+
 def test_optimizer_kernels():
     n = 100003
     p, g = rnd(n), rnd(n, seed=1) * 3
