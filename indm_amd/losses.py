@@ -102,8 +102,6 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
     def loss_fn(model, batch, st=False, recon_loss=None, importance_sampling=None, rng=None):
         if recon_loss is None:
             recon_loss = config.training.reconstruction_loss
-        if recon_loss:
-            raise NotImplementedError("reconstruction_loss is off in every shipped config")
         if importance_sampling is None:
             importance_sampling = config.training.importance_sampling
         rng = rng or default_rng(batch.device)
@@ -115,7 +113,8 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
         z = rng.randn_image(B, C, H, W)                                    # losses.py:103 (NHWC here)
         net = _unwrap(model)
         set_mode(net, train)
-        xt = ops.sde_perturb(ops.to_nhwc(batch), z, hip.to_device(mc, dev), hip.to_device(std, dev))
+        x_nhwc = ops.to_nhwc(batch)
+        xt = ops.sde_perturb(x_nhwc, z, hip.to_device(mc, dev), hip.to_device(std, dev))
         out = net(xt, hip.to_device(labels, dev), rng=rng, nhwc=True)
         if importance_sampling or not config.training.likelihood_weighting:
             w = (0.5 * Z) * torch.ones(B)
@@ -124,7 +123,28 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
             g2 = sde.diffusion(t) ** 2
             w = 0.5 * Z * g2
             mode = 1
-        return ops.dsm_loss(out, z, hip.to_device(std, dev), hip.to_device(w.float(), dev), kind, mode, reduce_mean)
+        losses = ops.dsm_loss(out, z, hip.to_device(std, dev), hip.to_device(w.float(), dev), kind, mode, reduce_mean)
+        if recon_loss:
+            # losses.py:120-140: a second network pass at t_min.  With perturbed = alpha x + beta z and
+            # q_mean = (perturbed + beta^2 score) / alpha:   x - q_mean = -(beta / alpha) (beta score + z),   so the
+            # squared-error sum IS the denoising sum of this pass and the whole term is one more fused DSM launch:
+            #   q_recon - p_entropy = n/2 (2 log q_std - 2 log beta - 1) + (beta / alpha)^2 / (2 q_std^2) * sum (beta score + z)^2
+            eps_vec = torch.ones(B) * t_min
+            alpha, beta, labels2 = _host_schedule(sde, eps_vec)
+            z2 = rng.randn_image(B, C, H, W)                               # losses.py:123
+            xt2 = ops.sde_perturb(x_nhwc, z2, hip.to_device(alpha, dev), hip.to_device(beta, dev))
+            out2 = net(xt2, hip.to_device(labels2, dev), rng=rng, nhwc=True)
+            a64, b64 = alpha.double(), beta.double()
+            q_std = b64 if variance == "ddpm" else b64 / a64
+            n_dim = float(C * H * W)
+            w2 = 0.5 * (b64 / a64) ** 2 / q_std ** 2
+            const = n_dim / 2.0 * (2.0 * torch.log(q_std) - 2.0 * torch.log(b64) - 1.0)
+            recon = ops.dsm_loss(out2, z2, hip.to_device(beta, dev), hip.to_device(w2.float(), dev), kind, 0, False)
+            recon = recon + hip.to_device(const.float(), dev)
+            if reduce_mean:
+                recon = recon / n_dim
+            losses = losses + recon
+        return losses
 
     return loss_fn
 

@@ -761,12 +761,23 @@ def flow_forward(P, cfg, x, log_det=0, reverse=False, training=False, rng=None, 
 
 
 # ----------------------------------------------------------------------------- losses / step functions
-def sde_loss(Ps, cfg, sde, batch, train, rng, recon_loss=False, importance_sampling=None):
-    """get_sde_loss_fn.loss_fn losses.py:83-142 (reconstruction_loss off, st=False -> t_min = sde.eps)"""
+def get_t_min(sde, cfg, st=False):
+    """SDE.get_t_min sde_lib.py:208-215 (VP) / 343-350 (VE): the truncation time, sampled from numpy's GLOBAL generator
+    when training.st is on (the reference calls np.random.rand() there)"""
+    if st:
+        if cfg.training.k == 1.0:
+            return sde.eps ** (1.0 - np.random.rand())
+        return sde.eps / (1.0 - np.random.rand() * (1 - sde.eps ** (cfg.training.k - 1))) ** (1.0 / (cfg.training.k - 1))
+    return sde.eps
+
+
+def sde_loss(Ps, cfg, sde, batch, train, rng, recon_loss=False, importance_sampling=None, st=False, variance="scoreflow"):
+    """get_sde_loss_fn.loss_fn losses.py:83-142, with its optional reconstruction term (:120-140) and st"""
     if importance_sampling is None:
         importance_sampling = cfg.training.importance_sampling
     reduce_op = torch.mean if cfg.training.reduce_mean else torch.sum
-    t, Z = sde.get_diffusion_time(batch.shape[0], sde.eps, importance_sampling, rng)
+    t_min = get_t_min(sde, cfg, st)
+    t, Z = sde.get_diffusion_time(batch.shape[0], t_min, importance_sampling, rng)
     score_fn = get_score_fn(Ps, cfg, sde, train=train, rng=rng)
     z = rng.randn_like(batch)
     mean, std = sde.marginal_prob(batch, t)
@@ -774,10 +785,29 @@ def sde_loss(Ps, cfg, sde, batch, train, rng, recon_loss=False, importance_sampl
     score = score_fn(perturbed, t)
     if importance_sampling or not cfg.training.likelihood_weighting:
         losses = torch.square(score * std[:, None, None, None] + z)
-        return 0.5 * Z * reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
-    g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
-    losses = torch.square(score + z / std[:, None, None, None])
-    return 0.5 * Z * reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * g2
+        losses = 0.5 * Z * reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
+    else:
+        g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
+        losses = torch.square(score + z / std[:, None, None, None])
+        losses = 0.5 * Z * reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * g2
+    if recon_loss:  # losses.py:120-140
+        eps_vec = torch.ones(batch.shape[0]) * t_min
+        mean, std = sde.marginal_prob(batch, eps_vec)
+        z = rng.randn_like(batch)
+        perturbed = mean + std[:, None, None, None] * z
+        score = score_fn(perturbed, eps_vec)
+        alpha, beta = sde.marginal_prob(torch.ones_like(batch), eps_vec)
+        q_mean = perturbed / alpha + beta[:, None, None, None] ** 2 * score / alpha
+        q_std = beta if variance == "ddpm" else beta / torch.mean(alpha, axis=(1, 2, 3))
+        n_dim = np.prod(batch.shape[1:])
+        p_entropy = n_dim / 2.0 * (np.log(2 * np.pi) + 2 * torch.log(std) + 1.0)
+        q_recon = n_dim / 2.0 * (np.log(2 * np.pi) + 2 * torch.log(q_std)) + 0.5 / (q_std ** 2) * torch.square(
+            batch - q_mean).sum(axis=(1, 2, 3))
+        reconstruction_loss = q_recon - p_entropy
+        if cfg.training.reduce_mean:
+            reconstruction_loss = reconstruction_loss / n_dim
+        losses = losses + reconstruction_loss
+    return losses
 
 
 def calculate_logp(sde, batch, rng):  # losses.py:219-225

@@ -705,6 +705,45 @@ def golden_round2(out_dir):
     print("mini_r2 done:", sum(v.nbytes for v in out.values()) / 1e6, "MB raw")
 
 
+def golden_round3(out_dir):
+    """mini_r3.npz: the optional branches of get_sde_loss_fn.loss_fn -- the reconstruction term (losses.py:120-140, both
+    `variance` settings) and the sampled truncation time st=True (sde_lib.py:208-215 / 343-350) -- on the mini nets of
+    mini_vp_nll / mini_vp_fid / mini_ve: per-image losses, the sampled t_min, gradient statistics of the mean loss."""
+    out = {}
+    cases = (("vp_recon", "mini_vp_nll", "configs.vp.CIFAR10.indm_nll", patch_vp_nll, "scoreflow", False),
+             ("vp_recon_ddpm", "mini_vp_nll", "configs.vp.CIFAR10.indm_nll", patch_vp_nll, "ddpm", False),
+             ("vp_recon_st", "mini_vp_nll", "configs.vp.CIFAR10.indm_nll", patch_vp_nll, "scoreflow", True),
+             ("vp_fid_recon", "mini_vp_fid", "configs.vp.CIFAR10.indm_fid", patch_vp_fid, "scoreflow", False),
+             ("ve_recon", "mini_ve", "configs.ve.CIFAR10.indm", patch_ve, "scoreflow", False),
+             ("ve_recon_st", "mini_ve", "configs.ve.CIFAR10.indm", patch_ve, "ddpm", True))
+    for tag, fixture, cfg_name, patch, variance, st in cases:
+        cfg = mini(ref_import.get_config(cfg_name))
+        patch(cfg)
+        score, flow = build(cfg, seed=1234)
+        _load_fixture_weights(fixture, score, flow)
+        sde = sde_lib.get_sde(cfg)
+        loss_fn = losses.get_sde_loss_fn(cfg, sde, train=True, variance=variance)
+        x = data_batch(cfg, 2, seed=400)
+        score.train()
+        np.random.seed(77)                       # get_t_min(st=True) draws from numpy's global generator
+        tmin_probe = sde.get_t_min(cfg, st)
+        np.random.seed(77)
+        rec = Recorder()
+        with rec.on():
+            l = loss_fn(score, x, st=st, recon_loss=True)
+        score.zero_grad()
+        l.mean().backward()
+        out[f"{tag}/x"], out[f"{tag}/loss"] = x.numpy(), l.detach().numpy()
+        out[f"{tag}/t_min"] = np.asarray(float(tmin_probe))
+        out[f"{tag}/numpy_seed"] = np.asarray(77)
+        pack_events(tag, rec.events, out)
+        named = [(n[len("module."):], p.grad.detach()) for n, p in score.named_parameters() if p.grad is not None]
+        for k, v in tensor_stats(named).items():
+            out[f"{tag}/grad/stat/{k}"] = v
+        print(tag, l.detach().numpy(), float(tmin_probe), len(rec.events), flush=True)
+    np.savez_compressed(os.path.join(out_dir, "mini_r3.npz"), **out)
+
+
 def patch_vp_nll(cfg):
     pass
 
@@ -736,3 +775,5 @@ if __name__ == "__main__":
         golden_celeba(HERE)
     if "r2" in which:
         golden_round2(HERE)
+    if "r3" in which:
+        golden_round3(HERE)

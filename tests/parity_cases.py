@@ -433,3 +433,39 @@ def case_reference_checkpoint(device, tol=1.0):
 
 
 R2_CASES = [case_ve_ode, case_reference_checkpoint]
+
+
+# ----------------------------------------------------------------------------- round-3 fixtures (mini_r3.npz)
+R3_TAGS = {"vp_recon": ("mini_vp_nll", "scoreflow", False), "vp_recon_ddpm": ("mini_vp_nll", "ddpm", False),
+           "vp_recon_st": ("mini_vp_nll", "scoreflow", True), "vp_fid_recon": ("mini_vp_fid", "scoreflow", False),
+           "ve_recon": ("mini_ve", "scoreflow", False), "ve_recon_st": ("mini_ve", "ddpm", True)}
+
+
+def case_reconstruction_loss(tag, device, tol=1.0):
+    """get_sde_loss_fn.loss_fn with recon_loss=True (losses.py:120-140) and st (sde_lib.py:208-215): per-image losses
+    and the gradient of the mean loss against the reference's goldens"""
+    d = gu.load("mini_r3")
+    fx, variance, st = R3_TAGS[tag]
+    _, cfg, score, _ = build(fx, device)
+    sde = sde_lib.get_sde(cfg)
+    loss_fn = losses.get_sde_loss_fn(cfg, sde, train=True, variance=variance)
+    score.train()
+    np.random.seed(int(d[f"{tag}/numpy_seed"]))      # get_t_min(st=True) draws from numpy's global generator
+    rng = ReplayRng(gu.events(d, tag), device)
+    loss = loss_fn(score, torch.from_numpy(d[f"{tag}/x"]).to(device), st=st, recon_loss=True, rng=rng)
+    assert rng.done()
+    gu.assert_close(loss, d[f"{tag}/loss"], 2e-4 * tol, 1e-5 * tol, f"{tag} loss")
+    for p in score.parameters():
+        p.grad = None
+    loss.mean().backward()
+    checked = 0
+    for n, p in score.named_parameters():
+        key = f"{tag}/grad/stat/{n}"
+        if key not in d or p.grad is None:
+            continue
+        got, ref = gu.stat(score.to_reference_layout(n, p.grad)), torch.from_numpy(d[key])
+        scale = (ref[1].item() * p.numel()) ** 0.5 + 1e-12
+        assert abs(got[0] - ref[0]).item() <= 5e-4 * tol * scale + 1e-6, ("grad sum " + n, got, ref)
+        assert abs(got[1] - ref[1]).item() <= 1e-3 * tol * ref[1].item() + 1e-9, ("grad sumsq " + n, got, ref)
+        checked += 1
+    assert checked > 20

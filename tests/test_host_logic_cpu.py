@@ -235,3 +235,9 @@ def test_fid_and_inception_score_statistics():
     assert len(ev.inception_scores_10_splits(np.tile(onehot, (10, 1)))) == 10
     with pytest.raises(ValueError):
         ev.inception_scores_10_splits(onehot)
+
+
+@pytest.mark.parametrize("tag", sorted(pc.R3_TAGS))
+def test_reconstruction_loss_golden(tag, emulate_hip):
+    """loss_fn(recon_loss=True[, st=True]) against the reference's goldens (mini_r3.npz)"""
+    pc.case_reconstruction_loss(tag, "cpu")

@@ -425,3 +425,32 @@ def test_chunked_step_matches_reference_goldens():
             gu.assert_close(st.P[k], v, 1e-4, 2e-6, "chunked full " + k)
     for k, v in gu.sub(d, "after2/flow/buffers").items():
         gu.assert_close(fstate.P[k].float(), v.float(), 1e-5, 1e-6, "chunked " + k)
+
+
+# ----------------------------------------------------------------------------- round-3 fixtures (mini_r3.npz)
+R3_CASES = {"vp_recon": ("mini_vp_nll", "scoreflow", False), "vp_recon_ddpm": ("mini_vp_nll", "ddpm", False),
+            "vp_recon_st": ("mini_vp_nll", "scoreflow", True), "vp_fid_recon": ("mini_vp_fid", "scoreflow", False),
+            "ve_recon": ("mini_ve", "scoreflow", False), "ve_recon_st": ("mini_ve", "ddpm", True)}
+
+
+@pytest.mark.parametrize("tag", sorted(R3_CASES))
+def test_reconstruction_loss_and_sampled_truncation_time(tag):
+    """get_sde_loss_fn.loss_fn with recon_loss=True (losses.py:120-140, both `variance` settings) and st=True
+    (sde_lib.py:208-215 / 343-350): per-image losses, the sampled t_min and the gradient of the mean loss"""
+    d = gu.load("mini_r3")
+    fx, variance, st = R3_CASES[tag]
+    dw, cfg = gu.load(fx), gu.mini_config(fx)
+    sde = O.get_sde(cfg)
+    P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in gu.state_dict(dw, "score").items()}
+    np.random.seed(int(d[f"{tag}/numpy_seed"]))
+    assert abs(O.get_t_min(sde, cfg, st) - float(d[f"{tag}/t_min"])) <= 1e-12
+    np.random.seed(int(d[f"{tag}/numpy_seed"]))
+    rng = O.ReplayRng(gu.events(d, tag))
+    loss = O.sde_loss(P, cfg, sde, torch.from_numpy(d[f"{tag}/x"]), True, rng, recon_loss=True, st=st, variance=variance)
+    assert rng.done()
+    gu.assert_close(loss, d[f"{tag}/loss"], 2e-5, 1e-6, f"{tag} loss")
+    loss.mean().backward()
+    keys = [k[len(f"{tag}/grad/stat/"):] for k in d if k.startswith(f"{tag}/grad/stat/")]
+    assert len(keys) > 20
+    for k in keys:
+        gu.assert_close(gu.stat(P[k].grad), d[f"{tag}/grad/stat/{k}"], 2e-4, 1e-5 * max(1.0, float(abs(d[f"{tag}/grad/stat/{k}"]).max())), f"{tag} grad {k}")

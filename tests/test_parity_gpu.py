@@ -159,3 +159,9 @@ def test_repeated_sampling_and_nelbo_do_not_grow_memory():
             gc.collect()
             marks.append(torch.cuda.memory_allocated())
     assert abs(marks[2] - marks[0]) <= 4 << 20 and abs(marks[2] - marks[1]) <= 4 << 20, marks
+
+
+@pytest.mark.parametrize("tag", sorted(pc.R3_TAGS))
+def test_reconstruction_loss_golden(tag):
+    """loss_fn(recon_loss=True[, st=True]) against the reference's goldens (mini_r3.npz)"""
+    pc.case_reconstruction_loss(tag, "cuda")
