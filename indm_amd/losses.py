@@ -107,7 +107,7 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
         rng = rng or default_rng(batch.device)
         dev = batch.device
         B, C, H, W = batch.shape
-        t_min = sde.get_t_min(config, st)
+        t_min = sde.get_t_min(config, st, rng)
         t, Z = sde.get_diffusion_time(config, B, "cpu", t_min, importance_sampling=importance_sampling, rng=rng)
         mc, std, labels = _host_schedule(sde, t)
         z = rng.randn_image(B, C, H, W)                                    # losses.py:103 (NHWC here)
@@ -236,12 +236,13 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         state["ema"].update()
         flow_state["ema"].update()
 
-    def _nll_losses(state, flow_state, mini_batch, rng, importance_sampling=None):
+    def _nll_losses(state, flow_state, mini_batch, rng, importance_sampling=None, st=False, keep=None):
         flow_model = flow_state["model"]
         _unwrap(flow_model).train()
         z, losses_flow = flow_forward(config, flow_model, mini_batch, reverse=False, rng=rng)
-        losses_score = loss_fn(state["model"], z, st=config.training.st, importance_sampling=importance_sampling,
-                               rng=rng)
+        losses_score = loss_fn(state["model"], z, st=st, importance_sampling=importance_sampling, rng=rng)
+        if keep is not None:   # training.st: flow_step_fn_fid's second phase re-uses these (losses.py:383-389)
+            keep["z"], keep["losses_score"] = z.detach(), losses_score.detach()
         losses_logp = calculate_logp(z, rng)
         D = float(np.prod(mini_batch.shape[1:]))
         if config.training.reduce_mean:
@@ -264,7 +265,7 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         if train:
             for k in range(nmb):
                 mb = batch[B // nmb * k: B // nmb * (k + 1)]
-                ls, lf, lp = _nll_losses(state, flow_state, mb, rng)
+                ls, lf, lp = _nll_losses(state, flow_state, mb, rng, st=config.training.st)   # losses.py:294
                 losses = ls + lf + lp
                 outs.push({0: losses, 1: ls, 2: lf, 3: lp})   # D2H enqueued before the backward pass
                 if k == nmb - 1 and hasattr(allreduce, "arm"):
@@ -280,9 +281,8 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         return outs.result(B)
 
     def flow_step_fn_fid(state, flow_state, batch, rng=None):
-        """losses.py:322-406 (training.st=False)"""
-        if config.training.st:
-            raise NotImplementedError("training.st=True is not used by any shipped config")
+        """losses.py:322-406, training.st included (:378-395)"""
+        st = bool(config.training.st)
         rng = rng or _step_rng(batch.device, state["step"])
         B = batch.shape[0]
         nmb = config.optim.num_micro_batch
@@ -292,19 +292,33 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
         if hasattr(allreduce, "begin_step"):
             allreduce.begin_step()
         if train:
+            keep = {} if st else None
             for k in range(nmb):
                 mb = batch[B // nmb * k: B // nmb * (k + 1)]
-                ls, lf, lp = _nll_losses(state, flow_state, mb, rng, importance_sampling=True)
+                ls, lf, lp = _nll_losses(state, flow_state, mb, rng, importance_sampling=True, keep=keep)
                 losses = ls + lf + lp
                 outs.push({0: losses, 2: lf, 3: lp})
                 torch.mean(losses).backward()
             _reduce_and_step([flow_state])
-            _zero(state)
+            sflat = state["optimizer"].flat
+            if st:
+                # the first phase's score gradients stay (no zero_grad, losses.py:379-380): collect them into the flat
+                # buffer and let the second phase's backward accumulate into its slices
+                sflat.gather_grads()
+                sflat.adopt_flat_grads()
+            else:
+                _zero(state)
             for k in range(nmb):
                 mb = batch[B // nmb * k: B // nmb * (k + 1)]
-                with torch.no_grad():
-                    z, _ = flow_forward(config, flow_state["model"], mb, log_det=None, reverse=False, rng=rng)
-                la = loss_fn(state["model"], z.detach(), st=config.training.st, recon_loss=False, rng=rng)
+                if not st:
+                    with torch.no_grad():
+                        z, _ = flow_forward(config, flow_state["model"], mb, log_det=None, reverse=False, rng=rng)
+                else:
+                    z = keep["z"]   # the LAST micro-batch's latent of the first phase, whatever `mb` is (losses.py:383-386)
+                la = loss_fn(state["model"], z.detach(), st=st, recon_loss=False, rng=rng)
+                if st:   # p.grad <- const_adj * p.grad for every score parameter (losses.py:389-395): one launch on the
+                    # flat buffer, the factor stays on the device
+                    sflat.g.mul_((la.mean() / keep["losses_score"].mean()).detach())
                 outs.push({1: la})
                 torch.mean(la).backward()
             _reduce_and_step([state])

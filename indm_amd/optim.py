@@ -70,6 +70,15 @@ class FlatParams:
         hip.multi_copy(srcs, dsts)
         self.gathered = True
 
+    def adopt_flat_grads(self):
+        """After gather_grads(): point every parameter's .grad at its slice of the flat buffer, so that a FURTHER
+        backward pass accumulates into the flat buffer (training.st's second phase adds to re-scaled first-phase
+        gradients, losses.py:389-397).  Parameters that received no gradient keep .grad = None, as in the reference."""
+        for p, dst, _ in self.gslices:
+            if p.grad is not None:
+                p.grad = dst.view(p.shape)
+        self.gathered = False   # gradients that appear (or get re-allocated) from here on are collected by the next gather
+
     def parameters(self):
         return [p for _, p in self.named]
 

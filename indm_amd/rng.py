@@ -113,6 +113,11 @@ class DeviceRng:
     def poisson(self, lam):
         return int(self.np.poisson(lam, 1)[0])
 
+    def np_rand(self):
+        """one host uniform: the sampled truncation time of training.st (sde_lib.py:208-215 draws it from numpy's
+        global generator, the stream the flow's Poisson draws use -- here the source's own numpy stream)"""
+        return float(self.np.rand())
+
     def dropout_seed(self):
         self._drop = (self._drop * 6364136223846793005 + 1442695040888963407) % (1 << 63)
         return self._drop
@@ -154,6 +159,9 @@ class ReplayRng:
 
     def poisson(self, lam):
         return int(self._next("poisson"))
+
+    def np_rand(self):
+        return float(self._next("np_rand"))
 
     def dropout_seed(self):
         """The parity fixtures are recorded with model.dropout = 0 (masks cannot be replayed by seed): the value is

@@ -156,12 +156,13 @@ class VPSDE(SDE):
             return t, Z.detach()
         return u * (self.T - t_min) + t_min, 1
 
-    def get_t_min(self, config, st=False):  # :208-215
+    def get_t_min(self, config, st=False, rng=None):  # :208-215
+        """rng: a noise source with np_rand() (indm_amd.rng); None = numpy's global generator, as the reference"""
         if st:
+            u = rng.np_rand() if rng is not None and hasattr(rng, "np_rand") else np.random.rand()
             if config.training.k == 1.0:
-                return self.eps ** (1.0 - np.random.rand())
-            return self.eps / (1.0 - np.random.rand() * (1 - self.eps ** (config.training.k - 1))) ** (
-                1.0 / (config.training.k - 1))
+                return self.eps ** (1.0 - u)
+            return self.eps / (1.0 - u * (1 - self.eps ** (config.training.k - 1))) ** (1.0 / (config.training.k - 1))
         return self.eps
 
 
@@ -234,8 +235,8 @@ class VESDE(SDE):
             return t_min + ((Z * u) / (2.0 * (np.log(self.sigma_max) - np.log(self.sigma_min)))), Z.detach()
         return u * (self.T - t_min) + t_min, 1
 
-    def get_t_min(self, config, st=False):
-        return VPSDE.get_t_min(self, config, st)
+    def get_t_min(self, config, st=False, rng=None):
+        return VPSDE.get_t_min(self, config, st, rng)
 
 
 def get_sde(config):

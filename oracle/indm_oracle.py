@@ -39,6 +39,9 @@ class Rng:
     def poisson(self, lam):  # iresblock.py:305-306
         return int(np.random.poisson(lam, 1)[0])
 
+    def np_rand(self):  # sde_lib.py:208-215: the sampled truncation time of training.st
+        return float(np.random.rand())
+
 
 class ReplayRng(Rng):
     """Feeds recorded draws back in order; shape-checked."""
@@ -70,6 +73,9 @@ class ReplayRng(Rng):
 
     def poisson(self, lam):
         return int(self._next("poisson"))
+
+    def np_rand(self):
+        return float(self._next("np_rand"))
 
     def done(self):
         return self.i == len(self.events)
@@ -761,13 +767,14 @@ def flow_forward(P, cfg, x, log_det=0, reverse=False, training=False, rng=None, 
 
 
 # ----------------------------------------------------------------------------- losses / step functions
-def get_t_min(sde, cfg, st=False):
-    """SDE.get_t_min sde_lib.py:208-215 (VP) / 343-350 (VE): the truncation time, sampled from numpy's GLOBAL generator
-    when training.st is on (the reference calls np.random.rand() there)"""
+def get_t_min(sde, cfg, st=False, rng=None):
+    """SDE.get_t_min sde_lib.py:208-215 (VP) / 343-350 (VE): the truncation time, sampled when training.st is on (the
+    reference calls np.random.rand() there: numpy's global generator, which the flow's Poisson draws share)"""
     if st:
+        u = (rng or Rng()).np_rand()
         if cfg.training.k == 1.0:
-            return sde.eps ** (1.0 - np.random.rand())
-        return sde.eps / (1.0 - np.random.rand() * (1 - sde.eps ** (cfg.training.k - 1))) ** (1.0 / (cfg.training.k - 1))
+            return sde.eps ** (1.0 - u)
+        return sde.eps / (1.0 - u * (1 - sde.eps ** (cfg.training.k - 1))) ** (1.0 / (cfg.training.k - 1))
     return sde.eps
 
 
@@ -776,7 +783,7 @@ def sde_loss(Ps, cfg, sde, batch, train, rng, recon_loss=False, importance_sampl
     if importance_sampling is None:
         importance_sampling = cfg.training.importance_sampling
     reduce_op = torch.mean if cfg.training.reduce_mean else torch.sum
-    t_min = get_t_min(sde, cfg, st)
+    t_min = get_t_min(sde, cfg, st, rng)
     t, Z = sde.get_diffusion_time(batch.shape[0], t_min, importance_sampling, rng)
     score_fn = get_score_fn(Ps, cfg, sde, train=train, rng=rng)
     z = rng.randn_like(batch)
@@ -869,10 +876,12 @@ def _micro_batches(cfg, batch):
     return [batch[B // n * k: B // n * (k + 1)] for k in range(n)]
 
 
-def _nll_losses(cfg, sde, state, flow_state, mb, rng, stats, importance_sampling=None):
+def _nll_losses(cfg, sde, state, flow_state, mb, rng, stats, importance_sampling=None, st=False, keep=None):
     bn = {}
     z, losses_flow = flow_forward(flow_state.P, cfg, mb, training=True, rng=rng, stats=stats, bn_updates=bn)
-    losses_score = sde_loss(state.P, cfg, sde, z, True, rng, importance_sampling=importance_sampling)
+    losses_score = sde_loss(state.P, cfg, sde, z, True, rng, importance_sampling=importance_sampling, st=st)
+    if keep is not None:   # training.st: the second phase of flow_step_fn_fid re-uses these (losses.py:383-389)
+        keep["z"], keep["losses_score"] = z.detach(), losses_score.detach()
     losses_logp = calculate_logp(sde, z, rng)
     D = np.prod(mb.shape[1:])
     if cfg.training.reduce_mean:
@@ -891,7 +900,8 @@ def flow_step_fn_nll(cfg, sde, state, flow_state, batch, rng, stats=None):
     """losses.py:258-320 (train=True)"""
     state.zero_grad()
     flow_state.zero_grad()
-    parts = [_nll_losses(cfg, sde, state, flow_state, mb, rng, stats) for mb in _micro_batches(cfg, batch)]
+    parts = [_nll_losses(cfg, sde, state, flow_state, mb, rng, stats, st=cfg.training.st)   # losses.py:294
+             for mb in _micro_batches(cfg, batch)]
     state.optimize()
     flow_state.optimize()
     state.step += 1
@@ -957,22 +967,33 @@ def flow_step_fn_nll_chunked(cfg, sde, state, flow_state, batch, events, chunk=1
 
 
 def flow_step_fn_fid(cfg, sde, state, flow_state, batch, rng, stats=None):
-    """losses.py:322-406 (training.st=False)"""
+    """losses.py:322-406, training.st included (:378-395)"""
+    st = bool(cfg.training.st)
     state.zero_grad()
     flow_state.zero_grad()
-    parts = [_nll_losses(cfg, sde, state, flow_state, mb, rng, stats, importance_sampling=True)
+    keep = {}
+    parts = [_nll_losses(cfg, sde, state, flow_state, mb, rng, stats, importance_sampling=True, keep=keep)
              for mb in _micro_batches(cfg, batch)]
     flow_state.optimize()
     flow_state.ema_update()
-    state.zero_grad()
+    if not st:
+        state.zero_grad()
     adds = []
     for mb in _micro_batches(cfg, batch):
-        bn = {}
-        with torch.no_grad():
-            z2, _ = flow_forward(flow_state.P, cfg, mb, log_det=None, training=True, rng=rng, bn_updates=bn)
-            for k, v in bn.items():
-                flow_state.P[k] = v
-        la = sde_loss(state.P, cfg, sde, z2.detach(), True, rng, recon_loss=False)
+        if not st:
+            bn = {}
+            with torch.no_grad():
+                z2, _ = flow_forward(flow_state.P, cfg, mb, log_det=None, training=True, rng=rng, bn_updates=bn)
+                for k, v in bn.items():
+                    flow_state.P[k] = v
+        else:
+            z2 = keep["z"]      # the LAST micro-batch's latent of the first phase, whatever `mb` is (losses.py:383-386)
+        la = sde_loss(state.P, cfg, sde, z2.detach(), True, rng, recon_loss=False, st=st)
+        if st:                  # the first phase's score gradients stay and are re-scaled in place (losses.py:389-395)
+            const_adj = (la.mean() / keep["losses_score"].mean()).detach()
+            for k in state.trainable:
+                if state.P[k].grad is not None:
+                    state.P[k].grad = const_adj * state.P[k].grad
         torch.mean(la).backward()
         adds.append(la.detach())
     state.optimize()

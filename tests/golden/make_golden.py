@@ -52,7 +52,7 @@ class Recorder:
     @contextlib.contextmanager
     def on(self):
         o = dict(randn=torch.randn, randn_like=torch.randn_like, rand=torch.rand, rand_like=torch.rand_like,
-                 randint_like=torch.randint_like, poisson=np.random.poisson)
+                 randint_like=torch.randint_like, poisson=np.random.poisson, np_rand=np.random.rand)
         ev = self.events
 
         def randn(*a, **k):
@@ -74,14 +74,17 @@ class Recorder:
         def poisson(lam, n):
             r = o["poisson"](lam, n); ev.append(("poisson", np.asarray(r[0], dtype=np.int64))); return r
 
+        def np_rand(*a):   # sde.get_t_min(st=True) draws its truncation time here (sde_lib.py:208-215)
+            r = o["np_rand"](*a); ev.append(("np_rand", np.asarray(r, dtype=np.float64))); return r
+
         torch.randn, torch.randn_like, torch.rand, torch.rand_like = randn, randn_like, rand, rand_like
-        torch.randint_like, np.random.poisson = randint_like, poisson
+        torch.randint_like, np.random.poisson, np.random.rand = randint_like, poisson, np_rand
         try:
             yield
         finally:
             torch.randn, torch.randn_like, torch.rand = o["randn"], o["randn_like"], o["rand"]
             torch.rand_like = o["rand_like"]
-            torch.randint_like, np.random.poisson = o["randint_like"], o["poisson"]
+            torch.randint_like, np.random.poisson, np.random.rand = o["randint_like"], o["poisson"], o["np_rand"]
 
 
 def pack_events(prefix, events, out):
@@ -741,6 +744,38 @@ def golden_round3(out_dir):
         for k, v in tensor_stats(named).items():
             out[f"{tag}/grad/stat/{k}"] = v
         print(tag, l.detach().numpy(), float(tmin_probe), len(rec.events), flush=True)
+    # ---- training.st = True through both step functions (losses.py:294 and :378-395, incl. the in-place re-scaling of the
+    # first phase's score gradients), one and two micro-batches ----
+    for tag, fixture, cfg_name, patch, nmb in (("st_nll", "mini_vp_nll", "configs.vp.CIFAR10.indm_nll", patch_vp_nll, 1),
+                                               ("st_fid", "mini_vp_fid", "configs.vp.CIFAR10.indm_fid", patch_vp_fid, 1),
+                                               ("st_fid_mb2", "mini_vp_fid", "configs.vp.CIFAR10.indm_fid", patch_vp_fid, 2)):
+        cfg = mini(ref_import.get_config(cfg_name), batch=4)
+        patch(cfg)
+        cfg.training.st = True
+        cfg.optim.num_micro_batch = nmb
+        score, flow = build(cfg, seed=1234)
+        _load_fixture_weights(fixture, score, flow)
+        sde = sde_lib.get_sde(cfg)
+        scaler = ref_datasets.get_data_scaler(cfg)
+        step_fn = losses.get_step_fn(cfg, sde, train=True, optimize_fn=losses.optimization_manager(cfg), scaler=scaler)
+        state, fstate = make_states(cfg, score, flow)
+        score.train(); flow.train()
+        xb = data_batch(cfg, 4, seed=500)
+        out[f"{tag}/x"] = xb.numpy()
+        np.random.seed(78)
+        out[f"{tag}/numpy_seed"] = np.asarray(78)
+        rec = Recorder()
+        with rec.on():
+            l, ls, lf, lp = step_fn(state, fstate, xb)
+        for nm, v in (("loss", l), ("loss_score", ls), ("loss_flow", lf), ("loss_logp", lp)):
+            out[f"{tag}/{nm}"] = v.numpy()
+        pack_events(tag, rec.events, out)
+        for pre, mod in (("score", score), ("flow", flow)):
+            named = [(n[len("module."):], p.detach()) for n, p in mod.named_parameters()]
+            for k, v in tensor_stats(named).items():
+                out[f"{tag}/after/{pre}/stat/{k}"] = v
+        out[f"{tag}/steps"] = np.asarray([state["step"], fstate["step"], state["ema"].num_updates])
+        print(tag, l.numpy(), ls.numpy(), len(rec.events), flush=True)
     np.savez_compressed(os.path.join(out_dir, "mini_r3.npz"), **out)
 
 

@@ -469,3 +469,24 @@ def case_reconstruction_loss(tag, device, tol=1.0):
         assert abs(got[1] - ref[1]).item() <= 1e-3 * tol * ref[1].item() + 1e-9, ("grad sumsq " + n, got, ref)
         checked += 1
     assert checked > 20
+
+
+def case_training_st_step(tag, device, tol=1.0):
+    """training.st = True through flow_step_fn_nll (losses.py:294) and the two-phase flow_step_fn_fid, whose second phase
+    keeps and re-scales the first phase's score gradients (losses.py:378-395); one and two micro-batches"""
+    d = gu.load("mini_r3")
+    fx = "mini_vp_nll" if tag == "st_nll" else "mini_vp_fid"
+    _, cfg, score, fl = build(fx, device)
+    cfg.training.st = True
+    cfg.optim.num_micro_batch = 2 if tag.endswith("mb2") else 1
+    sde = sde_lib.get_sde(cfg)
+    state, flow_state, _ = utils.build_states(cfg, score, fl, device)
+    step_fn = losses.get_step_fn(cfg, sde, train=True)
+    score.train(); fl.train()
+    rng = ReplayRng(gu.events(d, tag), device)
+    out = step_fn(state, flow_state, torch.from_numpy(d[f"{tag}/x"]).to(device), rng=rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+        gu.assert_close(v, d[f"{tag}/{nm}"], 5e-4 * tol, 2e-5 * tol, f"{tag} {nm}")
+    _check_param_stats(d, f"{tag}/after", (("score", score), ("flow", fl)), tol, slack=0.02 * cfg.flow.lr)
+    assert [state["step"], flow_state["step"], state["ema"].num_updates] == list(d[f"{tag}/steps"])

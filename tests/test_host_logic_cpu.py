@@ -241,3 +241,9 @@ def test_fid_and_inception_score_statistics():
 def test_reconstruction_loss_golden(tag, emulate_hip):
     """loss_fn(recon_loss=True[, st=True]) against the reference's goldens (mini_r3.npz)"""
     pc.case_reconstruction_loss(tag, "cpu")
+
+
+@pytest.mark.parametrize("tag", ["st_nll", "st_fid", "st_fid_mb2"])
+def test_training_st_golden(tag, emulate_hip):
+    """training.st = True steps against the reference's goldens (mini_r3.npz)"""
+    pc.case_training_st_step(tag, "cpu")

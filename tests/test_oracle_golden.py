@@ -443,8 +443,7 @@ def test_reconstruction_loss_and_sampled_truncation_time(tag):
     sde = O.get_sde(cfg)
     P = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in gu.state_dict(dw, "score").items()}
     np.random.seed(int(d[f"{tag}/numpy_seed"]))
-    assert abs(O.get_t_min(sde, cfg, st) - float(d[f"{tag}/t_min"])) <= 1e-12
-    np.random.seed(int(d[f"{tag}/numpy_seed"]))
+    assert abs(O.get_t_min(sde, cfg, st) - float(d[f"{tag}/t_min"])) <= 1e-12      # numpy's global stream, as seeded
     rng = O.ReplayRng(gu.events(d, tag))
     loss = O.sde_loss(P, cfg, sde, torch.from_numpy(d[f"{tag}/x"]), True, rng, recon_loss=True, st=st, variance=variance)
     assert rng.done()
@@ -454,3 +453,27 @@ def test_reconstruction_loss_and_sampled_truncation_time(tag):
     assert len(keys) > 20
     for k in keys:
         gu.assert_close(gu.stat(P[k].grad), d[f"{tag}/grad/stat/{k}"], 2e-4, 1e-5 * max(1.0, float(abs(d[f"{tag}/grad/stat/{k}"]).max())), f"{tag} grad {k}")
+
+
+@pytest.mark.parametrize("tag", ["st_nll", "st_fid", "st_fid_mb2"])
+def test_training_st_steps(tag):
+    """training.st = True through flow_step_fn_nll (losses.py:294) and the two-phase flow_step_fn_fid, whose second
+    phase keeps and re-scales the first phase's score gradients (losses.py:378-395), with one and two micro-batches"""
+    d = gu.load("mini_r3")
+    fx = "mini_vp_nll" if tag == "st_nll" else "mini_vp_fid"
+    dw, cfg = gu.load(fx), gu.mini_config(fx)
+    cfg.training.st = True
+    cfg.optim.num_micro_batch = 2 if tag.endswith("mb2") else 1
+    sde = O.get_sde(cfg)
+    state = O.OracleState(gu.state_dict(dw, "score"), cfg.optim.lr, cfg.model.ema_rate, cfg)
+    fstate = O.OracleState(gu.state_dict(dw, "flow"), cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    step = O.flow_step_fn_nll if cfg.training.likelihood_weighting else O.flow_step_fn_fid
+    rng = O.ReplayRng(gu.events(d, tag))
+    out = step(cfg, sde, state, fstate, torch.from_numpy(d[f"{tag}/x"]), rng)
+    assert rng.done()
+    for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+        gu.assert_close(v, d[f"{tag}/{nm}"], 2e-4, 1e-5, f"{tag} {nm}")
+    for pre, st in (("score", state), ("flow", fstate)):
+        for k in st.trainable:
+            gu.assert_close(gu.stat(st.P[k]), d[f"{tag}/after/{pre}/stat/{k}"], 1e-5, 1e-6, "param " + k)
+    assert [state.step, fstate.step, state.num_updates] == list(d[f"{tag}/steps"])

@@ -165,3 +165,9 @@ def test_repeated_sampling_and_nelbo_do_not_grow_memory():
 def test_reconstruction_loss_golden(tag):
     """loss_fn(recon_loss=True[, st=True]) against the reference's goldens (mini_r3.npz)"""
     pc.case_reconstruction_loss(tag, "cuda")
+
+
+@pytest.mark.parametrize("tag", ["st_nll", "st_fid", "st_fid_mb2"])
+def test_training_st_golden(tag):
+    """training.st = True steps against the reference's goldens (mini_r3.npz)"""
+    pc.case_training_st_step(tag, "cuda")
