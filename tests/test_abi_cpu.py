@@ -41,3 +41,11 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "indm_oracle" not in src and "import oracle" not in src and "_emu" not in src, fn
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md's appendix (tools/abi_table.py) names every function the header declares"""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    appendix = doc[doc.index("## Appendix A. Every exported entry point"):]
+    missing = [s for s in header_symbols() if f"`{s}`" not in appendix]
+    assert not missing, missing
