@@ -82,3 +82,32 @@ def test_flow_eval_paths_write_in_bounds(guards, dtype, B):
         bad = guards.check()
         assert not bad, "inverse: " + " | ".join(bad[:6])
     assert torch.isfinite(xr).all()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,pred,corr", [("ve/CIFAR10/indm", "reverse_diffusion", "langevin"),
+                                            ("vp/CIFAR10/indm_nll", "euler_maruyama", "none")])
+def test_sampler_and_likelihood_updates_write_in_bounds(guards, name, pred, corr):
+    """the block-level sampler entry points (noise drawn inside the update kernel) and the Hutchinson divergence under
+    guard bands: three PC steps + the flow inverse, then one NELBO evaluation"""
+    from indm_amd import likelihood, sampling
+    dev = torch.device(DEV)
+    cfg = configs.get_config(name)
+    cfg.device = dev
+    cfg.sampling.method, cfg.sampling.predictor, cfg.sampling.corrector = "pc", pred, corr
+    cfg.sampling.num_scales = 3
+    torch.manual_seed(0)
+    score = utils.create_model(cfg, dev).eval()
+    flow = create_flow_model(cfg).to(dev).eval()
+    sde = sde_lib.get_sde(cfg)
+    inv = utils.get_data_inverse_scaler(cfg)
+    fn = sampling.get_sampling_fn(cfg, sde, (2, 3, 32, 32), inv, cfg.sampling.truncation_time, device=dev)
+    before, after, _ = fn(score, flow, rng=DeviceRng(dev, seed=9), graph=False)
+    bad = guards.check()
+    assert not bad, "sampler: " + " | ".join(bad[:6])
+    assert torch.isfinite(before).all() and torch.isfinite(after).all()
+    x = (torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(dev)
+    nelbo = likelihood.get_elbo_fn(cfg, sde, inverse_scaler=inv)(score, flow, x, rng=DeviceRng(dev, seed=10))
+    bad = guards.check()
+    assert not bad, "nelbo: " + " | ".join(bad[:6])
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in nelbo)
