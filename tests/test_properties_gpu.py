@@ -219,14 +219,39 @@ def test_training_is_bit_reproducible(dtype):
         score.train(); flow.train()
         rng = DeviceRng(dev, seed=21, poisson_seed=22)
         g = torch.Generator().manual_seed(23)
+        # per-module checksums of every module's forward output and of the gradient arriving at it (EXACT: integer sums
+        # over the bit patterns, so a one-ulp change in one element shows), as device scalars in execution order: a
+        # failure then names the first MODULE whose output or cotangent differed
+        trace, order = [], []
+
+        def cksum(t):
+            v = t.detach().float().contiguous().view(torch.int32).to(torch.int64)
+            return torch.stack([v.sum(), (v * v).sum()])
+
+        def fwd_hook(name):
+            def hook(_m, _inp, out):
+                outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(o) and o.is_floating_point()]
+                for j, o in enumerate(outs):
+                    trace.append(cksum(o)); order.append(f"fwd {name}[{j}]")
+                    if o.requires_grad:
+                        o.register_hook(lambda gr, nm=f"bwd {name}[{j}]": (trace.append(cksum(gr)), order.append(nm)) and None)
+            return hook
+
+        for pre, mod in (("score", score), ("flow", flow)):
+            for n, m in mod.named_modules():
+                if n:
+                    m.register_forward_hook(fwd_hook(f"{pre}.{n}"))
         rec = []
         for _ in range(3):
             x = (torch.rand(4, 3, 32, 32, generator=g) * 2 - 1).to(dev)
+            del trace[:], order[:]
             out = torch.stack(step_fn(state, fstate, x, rng=rng))
             torch.cuda.synchronize()
+            step_trace, step_order = (torch.stack(trace) if trace else torch.zeros(0, 2, dtype=torch.int64)), list(order)
             # the flat gradient buffers still hold this step's gradients: kept so that a failure names the first
             # parameter whose gradient differed, not just "the losses differ"
-            rec.append({"loss": out, "score grad": state["optimizer"].flat.g.clone(),
+            rec.append({"module trace": step_trace, "_order": step_order,
+                        "loss": out, "score grad": state["optimizer"].flat.g.clone(),
                         "flow grad": fstate["optimizer"].flat.g.clone(),
                         "score params": state["optimizer"].flat.p.clone(),
                         "flow params": fstate["optimizer"].flat.p.clone()})
@@ -242,7 +267,20 @@ def test_training_is_bit_reproducible(dtype):
     def first_difference(a, b, names):
         for s in range(3):
             for key in a[s]:
+                if key == "_order":
+                    continue
                 x, y = a[s][key], b[s][key]
+                if key == "module trace":
+                    if a[s]["_order"] != b[s]["_order"]:
+                        return f"step {s}: the two runs executed different module sequences"
+                    bad = (x != y).any(dim=1).nonzero().flatten().tolist()
+                    if bad:
+                        od = a[s]["_order"]
+                        return (f"step {s}: {len(bad)} of {len(od)} module checksums differ; first (execution order): "
+                                f"{[(od[i], x[i].tolist(), y[i].tolist()) for i in bad[:4]]}; last identical before it: "
+                                f"{od[bad[0] - 1] if bad[0] else None}; kinds of the differing ones: "
+                                f"{sorted(set(od[i].split()[0] for i in bad))}")
+                    continue
                 if not torch.equal(x, y):
                     msg = f"step {s}: {key} differs, max |d| {(x - y).abs().max().item():.3e}"
                     if key == "loss":
