@@ -317,7 +317,9 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
                     z = keep["z"]   # the LAST micro-batch's latent of the first phase, whatever `mb` is (losses.py:383-386)
                 la = loss_fn(state["model"], z.detach(), st=st, recon_loss=False, rng=rng)
                 if st:   # p.grad <- const_adj * p.grad for every score parameter (losses.py:389-395): one launch on the
-                    # flat buffer, the factor stays on the device
+                    # flat buffer, the factor stays on the device.  (Data parallel: the factor is formed from THIS
+                    # rank's shard means, where the reference's single-process DataParallel sees the whole batch --
+                    # identical at world_size 1, the only setting a shipped config could reach this branch in.)
                     sflat.g.mul_((la.mean() / keep["losses_score"].mean()).detach())
                 outs.push({1: la})
                 torch.mean(la).backward()
