@@ -213,6 +213,19 @@ def _ws(nfloats, device):
 SPLITK_WS_FLOATS = 1 << 25  # 128 MiB of fp32 partial slabs for weight-grad split-K
 
 
+def debug_state():
+    """Fingerprint of every piece of process-wide state a launch could depend on (scratch buffer, caches, mode
+    switches, allocator totals): tests/test_properties_gpu.py prints it next to a reproducibility failure so that two
+    runs of one test can be compared for what the process history left behind."""
+    ws = {k: (v.data_ptr(), v.numel()) for k, v in _ws_cache.items()}
+    out = dict(ws=ws, packed=len(_packed), w2t_packed=len(_w2t_packed), tables=len(_tables), col_offs=len(_col_offs),
+               ires_ws=len(_ires_ws_sizes), dtype=_MFMA["dtype"], block_drivers=BLOCK_DRIVERS["on"],
+               poison=POISON_WS["on"], profile=_Profile.enabled, timer=_active_timer[0] is not None)
+    if torch.cuda.is_available():
+        out["allocated"], out["reserved"] = torch.cuda.memory_allocated(), torch.cuda.memory_reserved()
+    return out
+
+
 _MFMA = {"dtype": "f32"}  # "f32" | "bf16": see set_compute_dtype()
 
 # --------------------------------------------------------------------------- live per-kernel timing (bench.py)

@@ -223,6 +223,7 @@ def test_training_is_bit_reproducible(dtype):
         # over the bit patterns, so a one-ulp change in one element shows), as device scalars in execution order: a
         # failure then names the first MODULE whose output or cotangent differed
         trace, order = [], []
+        states.append(hip.debug_state())
 
         def cksum(t):
             v = t.detach().float().contiguous().view(torch.int32).to(torch.int64)
@@ -264,6 +265,8 @@ def test_training_is_bit_reproducible(dtype):
             names[key] = lst
         return rec, names
 
+    states = []
+
     def first_difference(a, b, names):
         for s in range(3):
             for key in a[s]:
@@ -304,5 +307,6 @@ def test_training_is_bit_reproducible(dtype):
             c, _ = run()
         finally:
             hip.set_compute_dtype("f32")
-        diff += f"  ||  run 2 vs run 3: {first_difference(b, c, names)}  ||  run 1 vs run 3: {first_difference(a, c, names)}"
+        diff += (f"  ||  run 2 vs run 3: {first_difference(b, c, names)}  ||  run 1 vs run 3: {first_difference(a, c, names)}"
+                 f"  ||  process state at the start of each run: {states}")
     assert diff is None, diff
