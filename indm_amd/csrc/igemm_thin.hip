@@ -219,10 +219,6 @@ __global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
 constexpr int TF_LDS = TK_TN + 8;
 constexpr int TF_AS = TK_KC * TK_LDA, TF_BS = TK_KC * TK_LDB, TF_STG = 4 * 8 * TF_LDS;
 
-__device__ __forceinline__ void async_load4(f32x4& dst, const float* src) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
-}
-
 __device__ float thin_zero_word[4];  // padded taps of the implicit im2col load from here (zero-initialised)
 
 __device__ __forceinline__ void async_load1(float& dst, const float* src) {
@@ -257,9 +253,16 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
     gk[j] = e0 - grow[j] * K;
     goff[j] = min(e0, tile_elems - 4);
   }
-  f32x4 ra[4];
+  // The flat form prefetches the next tile with PLAIN loads (`ra`; hipcc places their wait, possibly after sinking them
+  // below the MFMA loop -- this form is off the hot path).  Round 3 issued them as inline-asm global_load_dwordx4 awaited
+  // by a later asm `s_waitcnt`: where the asynchronous and the synchronous (ragged / first tile) definitions of the
+  // register set merged, hipcc copied the destination registers BEFORE the wait (v_mov_b64 of registers whose load was
+  // still in flight: stale data whenever memory was slower than the MFMA loop in between).  The IM2COL form below keeps
+  // asm loads into registers with a single definition; tools/asm_async_scan.py checks the ISA for such reads
+  // (tests/test_isa_cpu.py).
+  f32x4 ra[4], rs[4];
   // A tile -> LDS [k][row]; `total` = valid elements of the tile (ragged last tile: the rest stays stale, never stored)
-  auto sstore_a = [&](int total) {
+  auto sstore_a = [&](const f32x4 (&ra)[4], int total) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int e0 = (tid + j * 256) * 4;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
     for (int j = 0; j < 4; ++j) {
       const int e0 = (tid + j * 256) * 4;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) ra[j][t] = e0 + t < total ? src[e0 + t] : 0.f;
+      for (int t = 0; t < 4; ++t) rs[j][t] = e0 + t < total ? src[e0 + t] : 0.f;
     }
     return total;
   };
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
   }
   if ((K & 1) && tid < TK_TM) as[K * TK_LDA + tid] = 0.f;  // odd K: second half of the last k-pair
   if constexpr (!IM2COL) {
-    if (tm < tiles_m) sstore_a(load_tile_sync(tm));
+    if (tm < tiles_m) sstore_a(rs, load_tile_sync(tm));
   }
   const int npairs = (K + 1) >> 1;
   const int c4 = l31 * 4, n = n0 + c4;  // this lane's four output columns: the same for every row it stores
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
     } else if (next_full) {
       const float* src = p.A + (long)tnext * TK_TM * K;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) async_load4(ra[j], src + goff[j]);
+      for (int j = 0; j < 4; ++j) ra[j] = *(const f32x4*)(src + goff[j]);   // plain loads: hipcc owns their wait (see `ra`)
     }
 
     f32x16 acc[4];
@@ -444,10 +447,9 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
     if constexpr (IM2COL) {
       if (next_full) scatter();
     } else if (next_full) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3])::"memory");
-      sstore_a(tile_elems);
+      sstore_a(ra, tile_elems);
     } else if (tnext < tiles_m) {
-      sstore_a(load_tile_sync(tnext));
+      sstore_a(rs, load_tile_sync(tnext));
     }
     // stores last: nothing waits for them until the next tile's MFMAs are done
 #pragma unroll

@@ -130,6 +130,24 @@ def test_gemm_thin_k(M, N, K):
         close(out, ref, rtol=1e-5, atol=1e-4, name=f"thin-K gemm + epilogue rpg={rpg}")
 
 
+@pytest.mark.parametrize("M,N,K", [(131072, 512, 27), (131072 + 128 + 5, 512, 4), (65536, 256, 1), (98304, 512, 32)])
+def test_gemm_thin_k_persistent_walk(M, N, K):
+    """the flat thin-K kernel with MORE row tiles than workgroups: every workgroup walks several tiles and prefetches
+    the next one while it multiplies (the small cases above stop after one tile per workgroup).  Round 4 found the
+    prefetch -- inline-asm loads awaited by a later asm wait -- copied out of its registers before the wait by the
+    compiler; with K <= 4 the multiply loop between the two is shorter than any memory latency."""
+    a, b = rnd(M, K), rnd(K, N, seed=1)
+    for rep in range(3):
+        out = hip.gemm(a.to(DEV), b.to(DEV))
+        assert "thin_k" in hip.lib().indm_igemm_last_variant().decode()
+        # every row against fp64 on the GPU side of the comparison budget: rows are independent, check a strided sample
+        idx = torch.arange(0, M, 37)
+        ref = a[idx].double() @ b.double()
+        close(out[idx.to(DEV)], ref, rtol=1e-5, atol=1e-5 * math.sqrt(K), name=f"thin-K persistent rep {rep}")
+        idx = torch.arange(M - 300, M)
+        close(out[idx.to(DEV)], a[idx].double() @ b.double(), rtol=1e-5, atol=1e-5 * math.sqrt(K), name="thin-K tail")
+
+
 @pytest.mark.parametrize("T,N,P", [(27, 512, 8192), (108, 512, 4096), (5, 256, 4096 + 32), (128, 640, 6400), (12, 260, 4128)])
 def test_gemm_thin_wgrad(T, N, P):
     """weight-grad forms with a skinny side: thin^T wide -> [T, N] and (wide .* gate)^T thin -> [N, T]"""
