@@ -26,6 +26,54 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak of the same guide
+
+
+def step_gflop_per_image(n_bar):
+    """Algorithmic work of one vp/CIFAR10/indm_nll training step per image (BASELINE.md section 2 / SURVEY App. C, 2*MAC
+    convention): the score net's forward + backward (65.08 GFLOP) plus the flow's log-det forward + backward with n
+    Poisson series terms per block, 12.73 (n + 8) GFLOP -- evaluated at the REALISED mean series length of the timed
+    steps (E[n] = 2 gives the 192.4 GFLOP of BASELINE.md)."""
+    return 12.73 * (n_bar + 8.0) + 65.08
+
+
+class _CountingPoisson:
+    """wraps a noise source's poisson(): the realised series lengths of the timed region (BASELINE.md section 3 asks for
+    the roofline at the realised n-bar, not at its expectation)"""
+
+    def __init__(self, rng):
+        self.rng, self.draws, self._orig = rng, [], rng.poisson
+        rng.poisson = self
+
+    def __call__(self, lam):
+        n = self._orig(lam)
+        self.draws.append(n)
+        return n
+
+    def reset(self):
+        self.draws = []
+
+    def mean(self):
+        return sum(self.draws) / len(self.draws) if self.draws else None
+
+
+def step_roofline(n_bar, images_per_s, dtype, gflop_per_image=None):
+    """achieved = (algorithmic GFLOP per image at the realised n-bar) x images/s, vs the MFMA
+    peak of the arithmetic type"""
+    g = step_gflop_per_image(n_bar) if gflop_per_image is None else gflop_per_image
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    ach = g * images_per_s / 1e3
+    return {"gflop_per_image": g, "achieved_tflops": ach, "peak_tflops": peak, "frac": ach / peak, "n_bar": n_bar}
+
+
+def device_identity(dev):
+    """what this rank's GPU is: enough to tell N ranks on N GPUs from N ranks on one"""
+    pr = torch.cuda.get_device_properties(dev)
+    out = {"index": dev.index, "name": pr.name}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if hasattr(pr, k):
+            out[k] = str(getattr(pr, k))
+    return out
 
 
 def synthetic_batch(B, size, seed, device):
@@ -154,6 +202,16 @@ def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
             print("[bench] WARNING: NELBO differs from the CPU oracle by more than 0.01 bits/dim", file=sys.stderr)
     xb = synthetic_batch(32, cfg.data.image_size, 777, dev)
     rng = DeviceRng(dev, seed=5)
+    # algorithmic FLOPs of one call: the sum over its dense launches (2 M N K each), counted on the op-level composition
+    # (same kernels as the block drivers, which enqueue theirs from C++ where Python cannot see them)
+    from indm_amd import hip
+    drivers_on = hip.block_drivers()
+    hip.block_drivers(False)
+    hip.profile_start()
+    fn(score, flow, xb, rng=rng)
+    prof = hip.profile_stop()
+    hip.block_drivers(drivers_on)
+    flops_call = sum(q["flops"] for q in prof.values())
     fn(score, flow, xb, rng=rng)
     torch.cuda.synchronize()
     t0 = time.time()
@@ -161,6 +219,9 @@ def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
         fn(score, flow, xb, rng=rng)
     torch.cuda.synchronize()
     out["images_per_s"] = 3 * 32 / (time.time() - t0)
+    out["gflop_per_image"] = flops_call / 32 / 1e9
+    out["achieved_tflops"] = out["gflop_per_image"] * out["images_per_s"] / 1e3
+    out["frac"] = out["achieved_tflops"] / PEAK_F32_MFMA_TFLOPS
     out["note"] = "random-init weights after the timed steps; eval-mode flow log-det (n+20 power-series terms)"
     score.train(); flow.train()
     return out
@@ -189,6 +250,10 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
         x = st.rng.randn_image(batch, 3, cfg.data.image_size, cfg.data.image_size)
         ts = torch.linspace(sde.T, cfg.sampling.truncation_time, 1000)
         table = sampling.predictor_table(st, "euler_maruyama", ts[:steps + 2], batch).to(dev)
+        # algorithmic FLOPs of one sampler step: the sum over the dense launches of an eager step (2 M N K each)
+        hip.profile_start()
+        sampling._GraphedPredictor(st, x, table, use_graph=False).step(0)
+        flops_step = sum(q["flops"] for q in hip.profile_stop().values())
         for mode in ("graph", "eager"):
             gp = sampling._GraphedPredictor(st, x, table, use_graph=(mode == "graph"))
             gp.step(0); gp.step(1)
@@ -209,7 +274,6 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
         torch.cuda.synchronize()
         t_inv = time.time() - t0
     g = res["graph"]
-    flops = 2.0 * 21.693e9 * batch * (nrb / 4.0)   # score forward, App. C (nrb = 4) scaled to the deeper net: lower bound
     flow.train()
     del score
     return {"workload": f"pc_sampler step (EM predictor, no corrector), NCSN++ num_res_blocks={nrb}, batch {batch}, "
@@ -218,7 +282,10 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
             "sampler_steps_per_s": 1e3 / g["wall_ms_per_step"],
             "flow_inverse_s": t_inv,
             "images_per_s_1000_step_sampling": batch / (1000 * g["wall_ms_per_step"] * 1e-3 + t_inv),
-            "nfe_per_image": 1000}
+            "nfe_per_image": 1000,
+            "gflop_per_image_per_step": flops_step / batch / 1e9,
+            "achieved_tflops": flops_step / (g["gpu_ms_per_step"] * 1e-3) / 1e12,
+            "frac": flops_step / (g["gpu_ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
 
 def pmc_traffic(kernel_key):
@@ -267,6 +334,166 @@ def launch_ranks(n, argv):
     return proc.returncode
 
 
+def run_training(args, cfg_name, batch, dtype, steps, warmup, rank, world, dev, kernel_roofline=True, exposed=False):
+    """Build both networks (random init, the full architecture of `cfg_name`) and time `steps` train_step_fn calls after
+    `warmup` untimed ones, bracketed by barrier + synchronize.  Returns the measurements of this rank (elapsed is the MAX
+    over ranks) plus the live objects the extra legs of the headline run need."""
+    from indm_amd import configs, hip, losses, parallel, sde_lib, utils
+    from indm_amd.flow import create_flow_model
+    from indm_amd.rng import DeviceRng
+
+    cfg = configs.get_config(cfg_name)
+    cfg.training.batch_size = batch * world
+    cfg.device = dev
+    cfg.compute_dtype = dtype
+    torch.manual_seed(cfg.seed)                     # default_cifar10_configs.py:126
+    score = utils.create_model(cfg, dev)
+    flow = create_flow_model(cfg).to(dev)
+    state, flow_state, flat_g = utils.build_states(cfg, score, flow, dev)
+    dist_on = torch.distributed.is_initialized()
+    if dist_on:
+        parallel.broadcast_parameters(state["optimizer"].flat.p)
+        parallel.broadcast_parameters(flow_state["optimizer"].flat.p)
+    sde = sde_lib.get_sde(cfg)
+    reducer = parallel.make_allreduce(flat_g, world)
+    step_fn = losses.get_step_fn(cfg, sde, train=True, world_size=world, allreduce=reducer)
+    score.train(); flow.train()
+    batches = [synthetic_batch(batch, cfg.data.image_size, 1234 + rank + 1000 * i, dev) for i in range(steps + warmup)]
+    rng = DeviceRng(dev, seed=1234 + rank, poisson_seed=4321)   # same series lengths on every rank: balanced steps
+    counter = _CountingPoisson(rng)
+
+    def barrier():
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    dominant, warm_prof = None, {}
+    drivers_on = hip.block_drivers()
+    for i in range(warmup):
+        profiled = kernel_roofline and i == warmup - 1
+        if profiled:
+            # which dense kernel class owns the most GPU time?  Timed per launch with HIP events on the op-level
+            # composition (the block drivers enqueue the same kernels from C++, where Python cannot bracket them)
+            hip.block_drivers(False)
+            hip.profile_start()
+        step_fn(state, flow_state, batches[i], rng=rng)
+        if profiled:
+            prof = hip.profile_stop()
+            hip.block_drivers(drivers_on)
+            warm_prof = prof or {}
+            if prof:
+                dominant = max(prof, key=lambda k: prof[k]["ms"])
+                if rank == 0 and os.environ.get("INDM_BENCH_PROFILE"):
+                    for k in sorted(prof, key=lambda k: -prof[k]["ms"]):
+                        q = prof[k]
+                        print(f"[bench] {k:72s} launches {q['launches']:5d}  {q['ms']:8.2f} ms  "
+                              f"{q['flops'] / 1e9:10.1f} GFLOP  {q['flops'] / q['ms'] / 1e9:7.2f} TF/s",
+                              file=sys.stderr, flush=True)
+    barrier()
+    # the dominant class inside the timed region: HIP events on the launch stream around ITS launches only -- recorded by
+    # the C-side launch timer when the block drivers own those launches (chain-kernel classes), else by hip.py
+    chain_timer, variant = None, None
+    if dominant:
+        variant = dominant[len("igemm<"):-1].split(",", 2)[-1]
+        if drivers_on and variant.startswith("ires_chain"):
+            # capacity from the launches the profiled warm-up step counted for this class (x4: Poisson series lengths vary)
+            per_step = max(64, 4 * warm_prof[dominant]["launches"])
+            chain_timer = hip.ChainTimer(per_step * steps)
+            chain_timer.reset(variant)
+            hip.set_chain_timer(chain_timer)
+        hip.profile_start(only=dominant)
+    counter.reset()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.time()
+    last = None
+    marks[0].record()
+    for i in range(steps):
+        last = step_fn(state, flow_state, batches[warmup + i], rng=rng)
+        marks[i + 1].record()    # GPU-side step boundaries (no host sync): the median step time of SURVEY 8(d)
+    barrier()
+    elapsed = time.time() - t0
+    n_bar = counter.mean()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    prof = hip.profile_stop() if dominant else {}
+    if chain_timer is not None:
+        hip.set_chain_timer(None)
+        r = chain_timer.read()
+        p0 = prof.get(dominant, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+        # algorithmic bytes per launch of a chain class (hip.ires_chain's figure): t3 + d2 + d1 + W2T + P (+ t2 when stored)
+        M = batch * (1024 if "x32" in variant else 256)
+        J = 27 if "x32" in variant else 108
+        eb = 2.0 if hip.storage_dtype() == "bf16" else 4.0   # bytes per element of the 512-wide flow tensors
+        nb = eb * 3 * M * 512 + eb * 512 * 512 + 4.0 * M * J + (eb * M * 512 if "t2out" in variant else 0)
+        prof[dominant] = dict(launches=p0["launches"] + r["launches"], flops=p0["flops"] + r["flops"],
+                              bytes=p0["bytes"] + nb * r["launches"], ms=p0["ms"] + r["ms"])
+    exposed_ms = None
+    if exposed and dist_on and world > 1:
+        # the same step WITHOUT the collective (replicas drift apart from here on: last thing this function does): what
+        # the all-reduce costs on the critical path = step time with it - step time without it
+        nocoll = losses.get_step_fn(cfg, sde, train=True, world_size=world, allreduce=None)
+        k = max(2, min(steps, 6))
+        nocoll(state, flow_state, batches[0], rng=rng)
+        barrier()
+        t1 = time.time()
+        for i in range(k):
+            nocoll(state, flow_state, batches[i % len(batches)], rng=rng)
+        barrier()
+        t_nc = torch.tensor([(time.time() - t1) / k], device=dev)
+        torch.distributed.all_reduce(t_nc, op=torch.distributed.ReduceOp.MAX)
+        exposed_ms = 1e3 * float(t_nc)
+    if dist_on:
+        t = torch.tensor([elapsed], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    roof, measured_in = None, "timed region"
+    if dominant and not (dominant in prof and prof[dominant]["ms"] > 0) and warm_prof.get(dominant, {}).get("ms", 0) > 0:
+        # a short run whose timed steps did not launch the class (or lost its events): the same per-launch HIP-event
+        # timing taken in the profiled warm-up step stands in, and the line says so
+        prof[dominant], measured_in = warm_prof[dominant], "profiled warm-up step"
+        if rank == 0:
+            print(f"[bench] no timed-region launches recorded for {dominant}: roofline from the warm-up step",
+                  file=sys.stderr, flush=True)
+    if dominant and dominant in prof and prof[dominant]["ms"] > 0:
+        q = prof[dominant]
+        ach = q["flops"] / (q["ms"] * 1e-3) / 1e12
+        traffic, src = pmc_traffic(dominant)
+        peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": traffic, "traffic_source": src, "measured_in": measured_in, "launches": q["launches"],
+                "avg_launch_ms": q["ms"] / q["launches"], "algorithmic_gflop_per_launch": q["flops"] / q["launches"] / 1e9,
+                "algorithmic_bytes_per_launch": q["bytes"] / q["launches"]}
+    imgs_per_s = batch * world * steps / elapsed
+    if roof is not None and n_bar is not None:
+        # BASELINE.md section 3's definition: the WHOLE step at the realised n-bar (the dominant kernel above is ~13 % of it)
+        roof["step"] = step_roofline(n_bar, imgs_per_s / world, dtype)
+    return dict(cfg=cfg, sde=sde, score=score, flow=flow, elapsed=elapsed, images_per_s=imgs_per_s,
+                ms_per_step=1e3 * elapsed / steps, median_ms=median_ms, roofline=roof, n_bar=n_bar,
+                last_loss_mean=float(last[0].mean()) if last is not None else None,
+                allreduce_exposed_ms=(1e3 * elapsed / steps - exposed_ms) if exposed_ms is not None else None,
+                ms_per_step_without_collective=exposed_ms,
+                collectives_per_step=list(reducer.calls) if reducer is not None else None)
+
+
+def shard_legs(args, dev):
+    """One rank's share of every multi-GPU BASELINE configuration's partitioning on 8 GPUs: config #2's global
+    batch 128 strong-scaled (16 images per rank), #5 / #4-sized 32 and #3-sized 64 images per rank, on the headline's
+    network, fp32 and bf16; no collective (x 8 minus the all-reduce is the node figure).  Short runs: 2 warm-up + 5 steps."""
+    out = {}
+    for b in (16, 32, 64):
+        for dtype in ("f32", "bf16"):
+            r = run_training(args, "vp/CIFAR10/indm_nll", b, dtype, steps=5, warmup=2, rank=0, world=1, dev=dev,
+                             kernel_roofline=False)
+            out[f"batch{b}_{dtype}"] = {"ms_per_step": r["ms_per_step"], "images_per_s": r["images_per_s"],
+                                        "step_roofline_frac": step_roofline(r["n_bar"], r["images_per_s"], dtype)["frac"],
+                                        "n_bar": r["n_bar"]}
+            del r
+            torch.cuda.empty_cache()
+    out["workload"] = ("configs/vp/CIFAR10/indm_nll.py train step on one rank's shard of an 8-GPU job (no collective): "
+                       "16 / 32 / 64 images, 2 warm-up + 5 timed steps each")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -277,11 +504,12 @@ def main():
                     help="strong scaling: a fixed GLOBAL batch sharded evenly over the ranks (SURVEY 8e: 128 -> 16/rank, "
                          "512 -> 64, 256 -> 32 at 8 GPUs); overrides --batch")
     ap.add_argument("--no-sampling", action="store_true", help="skip the config-#5 sampling leg")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the bf16 and per-rank-shard training legs (N = 1)")
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = the headline (exact fp32 MFMA); bf16 = MFMA inputs rounded to bf16, fp32 accumulate "
-                         "(the dtype of BASELINE configs #3-#5; NOT the headline configuration)")
+                    help="f32 = the headline (exact fp32 MFMA); bf16 = MFMA inputs rounded to bf16, fp32 accumulate, the "
+                         "flow's wide tensors stored as bf16 (the dtype of BASELINE configs #3-#5; NOT the headline)")
     ap.add_argument("--cpu-baseline-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -291,9 +519,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return sys.exit(launch_ranks(args.gpus, sys.argv[1:]))      # before any GPU call in this process
 
-    from indm_amd import configs, hip, losses, parallel, sde_lib, utils
-    from indm_amd.flow import create_flow_model
-    from indm_amd.rng import DeviceRng
+    from indm_amd import hip, parallel
 
     # test hook (tests/test_bench_multirank_gpu.py): all ranks share GPU 0 and exchange gradients over gloo, so that
     # the multi-process path of this file can be exercised on a single-GPU box (RCCL refuses two ranks on one device)
@@ -316,127 +542,44 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     hip.lib()
-
-    cfg = configs.get_config("vp/CIFAR10/indm_nll")
-    cfg.training.batch_size = args.batch * world
-    cfg.device = dev
-    cfg.compute_dtype = args.dtype
-    torch.manual_seed(cfg.seed)                     # default_cifar10_configs.py:126
-    score = utils.create_model(cfg, dev)
-    flow = create_flow_model(cfg).to(dev)
-    state, flow_state, flat_g = utils.build_states(cfg, score, flow, dev)
     dist_on = torch.distributed.is_initialized()
+    ident = device_identity(dev)
+    idents = [ident]
     if dist_on:
-        parallel.broadcast_parameters(state["optimizer"].flat.p)
-        parallel.broadcast_parameters(flow_state["optimizer"].flat.p)
-    sde = sde_lib.get_sde(cfg)
-    step_fn = losses.get_step_fn(cfg, sde, train=True, world_size=world,
-                                 allreduce=parallel.make_allreduce(flat_g, world))
-    score.train(); flow.train()
-    batches = [synthetic_batch(args.batch, cfg.data.image_size, 1234 + rank + 1000 * i, dev)
-               for i in range(args.steps + args.warmup)]
-    rng = DeviceRng(dev, seed=1234 + rank, poisson_seed=4321)   # same series lengths on every rank: balanced steps
+        idents = [None] * world
+        torch.distributed.all_gather_object(idents, ident)
 
-    def barrier():
-        if dist_on:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    dominant, warm_prof = None, {}
-    drivers_on = hip.block_drivers()
-    for i in range(args.warmup):
-        if i == args.warmup - 1:
-            # which dense kernel class owns the most GPU time?  Timed per launch with HIP events on the op-level
-            # composition (the block drivers enqueue the same kernels from C++, where Python cannot bracket them)
-            hip.block_drivers(False)
-            hip.profile_start()
-        step_fn(state, flow_state, batches[i], rng=rng)
-        if i == args.warmup - 1:
-            prof = hip.profile_stop()
-            hip.block_drivers(drivers_on)
-            warm_prof = prof or {}
-            if prof:
-                dominant = max(prof, key=lambda k: prof[k]["ms"])
-                if rank == 0 and os.environ.get("INDM_BENCH_PROFILE"):
-                    for k in sorted(prof, key=lambda k: -prof[k]["ms"]):
-                        p = prof[k]
-                        print(f"[bench] {k:72s} launches {p['launches']:5d}  {p['ms']:8.2f} ms  "
-                              f"{p['flops'] / 1e9:10.1f} GFLOP  {p['flops'] / p['ms'] / 1e9:7.2f} TF/s",
-                              file=sys.stderr, flush=True)
-    barrier()
-    # the dominant class inside the timed region: HIP events on the launch stream around ITS launches only -- recorded by
-    # the C-side launch timer when the block drivers own those launches (chain-kernel classes), else by hip.py
-    chain_timer = None
-    if dominant:
-        variant = dominant[len("igemm<"):-1].split(",", 2)[-1]
-        if drivers_on and variant.startswith("ires_chain"):
-            chain_timer = hip.ChainTimer(64 * args.steps * 16)
-            chain_timer.reset(variant)
-            hip.set_chain_timer(chain_timer)
-        hip.profile_start(only=dominant)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.time()
-    last = None
-    marks[0].record()
-    for i in range(args.steps):
-        last = step_fn(state, flow_state, batches[args.warmup + i], rng=rng)
-        marks[i + 1].record()    # GPU-side step boundaries (no host sync): the median step time of SURVEY 8(d)
-    barrier()
-    elapsed = time.time() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
-    prof = hip.profile_stop() if dominant else {}
-    if chain_timer is not None:
-        hip.set_chain_timer(None)
-        r = chain_timer.read()
-        p0 = prof.get(dominant, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
-        # algorithmic bytes per launch of a chain class (hip.ires_chain's figure): t3 + d2 + d1 + W2T + P (+ t2 when stored)
-        M = args.batch * (1024 if "x32" in variant else 256)
-        J = 27 if "x32" in variant else 108
-        nb = 4.0 * (3 * M * 512 + 512 * 512 + M * J + (M * 512 if "t2out" in variant else 0))
-        prof[dominant] = dict(launches=p0["launches"] + r["launches"], flops=p0["flops"] + r["flops"],
-                              bytes=p0["bytes"] + nb * r["launches"], ms=p0["ms"] + r["ms"])
-    if dist_on:
-        t = torch.tensor([elapsed], device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
+    r = run_training(args, "vp/CIFAR10/indm_nll", args.batch, args.dtype, args.steps, args.warmup, rank, world, dev,
+                     exposed=True)
+    cfg, sde, score, flow, elapsed = r["cfg"], r["sde"], r["score"], r["flow"], r["elapsed"]
 
     if rank == 0:
         print(f"[bench] {args.steps} steps in {elapsed:.2f}s on {world} GPU(s)", file=sys.stderr, flush=True)
-        imgs = args.batch * world * args.steps
         out = {
             "metric": "training images/sec, CIFAR-10 INDM (VP, NLL)",
-            "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "value": r["images_per_s"], "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "ms_per_step_median": median_ms, "value_at_median_step": args.batch * world / (median_ms * 1e-3),
+            "ms_per_step_median": r["median_ms"], "value_at_median_step": args.batch * world / (r["median_ms"] * 1e-3),
             "config": {"workload": "configs/vp/CIFAR10/indm_nll.py train step (flow 16-16 idim 512 + NCSN++ nf128), "
                                    f"batch {args.batch}/GPU, 32x32x3, "
-                                   + ("fp32" if args.dtype == "f32" else "bf16 MFMA inputs / fp32 accumulate (NOT the "
-                                      "fp32 parity configuration)") + ", dropout 0.1, random-init weights",
+                                   + ("fp32" if args.dtype == "f32" else "bf16 MFMA inputs / fp32 accumulate, bf16 storage of "
+                                      "the flow's 512-wide tensors (NOT the fp32 parity configuration)")
+                                   + ", dropout 0.1, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "last_loss_mean": float(last[0].mean()) if last is not None else None},
+                       "last_loss_mean": r["last_loss_mean"], "n_bar": r["n_bar"]},
+            "roofline": r["roofline"],
         }
-        measured_in = "timed region"
-        if dominant and not (dominant in prof and prof[dominant]["ms"] > 0) and warm_prof.get(dominant, {}).get("ms", 0) > 0:
-            # a short run whose timed steps did not launch the class (or lost its events): the same per-launch HIP-event
-            # timing taken in the profiled warm-up step stands in, and the line says so
-            prof[dominant], measured_in = warm_prof[dominant], "profiled warm-up step"
-            print(f"[bench] no timed-region launches recorded for {dominant}: roofline from the warm-up step",
-                  file=sys.stderr, flush=True)
-        if dominant and dominant in prof and prof[dominant]["ms"] > 0:
-            p = prof[dominant]
-            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
-            traffic, src = pmc_traffic(dominant)
-            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0   # dense bf16 MFMA peak (same guide)
-            out["roofline"] = {"bound": "mfma", "kernel": dominant, "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                               "traffic_source": src, "measured_in": measured_in,
-                               "launches": p["launches"], "avg_launch_ms": p["ms"] / p["launches"],
-                               "algorithmic_gflop_per_launch": p["flops"] / p["launches"] / 1e9,
-                               "algorithmic_bytes_per_launch": p["bytes"] / p["launches"]}
-        else:
-            out["roofline"] = None
+        # who ran: one entry per rank (device uuid / PCI bus id), so that N ranks on N GPUs can be told from N ranks on one
+        keys = [d.get("uuid") or d.get("pci_bus_id") or str(d.get("index")) for d in idents]
+        out["ranks_seen"] = len(idents)
+        out["distinct_devices"] = len(set(keys))
+        out["devices"] = idents
+        out["backend"] = torch.distributed.get_backend() if dist_on else None
+        if world > 1:
+            out["allreduce_exposed_ms"] = r["allreduce_exposed_ms"]
+            out["ms_per_step_without_collective"] = r["ms_per_step_without_collective"]
+            out["collective_elements_per_step"] = r["collectives_per_step"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], oracle_nelbo, out["cpu_baseline_8_threads"] = cpu_baseline(cfg, score, flow)
             out["nelbo"] = nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo)
@@ -449,6 +592,25 @@ def main():
                 out["sampling"]["per_rank_shard_of_8"] = sampling_leg(cfg, flow, dev, steps=60, batch=32)
             except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of an extra leg)
                 out["sampling"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_extra_legs:
+            del r, score, flow
+            torch.cuda.empty_cache()
+            try:
+                if args.dtype == "f32":
+                    # BASELINE configs #3-#5 compute in bf16: the same workload in that mode, as a sub-leg of the default run
+                    b = run_training(args, "vp/CIFAR10/indm_nll", args.batch, "bf16", steps=min(args.steps, 8), warmup=2,
+                                     rank=0, world=1, dev=dev)
+                    out["bf16"] = {"value": b["images_per_s"], "unit": "images/s", "ms_per_step": b["ms_per_step"],
+                                   "ms_per_step_median": b["median_ms"], "steps": min(args.steps, 8), "warmup": 2,
+                                   "roofline": b["roofline"], "last_loss_mean": b["last_loss_mean"], "n_bar": b["n_bar"],
+                                   "dtype": "bf16 MFMA inputs, fp32 accumulate, bf16 storage of the flow's 512-wide tensors"}
+                    del b
+                    torch.cuda.empty_cache()
+                out["train_per_rank_shard_of_8"] = shard_legs(args, dev)
+            except Exception as e:  # noqa: BLE001
+                out["extra_legs_error"] = f"{type(e).__name__}: {e}"
+            finally:
+                hip.set_compute_dtype("f32")
         print(json.dumps(out))
     if dist_on:
         torch.distributed.destroy_process_group()

@@ -350,10 +350,18 @@ INDM_API int indm_iresblock_inverse(const indm_iresblock_fwd_args* a, float atol
 // ---- launch timer ------------------------------------------------------------------------------------------------
 INDM_API int indm_timer_create(int capacity, void** handle) {
   if (!handle || capacity <= 0) return INDM_E_ARG;
+  *handle = nullptr;
   Timer* t = new Timer();
-  t->ev.resize(2 * (size_t)capacity);
-  for (auto& e : t->ev)
-    if (hipEventCreate(&e) != hipSuccess) return INDM_E_LAUNCH;
+  t->ev.reserve(2 * (size_t)capacity);
+  for (size_t i = 0; i < 2 * (size_t)capacity; ++i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {   // give back what was created: the caller gets no handle to destroy
+      for (auto& d : t->ev) (void)hipEventDestroy(d);
+      delete t;
+      return INDM_E_LAUNCH;
+    }
+    t->ev.push_back(e);
+  }
   *handle = t;
   return INDM_OK;
 }

@@ -338,6 +338,11 @@ def compute_dtype():
     return _MFMA["dtype"]
 
 
+def storage_dtype():
+    """'bf16' when the flow's 512-wide tensors live in HBM as bf16 (bf16 compute mode on the block drivers), else 'f32'"""
+    return _MFMA.get("storage", "f32") if _MFMA["dtype"] == "bf16" else "f32"
+
+
 def _dense(name):
     return getattr(lib(), f"indm_{name}_bf16" if _MFMA["dtype"] == "bf16" else f"indm_{name}_f32")
 

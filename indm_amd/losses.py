@@ -317,10 +317,14 @@ def get_step_fn(config, sde, train, optimize_fn=None, scaler=None, world_size=1,
                     z = keep["z"]   # the LAST micro-batch's latent of the first phase, whatever `mb` is (losses.py:383-386)
                 la = loss_fn(state["model"], z.detach(), st=st, recon_loss=False, rng=rng)
                 if st:   # p.grad <- const_adj * p.grad for every score parameter (losses.py:389-395): one launch on the
-                    # flat buffer, the factor stays on the device.  (Data parallel: the factor is formed from THIS
-                    # rank's shard means, where the reference's single-process DataParallel sees the whole batch --
-                    # identical at world_size 1, the only setting a shipped config could reach this branch in.)
-                    sflat.g.mul_((la.mean() / keep["losses_score"].mean()).detach())
+                    # flat buffer, the factor stays on the device.  Data parallel: the reference's single-process
+                    # DataParallel forms the two means over the WHOLE batch, so the per-rank means are all-reduced
+                    # first (equal shards: the ratio of summed means is the ratio of global means) -- every rank then
+                    # scales its un-reduced phase-1 gradients by the same factor, which commutes with the later SUM.
+                    means = torch.stack([la.mean(), keep["losses_score"].mean()]).detach()
+                    if world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+                        torch.distributed.all_reduce(means, op=torch.distributed.ReduceOp.SUM)
+                    sflat.g.mul_(means[0] / means[1])
                 outs.push({1: la})
                 torch.mean(la).backward()
             _reduce_and_step([state])

@@ -71,12 +71,14 @@ class FlatParams:
         self.gathered = True
 
     def adopt_flat_grads(self):
-        """After gather_grads(): point every parameter's .grad at its slice of the flat buffer, so that a FURTHER
+        """After gather_grads(): point EVERY parameter's .grad at its slice of the flat buffer, so that a FURTHER
         backward pass accumulates into the flat buffer (training.st's second phase adds to re-scaled first-phase
-        gradients, losses.py:389-397).  Parameters that received no gradient keep .grad = None, as in the reference."""
+        gradients, losses.py:389-397).  A parameter that has received no gradient so far gets its zero-filled slice
+        (zero_grad() cleared the buffer): a gradient that first appears in the later pass then lands in the flat buffer
+        as well, where the per-micro-batch re-scaling (one mul_ on the flat buffer) reaches it like the reference's loop
+        over every non-None p.grad does."""
         for p, dst, _ in self.gslices:
-            if p.grad is not None:
-                p.grad = dst.view(p.shape)
+            p.grad = dst.view(p.shape)
         self.gathered = False   # gradients that appear (or get re-allocated) from here on are collected by the next gather
 
     def parameters(self):

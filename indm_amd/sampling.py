@@ -69,11 +69,18 @@ class _Stepper:
             return None, ph
         return self.rng.randn_image(*_nchw(x)), None
 
-    def em(self, x, t):
+    def em(self, x, t, probability_flow=False):
+        """probability_flow: Predictor.__init__ builds rsde = sde.reverse(score_fn, probability_flow) (sampling.py:139-144).
+        With it the reference's RSDE.sde returns the float 0. as diffusion (sde_lib.py:103), which
+        EulerMaruyamaPredictor.update_fn indexes (sampling.py:196): the reference RAISES TypeError for this setting
+        (golden mini_r4.npz: pf_em/raises), and so does this mirror -- indm_pc_step_em_f32 itself implements the flag."""
+        if probability_flow:
+            raise TypeError("'float' object is not subscriptable (EulerMaruyamaPredictor with probability_flow=True: "
+                            "the reference indexes RSDE.sde's float diffusion, sampling.py:196)")
         out, _ = self.net_out(x, t)
         f_lin, g, k = self.em_terms(t)
-        z, ph = self._noise(x)
-        return hip.pc_step_em(x, out, _d(f_lin, x), _d(g, x), _d(k, x), -1.0 / self.sde.N, False, z, ph)
+        z, ph = self._noise(x)   # drawn by the reference's probability-flow step too (multiplied by a zero diffusion)
+        return hip.pc_step_em(x, out, _d(f_lin, x), _d(g, x), _d(k, x), -1.0 / self.sde.N, probability_flow, z, ph)
 
     def rd(self, x, t, next_t=None, probability_flow=False):
         out, _ = self.net_out(x, t)
@@ -121,6 +128,9 @@ class _GraphedPredictor:
     def __init__(self, st, x, table, use_graph=True, predictor="euler_maruyama", probability_flow=False):
         self.st, self.table, self.use_graph = st, table, use_graph
         self.predictor, self.pf = predictor, probability_flow
+        if predictor == "euler_maruyama" and probability_flow:
+            raise TypeError("'float' object is not subscriptable (EulerMaruyamaPredictor with probability_flow=True, "
+                            "sampling.py:196)")
         self.x = x.clone()
         self.row = torch.empty_like(table[0])
         self.graph, self.x_mean, self.steps_done = None, None, 0
@@ -131,7 +141,7 @@ class _GraphedPredictor:
         ph = self.st.rng.philox
         if self.predictor == "euler_maruyama":
             x_new, self.x_mean = hip.pc_step_em(self.x, out, self.row[1], self.row[2], self.row[3], -1.0 / self.st.sde.N,
-                                                False, None, ph)
+                                                self.pf, None, ph)
         else:
             x_new, self.x_mean = hip.pc_step_rd(self.x, out, self.row[1], self.row[2], self.row[3], self.pf, None, ph)
         self.x.copy_(x_new)
@@ -185,7 +195,7 @@ def get_pc_sampler(config, sde, shape, predictor, corrector, inverse_scaler, snr
 
     def predictor_update(st, x, vec_t, vec_next_t):
         if predictor == "euler_maruyama":
-            return st.em(x, vec_t)
+            return st.em(x, vec_t, probability_flow)
         if predictor == "reverse_diffusion":
             return st.rd(x, vec_t, vec_next_t, probability_flow)
         return x, x

@@ -1110,12 +1110,14 @@ def likelihood_fn(Ps, Pf, cfg, sde, data, rng, residual=True, eps_bpd=1e-5, rtol
 
 
 # ----------------------------------------------------------------------------- samplers
-def em_predictor(sde, score_fn, x, t, rng):  # sampling.py:186-197
+def em_predictor(sde, score_fn, x, t, rng, probability_flow=False):  # sampling.py:186-197 (Predictor.__init__ :139-144)
     dt = -1.0 / sde.N
     z = rng.randn_like(x)
-    rsde, _ = reverse_sde(sde, score_fn)
+    rsde, _ = reverse_sde(sde, score_fn, probability_flow)
     drift, diffusion = rsde(x, t)
     x_mean = x + drift * dt
+    # probability_flow=True: rsde returns the float 0. as diffusion and this line raises TypeError -- the reference's own
+    # behaviour (sampling.py:196; golden mini_r4.npz pf_em/raises)
     return x_mean + diffusion[:, None, None, None] * np.sqrt(-dt) * z, x_mean
 
 
@@ -1160,9 +1162,9 @@ def pc_sampler(Ps, Pf, cfg, sde, shape, rng, eps, num_scales=None, temperature=1
                 x, x_mean = langevin_corrector(sde, score_fn, x, vec_t, rng, cfg.sampling.snr,
                                                cfg.sampling.n_steps_each)
             if pred == "euler_maruyama":
-                x, x_mean = em_predictor(sde, score_fn, x, vec_t, rng)
+                x, x_mean = em_predictor(sde, score_fn, x, vec_t, rng, cfg.sampling.probability_flow)
             elif pred == "reverse_diffusion":
-                x, x_mean = rd_predictor(sde, score_fn, x, vec_t, rng)
+                x, x_mean = rd_predictor(sde, score_fn, x, vec_t, rng, probability_flow=cfg.sampling.probability_flow)
             if trace is not None:
                 trace.append(x.clone())
         before = x_mean if cfg.sampling.noise_removal else x
@@ -1202,7 +1204,7 @@ def _pc_updates(cfg, sde, score_fn, rng):
 
     def predictor(x, vec_t, vec_next_t):
         if pred == "euler_maruyama":
-            return em_predictor(sde, score_fn, x, vec_t, rng)
+            return em_predictor(sde, score_fn, x, vec_t, rng, cfg.sampling.probability_flow)
         if pred == "reverse_diffusion":
             return rd_predictor(sde, score_fn, x, vec_t, rng, vec_next_t, cfg.sampling.probability_flow)
         return x, x

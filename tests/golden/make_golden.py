@@ -779,6 +779,42 @@ def golden_round3(out_dir):
     np.savez_compressed(os.path.join(out_dir, "mini_r3.npz"), **out)
 
 
+def golden_round4(out_dir):
+    """mini_r4.npz: the PC sampler with sampling.probability_flow = True (Predictor.__init__ sampling.py:139-144 builds
+    rsde = sde.reverse(score_fn, probability_flow): half the score term and no diffusion) -- reverse diffusion + Langevin
+    on the mini VE net, 4 scales; and the Euler-Maruyama predictor on the mini VP net, where the reference RAISES
+    (RSDE.sde returns the float 0. as diffusion, which update_fn indexes, sampling.py:196): the exception type is the golden."""
+    out = {}
+    for tag, fixture, cfg_name, patch in (("pf_em", "mini_vp_nll", "configs.vp.CIFAR10.indm_nll", patch_vp_nll),
+                                          ("pf_rd", "mini_ve", "configs.ve.CIFAR10.indm", patch_ve)):
+        cfg = mini(ref_import.get_config(cfg_name))
+        patch(cfg)
+        cfg.sampling.method = "pc"
+        cfg.sampling.probability_flow = True
+        cfg.sampling.num_scales = 4
+        score, flow = build(cfg, seed=1234)
+        _load_fixture_weights(fixture, score, flow)
+        sde = sde_lib.get_sde(cfg)
+        score.eval(); flow.eval()
+        shape = (2, 3, cfg.data.image_size, cfg.data.image_size)
+        sampler = sampling.get_sampling_fn(cfg, sde, shape, ref_datasets.get_data_inverse_scaler(cfg),
+                                           cfg.sampling.truncation_time)
+        torch.manual_seed(91)
+        rec = Recorder()
+        try:
+            with rec.on():
+                before, after, nfe = sampler(score, flow, sample_dir="/tmp", r=0)
+        except Exception as e:  # noqa: BLE001  -- the reference's own behaviour for this setting is the golden
+            out[f"{tag}/raises"] = np.asarray(type(e).__name__)
+            print(tag, "the reference raises", type(e).__name__, e, flush=True)
+            continue
+        out[f"{tag}/before"], out[f"{tag}/after"], out[f"{tag}/nfe"] = before.numpy(), after.numpy(), np.asarray(nfe)
+        out[f"{tag}/predictor"] = np.asarray(cfg.sampling.predictor)
+        pack_events(tag, rec.events, out)
+        print(tag, cfg.sampling.predictor, cfg.sampling.corrector, float(before.abs().mean()), len(rec.events), flush=True)
+    np.savez_compressed(os.path.join(out_dir, "mini_r4.npz"), **out)
+
+
 def patch_vp_nll(cfg):
     pass
 
@@ -812,3 +848,5 @@ if __name__ == "__main__":
         golden_round2(HERE)
     if "r3" in which:
         golden_round3(HERE)
+    if "r4" in which:
+        golden_round4(HERE)

@@ -490,3 +490,32 @@ def case_training_st_step(tag, device, tol=1.0):
         gu.assert_close(v, d[f"{tag}/{nm}"], 5e-4 * tol, 2e-5 * tol, f"{tag} {nm}")
     _check_param_stats(d, f"{tag}/after", (("score", score), ("flow", fl)), tol, slack=0.02 * cfg.flow.lr)
     assert [state["step"], flow_state["step"], state["ema"].num_updates] == list(d[f"{tag}/steps"])
+
+
+def case_probability_flow_sampler(device, tol=1.0):
+    """mini_r4.npz: sampling.probability_flow = True -- reverse diffusion + Langevin on the VE net against the reference's
+    samples (eager launches and the hipGraph-able predictor-only form are covered by the other sampler cases), and the
+    Euler-Maruyama predictor, for which the reference raises TypeError (so must the mirror, eager and graphed)."""
+    import pytest
+    d = gu.load("mini_r4")
+    _, cfg, score, fl = build("mini_ve", device)
+    cfg.sampling.method, cfg.sampling.probability_flow, cfg.sampling.num_scales = "pc", True, 4
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    shape = tuple(d["pf_rd/before"].shape)
+    fn = sampling.get_sampling_fn(cfg, sde, shape, utils.get_data_inverse_scaler(cfg), cfg.sampling.truncation_time,
+                                  device=device)
+    rng = ReplayRng(gu.events(d, "pf_rd"), device)
+    before, after, nfe = fn(score, fl, rng=rng)
+    assert rng.done() and nfe == int(d["pf_rd/nfe"])
+    gu.assert_close(before, d["pf_rd/before"], 2e-4 * tol, 2e-4 * tol, "pf rd before")
+    gu.assert_close(after, d["pf_rd/after"], 2e-3 * tol, 2e-3 * tol, "pf rd after")
+    _, cfg, score, fl = build("mini_vp_nll", device)
+    cfg.sampling.method, cfg.sampling.probability_flow, cfg.sampling.num_scales = "pc", True, 4
+    sde = sde_lib.get_sde(cfg)
+    score.eval(); fl.eval()
+    fn = sampling.get_sampling_fn(cfg, sde, (2, 3, 32, 32), utils.get_data_inverse_scaler(cfg),
+                                  cfg.sampling.truncation_time, device=device)
+    from indm_amd.rng import DeviceRng
+    with pytest.raises(TypeError):
+        fn(score, fl, rng=DeviceRng(device, seed=3))

@@ -247,3 +247,8 @@ def test_reconstruction_loss_golden(tag, emulate_hip):
 def test_training_st_golden(tag, emulate_hip):
     """training.st = True steps against the reference's goldens (mini_r3.npz)"""
     pc.case_training_st_step(tag, "cpu")
+
+
+def test_probability_flow_sampler_golden(emulate_hip):
+    """sampling.probability_flow = True against the reference's goldens (mini_r4.npz)"""
+    pc.case_probability_flow_sampler("cpu")

@@ -477,3 +477,25 @@ def test_training_st_steps(tag):
         for k in st.trainable:
             gu.assert_close(gu.stat(st.P[k]), d[f"{tag}/after/{pre}/stat/{k}"], 1e-5, 1e-6, "param " + k)
     assert [state.step, fstate.step, state.num_updates] == list(d[f"{tag}/steps"])
+
+
+def test_probability_flow_predictors():
+    """mini_r4.npz: sampling.probability_flow = True through pc_sampler -- the reverse-diffusion predictor (VE net, with
+    the Langevin corrector) against the reference's samples, and the Euler-Maruyama predictor, for which the reference
+    itself raises TypeError (it indexes the float diffusion of the probability-flow RSDE)"""
+    d = gu.load("mini_r4")
+    dv, cfg = gu.load("mini_ve"), gu.mini_config("mini_ve")
+    cfg.sampling.method, cfg.sampling.probability_flow, cfg.sampling.num_scales = "pc", True, 4
+    assert str(d["pf_rd/predictor"]) == cfg.sampling.predictor == "reverse_diffusion"
+    rng = O.ReplayRng(gu.events(d, "pf_rd"))
+    before, after, nfe = O.pc_sampler(gu.state_dict(dv, "score"), gu.state_dict(dv, "flow"), cfg, O.get_sde(cfg),
+                                      tuple(d["pf_rd/before"].shape), rng, cfg.sampling.truncation_time)
+    assert rng.done() and nfe == int(d["pf_rd/nfe"])
+    gu.assert_close(before, d["pf_rd/before"], 1e-4, 1e-4, "pf rd before")
+    gu.assert_close(after, d["pf_rd/after"], 1e-3, 1e-3, "pf rd after")
+    dp, cfg = gu.load("mini_vp_nll"), gu.mini_config("mini_vp_nll")
+    cfg.sampling.method, cfg.sampling.probability_flow, cfg.sampling.num_scales = "pc", True, 4
+    assert str(d["pf_em/raises"]) == "TypeError" and cfg.sampling.predictor == "euler_maruyama"
+    with pytest.raises(TypeError):
+        O.pc_sampler(gu.state_dict(dp, "score"), gu.state_dict(dp, "flow"), cfg, O.get_sde(cfg), (2, 3, 32, 32), O.Rng(),
+                     cfg.sampling.truncation_time)

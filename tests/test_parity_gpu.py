@@ -171,3 +171,8 @@ def test_reconstruction_loss_golden(tag):
 def test_training_st_golden(tag):
     """training.st = True steps against the reference's goldens (mini_r3.npz)"""
     pc.case_training_st_step(tag, "cuda")
+
+
+def test_probability_flow_sampler_golden():
+    """sampling.probability_flow = True against the reference's goldens (mini_r4.npz)"""
+    pc.case_probability_flow_sampler("cuda")
