@@ -183,6 +183,33 @@ int indm_ires_chain_bf16w(const float* A, const float* G, const void* W2Tp, cons
 long indm_ires_bwd_act_ws_floats(long R, int C);
 int indm_ires_bwd_act_f32(const float* da, const float* du, const float* d, const float* a, const float* t, float* dp,
                           float* dt_out, float* seg_out, long R, int C, long rows_per_seg, float* ws, void* stream);
+/* ---- bf16 STORAGE of the flow's [pixels, 512] tensors (BASELINE configs #3-#5; csrc/flow_f16.hip) ---------------
+ * "F16" = bf16 in MFMA-fragment order: X[M, N] (M, N multiples of 32) is cut into 32 x 32 blocks (mt = m / 32, nb = n / 32),
+ * a block into two 1 KB chunks s; chunk (mt, nb, s) holds for lane = 32 lhi + m % 32 and e < 8 the element
+ * X[m][32 nb + 16 s + 8 (e >> 2) + 4 lhi + (e & 3)] at bf16 index (((mt N/32 + nb) 2 + s) 64 + lane) 8 + e -- the accumulator
+ * layout of v_mfma_f32_32x32x16_bf16 and, unchanged, its input fragment for a contraction over n.  Packed weights:
+ * Wp[ks][nblk][lane][e] = bf16(W[16 ks + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 nblk + (lane & 31)]) (the layout of
+ * indm_ires_chain_bf16w's W2Tp) for a row-major W[K][Nw], Nw a multiple of 32 (zero-padded panels included).
+ * The tensors of one iResBlock (iresblock.py:60-76 g-net, :253-273 estimators) never exist as fp32 in this mode. */
+/* fp32 row-major [M, N] <-> F16 */
+int indm_f16_pack_f32(const float* x, void* y, long M, int N, void* stream);
+int indm_f16_unpack_f32(const void* x, float* y, long M, int N, void* stream);
+/* 3x3 / pad 1 / stride 1 convolution of a skinny fp32 NHWC tensor (C <= 3, or C <= 12 with C % 4 == 0) -> F16
+ * [Nimg H W, Cout] (LopConv2d at the flow's image side, lipschitz.py:321-369; sign -1 conv, +1 transposed conv with w
+ * pre-packed as [(tap, co), ci]); w: [9 C, Cout] fp32.  epilogue 0: out1 = conv + bias; 1: (out1, out2) = (sin(2 pi p)/(2 pi),
+ * cos(2 pi p)) of p = conv + bias (the Sin activation, activations.py:7-12: the pre-activation is never stored);
+ * 2: out1 = (conv + bias) .* gate (F16), out2 (optional) = conv + bias.  Returns 1 if the geometry is not covered. */
+int indm_f16_thin_conv(const float* x, const float* w, const float* bias, const void* gate, void* out1, void* out2,
+                       int Nimg, int H, int W, int C, int Cout, int sign, int epilogue, void* stream);
+/* A workgroup owns 64 rows x 512 columns of an F16 A[M, 512] (M % 64 == 0):
+ * mode 0  out1 = A Wp + bias[n] + bias2[m / rows_per_group][n]                        (F16; LopCondConv2d 1x1 lipschitz.py:429-435 and its data gradients)
+ * mode 1  (out1, out2) = Sin activation of that product (a, cos)
+ * mode 2  P[M, J] = ((A Wp) .* D1) Pp[:, :J]; out1 (optional) = A Wp                (the back-to-back VJP link of indm_ires_chain_*, iresblock.py:257,269)
+ * mode 3  P[M, J] = A Pp[:, :J]                                                       (3x3 conv with a skinny OUTPUT before its tap gather)
+ * Wp: packed [512, 512]; Pp: packed [512, 32 | 128] panel (J <= 32 | J <= 128), P fp32 row-major.  Returns 1 if not covered. */
+int indm_f16_rows(int mode, const void* A, const void* Wp, const void* D1, const void* Pp, float* P, void* out1, void* out2,
+                  const float* bias, const float* bias2, int M, int J, int rows_per_group, void* stream);
+
 /* act 1 SiLU (models/layers.py:38-39), 2 ELU (resnet_batchnorm.py:27) */
 int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);
 int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);

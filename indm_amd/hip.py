@@ -119,6 +119,10 @@ _SIGS = {
     "indm_iresblock_fwd_logdet": [c_p, c_p],
     "indm_iresblock_bwd": [c_p, c_p],
     "indm_iresblock_inverse": [c_p, c_f, c_f, c_p, c_p],
+    "indm_f16_pack_f32": [c_p, c_p, c_l, c_i, c_p],
+    "indm_f16_unpack_f32": [c_p, c_p, c_l, c_i, c_p],
+    "indm_f16_thin_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "indm_f16_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "indm_timer_create": [c_i, c_p],
     "indm_timer_destroy": [c_p],
     "indm_timer_reset": [c_p, c_i],
@@ -1228,6 +1232,85 @@ def fused_bias_act(x, bias, ref, act, grad, alpha, scale):
                                        _ptr(ref) if ref is not None and ref.numel() > 0 else None, _ptr(y), x.numel(),
                                        step_b, size_b, act, grad, alpha, scale, _stream()), "indm_fused_bias_act_f32")
     return y
+
+
+# --------------------------------------------------------------------------- bf16 storage of the flow (csrc/flow_f16.hip)
+def _ptr16(t):
+    """raw pointer of an F16 / packed-weight tensor (torch.bfloat16, contiguous, on the GPU)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("indm_amd.hip: tensor is not on the GPU; the HIP path has no CPU fallback")
+    if t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise RuntimeError(f"indm_amd.hip: expected a contiguous bfloat16 tensor, got {t.dtype}")
+    return t.data_ptr()
+
+
+def f16_pack(x):
+    """fp32 [M, N] row-major -> F16 (bf16, MFMA-fragment order; include/indm_hip.h) as a flat bfloat16 tensor"""
+    M, N = x.shape
+    y = torch.empty(M * N, dtype=torch.bfloat16, device=x.device)
+    _chk(lib().indm_f16_pack_f32(_ptr(x), y.data_ptr(), M, N, _stream()), "indm_f16_pack_f32")
+    return y
+
+
+def f16_unpack(y, M, N):
+    x = torch.empty((M, N), dtype=torch.float32, device=y.device)
+    _chk(lib().indm_f16_unpack_f32(_ptr16(y), _ptr(x), M, N, _stream()), "indm_f16_unpack_f32")
+    return x
+
+
+def pack_weight_bf16(w):
+    """row-major fp32 W[K, Nw] (K % 16 == 0; Nw zero-padded to a multiple of 32) -> the packed bf16 fragment order every F16
+    kernel multiplies by: Wp[ks][nblk][lane][e] = W[16 ks + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 nblk + (lane & 31)]"""
+    K, N = w.shape
+    if N % 32:
+        w = torch.nn.functional.pad(w, (0, 32 - N % 32))
+        N = w.shape[1]
+    with torch.no_grad():
+        return (w.detach().to(torch.bfloat16).view(K // 16, 2, 2, 4, N // 32, 32).permute(0, 4, 2, 5, 1, 3).contiguous().view(-1))
+
+
+F16_PLAIN, F16_ACT, F16_GATE = 0, 1, 2
+F16_GEMM, F16_GEMM_ACT, F16_CHAIN, F16_THINN = 0, 1, 2, 3
+
+
+def f16_thin_conv(x, w2d, sign, epilogue=F16_PLAIN, bias=None, gate=None, want_raw=False):
+    """3x3 conv of a skinny NHWC fp32 x with w2d [9C, Cout] -> F16 [pixels, Cout] tensors (see indm_f16_thin_conv).
+    Returns None if the geometry is not covered, else out1 | (a, cos) | (gated, raw or None)."""
+    N, H, W, C = x.shape
+    Co = w2d.shape[1]
+    new = lambda: torch.empty(N * H * W * Co, dtype=torch.bfloat16, device=x.device)  # noqa: E731
+    o1 = new()
+    o2 = new() if (epilogue == F16_ACT or (epilogue == F16_GATE and want_raw)) else None
+    st = lib().indm_f16_thin_conv(_ptr(x), _ptr(w2d), _ptr(bias), _ptr16(gate), o1.data_ptr(),
+                                  o2.data_ptr() if o2 is not None else None, N, H, W, C, Co, sign, epilogue, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_thin_conv")
+    return o1 if epilogue == F16_PLAIN else (o1, o2)
+
+
+def f16_rows(mode, A, M, Wp=None, D1=None, Pp=None, J=0, bias=None, bias2=None, rows_per_group=1, want_t2=False):
+    """indm_f16_rows: mode F16_GEMM -> C; F16_GEMM_ACT -> (a, cos); F16_CHAIN -> (P, t2 or None); F16_THINN -> P.  None if not covered."""
+    dev = A.device
+    new16 = lambda: torch.empty(M * 512, dtype=torch.bfloat16, device=dev)  # noqa: E731
+    o1 = new16() if (mode in (F16_GEMM, F16_GEMM_ACT) or (mode == F16_CHAIN and want_t2)) else None
+    o2 = new16() if mode == F16_GEMM_ACT else None
+    P = torch.empty((M, J), dtype=torch.float32, device=dev) if mode in (F16_CHAIN, F16_THINN) else None
+    st = lib().indm_f16_rows(mode, _ptr16(A), _ptr16(Wp), _ptr16(D1), _ptr16(Pp), _ptr(P),
+                             o1.data_ptr() if o1 is not None else None, o2.data_ptr() if o2 is not None else None,
+                             _ptr(bias), _ptr(bias2), M, J, rows_per_group, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_rows")
+    if mode == F16_GEMM:
+        return o1
+    if mode == F16_GEMM_ACT:
+        return o1, o2
+    if mode == F16_CHAIN:
+        return P, o1
+    return P
 
 
 # --------------------------------------------------------------------------- block-level drivers (csrc/iresblock.hip)

@@ -1,0 +1,124 @@
+"""bf16-storage kernels of the residual flow (csrc/flow_f16.hip) against fp64 statements of the same contractions on
+bf16-rounded inputs: the F16 fragment layout itself, the skinny 3x3 convolution with its three epilogues, and the four
+modes of the 64-row kernel (GEMM, GEMM + Sin activation, the back-to-back chain link, the thin-N panel product)."""
+import math
+
+import pytest
+import torch
+
+import _emu
+from indm_amd import hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def r16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def f16_order(x):
+    """fp32 [M, N] -> the flat element order of the F16 layout (include/indm_hip.h), on the host"""
+    M, N = x.shape
+    v = x.view(M // 32, 32, N // 32, 2, 2, 2, 4)          # [mt, l31, nb, s, a, lhi, b]: n = 32 nb + 16 s + 8 a + 4 lhi + b
+    return v.permute(0, 2, 3, 5, 1, 4, 6).reshape(-1)     # [mt, nb, s, lhi, l31, a, b]
+
+
+def close16(got, ref, name, ulps=1.0, atol=1e-6):
+    """got: fp32 values of a bf16 result; ref: fp64.  One bf16 ulp = 2^-8 relative (round-to-nearest: half of it, plus
+    the accumulation-order noise of an fp32 MFMA chain)."""
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = (got - ref).abs()
+    bound = ulps * 2.0 ** -8 * ref.abs() + atol + 1e-3 * 2.0 ** -8 * ref.abs().max()
+    bad = (err > bound)
+    assert not bad.any(), f"{name}: {int(bad.sum())} of {bad.numel()} beyond {ulps} bf16 ulp; max err {err.max():.3e} (ref max {ref.abs().max():.3e})"
+
+
+@pytest.mark.parametrize("M,N", [(64, 512), (4096, 512), (96, 64)])
+def test_pack_unpack_layout(M, N):
+    x = rnd(M, N)
+    y = hip.f16_pack(x.to(DEV))
+    assert y.dtype == torch.bfloat16 and y.numel() == M * N
+    assert torch.equal(y.cpu().float(), f16_order(r16(x)))
+    assert torch.equal(hip.f16_unpack(y, M, N).cpu(), r16(x))
+
+
+def test_packed_weight_order():
+    w = rnd(512, 27, seed=3)
+    p = hip.pack_weight_bf16(w.to(DEV)).cpu().float().view(32, 1, 64, 8)
+    wp = torch.nn.functional.pad(r16(w), (0, 5))
+    for ks, lane, e in ((0, 0, 0), (3, 37, 5), (31, 63, 7), (17, 31, 2)):
+        k = 16 * ks + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3)
+        assert p[ks, 0, lane, e] == wp[k, lane & 31]
+
+
+@pytest.mark.parametrize("N,H,W,C", [(8, 32, 32, 3), (4, 16, 16, 12), (2, 64, 64, 3), (32, 16, 16, 1), (3 * 4, 32, 32, 3)])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_thin_conv(N, H, W, C, sign):
+    Co, M = 512, N * H * W
+    x, w, b = rnd(N, H, W, C), rnd(9 * C, Co, seed=1, scale=0.3), rnd(Co, seed=2)
+    ref = _emu.conv3x3_thin(r16(x).double(), r16(w).double(), sign) .reshape(M, Co) + b.double()
+    out = hip.f16_thin_conv(x.to(DEV), w.to(DEV), sign, hip.F16_PLAIN, bias=b.to(DEV))
+    assert out is not None
+    close16(hip.f16_unpack(out, M, Co), ref, "thin conv")
+    a, d = hip.f16_thin_conv(x.to(DEV), w.to(DEV), sign, hip.F16_ACT, bias=b.to(DEV))
+    close16(hip.f16_unpack(a, M, Co), torch.sin(2 * math.pi * ref) / (2 * math.pi), "thin conv sin", ulps=1.0, atol=3e-5)
+    close16(hip.f16_unpack(d, M, Co), torch.cos(2 * math.pi * ref), "thin conv cos", ulps=1.0, atol=2e-4)
+    g = rnd(M, Co, seed=5)
+    u, raw = hip.f16_thin_conv(x.to(DEV), w.to(DEV), sign, hip.F16_GATE, bias=b.to(DEV), gate=hip.f16_pack(g.to(DEV)),
+                               want_raw=True)
+    close16(hip.f16_unpack(raw, M, Co), ref, "thin conv raw")
+    close16(hip.f16_unpack(u, M, Co), ref * r16(g).double(), "thin conv gated", ulps=1.5)
+    u2, none = hip.f16_thin_conv(x.to(DEV), w.to(DEV), sign, hip.F16_GATE, bias=None, gate=hip.f16_pack(g.to(DEV)))
+    assert none is None
+    close16(hip.f16_unpack(u2, M, Co), (ref - b.double()) * r16(g).double(), "thin conv gated, no bias", ulps=1.5)
+
+
+def test_thin_conv_declines_uncovered_geometry():
+    assert hip.f16_thin_conv(rnd(2, 32, 32, 5).to(DEV), rnd(45, 512).to(DEV), -1) is None
+    assert hip.f16_thin_conv(rnd(1, 8, 8, 3).to(DEV), rnd(27, 512).to(DEV), -1) is None      # 64 pixels: M % 128
+
+
+@pytest.mark.parametrize("M", [64, 4096, 131072])
+def test_rows_gemm_and_activation(M):
+    K = N = 512
+    A, Wm, b, b2 = rnd(M, K), rnd(K, N, seed=1, scale=0.05), rnd(N, seed=2), rnd(M // 64, N, seed=3)
+    A16, Wp = hip.f16_pack(A.to(DEV)), hip.pack_weight_bf16(Wm.to(DEV))
+    idx = torch.arange(0, M, max(1, M // 512))
+    ref = r16(A)[idx].double() @ r16(Wm).double()
+    out = hip.f16_rows(hip.F16_GEMM, A16, M, Wp=Wp)
+    close16(hip.f16_unpack(out, M, N)[idx.to(DEV)], ref, "rows gemm", atol=1e-5)
+    refb = ref + b.double() + b2.double()[idx // 64]
+    out = hip.f16_rows(hip.F16_GEMM, A16, M, Wp=Wp, bias=b.to(DEV), bias2=b2.to(DEV), rows_per_group=64)
+    close16(hip.f16_unpack(out, M, N)[idx.to(DEV)], refb, "rows gemm + biases", atol=1e-5)
+    a, d = hip.f16_rows(hip.F16_GEMM_ACT, A16, M, Wp=Wp, bias=b.to(DEV), bias2=b2.to(DEV), rows_per_group=64)
+    close16(hip.f16_unpack(a, M, N)[idx.to(DEV)], torch.sin(2 * math.pi * refb) / (2 * math.pi), "rows act sin", atol=3e-5)
+    close16(hip.f16_unpack(d, M, N)[idx.to(DEV)], torch.cos(2 * math.pi * refb), "rows act cos", atol=2e-4)
+
+
+@pytest.mark.parametrize("M,J", [(64, 27), (4096, 27), (8192, 108), (131072, 27), (32768, 108)])
+def test_rows_chain_and_thin_n(M, J):
+    K = N = 512
+    A, Wm, D1 = rnd(M, K), rnd(K, N, seed=1, scale=0.05), rnd(M, N, seed=4)
+    panel = rnd(N, J, seed=6, scale=0.1)
+    A16, D16 = hip.f16_pack(A.to(DEV)), hip.f16_pack(D1.to(DEV))
+    Wp, Pp = hip.pack_weight_bf16(Wm.to(DEV)), hip.pack_weight_bf16(torch.nn.functional.pad(panel, (0, (32 if J <= 32 else 128) - J)).to(DEV))
+    idx = torch.cat([torch.arange(0, M, max(1, M // 256)), torch.arange(max(0, M - 70), M)]).unique()
+    t2 = r16(A)[idx].double() @ r16(Wm).double()
+    u1 = r16((t2 * r16(D1)[idx].double()).float()).double()       # the gated intermediate is rounded to bf16 for the second MFMA
+    refP = u1 @ r16(panel).double()
+    P, t2o = hip.f16_rows(hip.F16_CHAIN, A16, M, Wp=Wp, D1=D16, Pp=Pp, J=J, want_t2=True)
+    scale = refP.abs().max().item()
+    assert (P[idx.to(DEV)].cpu().double() - refP).abs().max().item() <= 4e-3 * scale, "chain P"
+    close16(hip.f16_unpack(t2o, M, N)[idx.to(DEV)], t2, "chain t2", atol=1e-5)
+    P2, none = hip.f16_rows(hip.F16_CHAIN, A16, M, Wp=Wp, D1=D16, Pp=Pp, J=J)
+    assert none is None and torch.equal(P2, P)
+    refT = r16(A)[idx].double() @ r16(panel).double()
+    T = hip.f16_rows(hip.F16_THINN, A16, M, Pp=Pp, J=J)
+    assert (T[idx.to(DEV)].cpu().double() - refT).abs().max().item() <= 1e-4 * refT.abs().max().item() + 1e-5, "thin-N"
