@@ -345,7 +345,10 @@ typedef struct {
   int N, H, W, C, idim; /* block input [N,H,W,C]; width of the g-net (512) */
   int preact;           /* the block starts with a Sin activation (every block but the flow's first) */
   int training;         /* 1: Neumann surrogate + tensors saved for indm_iresblock_bwd; 0: power series, nothing saved */
-  int bf16;             /* 0: exact fp32 MFMA; 1: MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate) */
+  int bf16;             /* 0: exact fp32 MFMA; 1: MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate);
+                         * 2: bf16 STORAGE as well -- a1, d1, a2, d2, t3, t2 are F16 buffers (bf16 in MFMA-fragment order,
+                         * N H W idim elements each; see the F16 section above), the kernels are csrc/flow_f16.hip's, and the
+                         * packed weights W2T_bf16w, W2_bf16w, panel_bf16w, W3_bf16w must be given */
   const float* x;       /* [N,H,W,C] */
   const float* cb;      /* [N, idim] folded conditioning bias Linear(h) W2 (lipschitz.py:429-435) */
   const float* W1;      /* [3,3,C,idim] RSCK == [(tap,c), idim] */
@@ -368,6 +371,10 @@ typedef struct {
   float* ws; long ws_floats;
   float* splitk_ws; long splitk_ws_floats;
   void* timer;          /* optional indm_timer handle: HIP events around the chain-kernel launches (bench roofline) */
+  /* bf16 = 2 only: weights in the packed bf16 fragment order (F16 section above) */
+  const void* W2_bf16w;    /* W2 [idim, idim] (= [Cin, Cout]) */
+  const void* panel_bf16w; /* `panel` */
+  const void* W3_bf16w;    /* W3_ci_tapco zero-padded to [idim, 32 | 128] */
 } indm_iresblock_fwd_args;
 
 /* Backward of the training-mode block (replaces autograd's double backward through iresblock.py:264-273 and g's own
@@ -383,12 +390,14 @@ typedef struct {
   float *dx, *dcb, *dW1, *dW2, *dW3, *dW2T, *db1, *db2, *db3;
   float* ws; long ws_floats;
   float* splitk_ws; long splitk_ws_floats;
+  /* bf16 = 2 only (a1, d1, a2, d2, t3, t2 are F16 buffers): packed weights */
+  const void *W2_bf16w, *W2T_bf16w, *panel_bf16w;
 } indm_iresblock_bwd_args;
 
 /* Fixed-point inverse x <- y - g(x) (iresblock.py:78-88): iterates until every element passes
  * (dx)^2 / (atol + |y| rtol) < 1 or 1000 iterations; reads ONE device scalar per iteration (the reference's torch.all).
  * Uses the forward argument block: x = y (input), y = x_out (output); eps / coeffs / logdet / saved tensors unused. */
-long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int which /* 0 fwd train, 1 fwd eval, 2 bwd, 3 inverse */);
+long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int which /* 0 fwd train, 1 fwd eval, 2 bwd, 3 inverse; +16: the bf16 = 2 form */);
 int indm_iresblock_fwd_logdet(const indm_iresblock_fwd_args* a, void* stream);
 int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream);
 int indm_iresblock_inverse(const indm_iresblock_fwd_args* a, float atol, float rtol, int* iterations, void* stream);

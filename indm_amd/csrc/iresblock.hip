@@ -145,7 +145,12 @@ static int permute021_add(const float* x, const float* x2, const float* y, float
 INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int which) {
   const long M = (long)N * H * W, nC = pad64(M * C), nW = pad64(M * idim), nP = pad64(M * 9 * C);
   const long red = pad64(indm_rowreduce_ws_floats(N, (long)H * W * C)) + pad64(N);
+  const long nH = pad64(M * idim / 2);   // one F16 [M, idim] tensor, in floats
   switch (which) {
+    case 16:  // forward, training, bf16 storage: u2 (F16) + Pn, g, v, wtmp + reductions
+      return nH + nP + 4 * nC + red + 64;
+    case 17:  // forward, eval, bf16 storage: + a0, d0 (fp32) and a1, d1, a2, d2 (F16) live here
+      return nH + nP + 3 * nC + red + 2 * nC + 4 * nH + 64;
     case 0:  // forward, training: p, Pn, g, v, wtmp, vj + reductions
       return nW + nP + 4 * nC + red + 64;
     case 1:  // forward, eval: + a0,d0,a1,d1,a2,d2,t3 live here
@@ -161,9 +166,136 @@ INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int
   }
 }
 
+// ---- bf16 storage (args.bf16 == 2): the same block on the F16 kernels of flow_f16.hip ---------------------------------
+// The [M, 512] tensors live in HBM as bf16 in MFMA-fragment order; pre-activations are never stored (the Sin activation is
+// the epilogue of the contraction that produces them), the d2 gate of a chain link is applied by the thin transposed
+// convolution that produces t3 (so the chain kernel's main loop multiplies fragments as they come out of LDS), the d1 gate
+// by the chain kernel on its accumulators.  Per series iteration: 134 MB written + 134 MB read by the thin convolution,
+// 268 MB read by the chain kernel at batch 128 (fp32 tensors: 268 written, 805 read).
+namespace {
+enum { F16_PLAIN = 0, F16_ACT = 1, F16_GATE = 2, F16R_GEMM = 0, F16R_GEMM_ACT = 1, F16R_CHAIN = 2, F16R_THINN = 3 };
+
+struct Ctx16 {
+  int N, H, W, C, Cw;
+  long M;
+  void* st;
+  Timer* timer;
+  int thin(const float* x, const float* w2d, const float* bias, const void* gate, void* o1, void* o2, int sign, int epi) const {
+    return indm_f16_thin_conv(x, w2d, bias, gate, o1, o2, N, H, W, C, Cw, sign, epi, st);
+  }
+  int chain(const void* u2, const void* W2Tp, const void* d1, const void* panelp, float* P, void* t2) const {
+    const int J = 9 * C;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timer) {
+      const int cls = (J <= 32 ? 0 : 2) + (t2 ? 1 : 0);
+      if (((timer->mask >> cls) & 1) && timer->used + 2 <= (int)timer->ev.size()) {
+        e0 = timer->ev[timer->used];
+        e1 = timer->ev[timer->used + 1];
+      }
+    }
+    if (e0) (void)hipEventRecord(e0, (hipStream_t)st);
+    const int r = indm_f16_rows(F16R_CHAIN, u2, W2Tp, d1, panelp, P, t2, nullptr, nullptr, nullptr, (int)M, J, 1, st);
+    if (e0) {
+      (void)hipEventRecord(e1, (hipStream_t)st);
+      timer->used += 2;
+      timer->flops += 2.0 * (double)M * Cw * (Cw + J);
+    }
+    return r;
+  }
+};
+
+static bool covered16(int N, int H, int W, int C, int idim) {
+  const long M = (long)N * H * W;
+  return idim == 512 && (C <= 3 || (C <= 12 && !(C & 3))) && M >= 1024 && !(M % 128) && !(((long)H * W) % 64) &&
+         M * 9 * C < (1L << 31);
+}
+
+// g(x, h) on F16 tensors: fills a0, d0 (preact, fp32), a1, d1, a2, d2 (F16) and g (fp32) [+ y = x + g]
+static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb, const float* W1, const void* W2p,
+                    const void* W3p, const float* b1, const float* b2, const float* b3, float* a0, float* d0, void* a1, void* d1,
+                    void* a2, void* d2, float* Pn, float* g, float* y_res) {
+  const long nC = c.M * c.C;
+  const float* in = x;
+  if (preact) {
+    TRY(indm_sincos_act_fwd_f32(x, a0, d0, nC, c.st));
+    in = a0;
+  }
+  TRY(c.thin(in, W1, b1, nullptr, a1, d1, -1, F16_ACT));                                     // (a1, d1) = Sin(conv(a0, W1) + b1)
+  TRY(indm_f16_rows(F16R_GEMM_ACT, a1, W2p, nullptr, nullptr, nullptr, a2, d2, b2, cb, (int)c.M, 0, c.H * c.W, c.st));   // Sin(a1 W2 + b2 + cb[n])
+  TRY(indm_f16_rows(F16R_THINN, a2, nullptr, nullptr, W3p, Pn, nullptr, nullptr, nullptr, nullptr, (int)c.M, 9 * c.C, 1, c.st));
+  if (y_res) TRY(indm_tap_gather_acc_f32(Pn, b3, nullptr, g, x, y_res, 1.0f, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
+  else TRY(indm_tap_gather_f32(Pn, b3, g, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
+  return 0;
+}
+
+static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
+  if (!covered16(a->N, a->H, a->W, a->C, a->idim) || !a->panel) return 1;
+  if (!a->x || !a->cb || !a->W1 || !a->W3_tapco_ci || !a->b1 || !a->b2 || !a->b3 || !a->eps || !a->y || !a->logdet ||
+      !a->W2T_bf16w || !a->W2_bf16w || !a->panel_bf16w || !a->W3_bf16w || (a->ncoeff > 0 && !a->coeffs) || a->ncoeff < 0)
+    return INDM_E_ARG;
+  Ctx16 c = {a->N, a->H, a->W, a->C, a->idim, (long)a->N * a->H * a->W, stream, (Timer*)a->timer};
+  const long nC = c.M * c.C, nP = c.M * 9 * c.C, nH = c.M * c.Cw / 2;
+  Bump ws = {a->ws, a->ws_floats, 0};
+  float *a0 = a->a0, *d0 = a->d0;
+  void *a1 = a->a1, *d1 = a->d1, *a2 = a->a2, *d2 = a->d2;
+  if (a->training) {
+    if (!a1 || !d1 || !a2 || !d2 || !a->t3 || !a->t2 || !a->w || (a->preact && (!a0 || !d0 || !a->c1))) return INDM_E_ARG;
+  } else {
+    if (a->preact) { a0 = ws.get(nC); d0 = ws.get(nC); }
+    a1 = ws.get(nH); d1 = ws.get(nH); a2 = ws.get(nH); d2 = ws.get(nH);
+  }
+  void* u2 = ws.get(nH);
+  float *Pn = ws.get(nP), *g = ws.get(nC), *v = ws.get(nC);
+  float* rws = ws.get(indm_rowreduce_ws_floats(c.N, (long)c.H * c.W * c.C));
+  if (!u2 || !Pn || !g || !v || !rws || (!a->training && (!a1 || !d2 || (a->preact && !d0)))) return INDM_E_ARG;
+  const int K = a->ncoeff;
+  TRY(g_pass16(c, a->preact, a->x, a->cb, a->W1, a->W2_bf16w, a->W3_bf16w, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2, Pn, g, a->y));
+  const float* gate0 = a->preact ? d0 : nullptr;
+  if (a->training) {
+    float* wtmp = ws.get(nC);
+    if (!wtmp) return INDM_E_ARG;
+    const float *vin = a->eps, *win = a->eps;
+    for (int k = 0; k < K; ++k) {
+      float* wout = ((K - 1 - k) & 1) ? wtmp : a->w;
+      TRY(c.thin(vin, a->W3_tapco_ci, nullptr, d2, u2, nullptr, 1, F16_GATE));            // u2 = (C3^T v) .* d2
+      TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, nullptr));
+      TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, win, wout, a->coeffs[k], c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+      vin = v;
+      win = wout;
+    }
+    if (K == 0 && hipMemcpyAsync(a->w, a->eps, nC * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+      return INDM_E_LAUNCH;
+    TRY(c.thin(a->w, a->W3_tapco_ci, nullptr, d2, u2, a->t3, 1, F16_GATE));               // ... and t3 itself, saved
+    TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, a->t2));
+    if (a->preact) {
+      TRY(indm_tap_gather_f32(Pn, nullptr, a->c1, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+      TRY(indm_mul_f32(a->c1, d0, g, 1.0f, nC, stream));
+    } else {
+      TRY(indm_tap_gather_f32(Pn, nullptr, g, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+    }
+    TRY(indm_rowreduce_f32(g, a->eps, a->logdet, c.N, (long)c.H * c.W * c.C, 0, 1.0f, rws, stream));
+    return INDM_OK;
+  }
+  float* tr = ws.get(c.N);
+  if (!tr) return INDM_E_ARG;
+  const float* vin = a->eps;
+  for (int k = 0; k < K; ++k) {
+    TRY(c.thin(vin, a->W3_tapco_ci, nullptr, d2, u2, nullptr, 1, F16_GATE));
+    TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, nullptr));
+    TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, nullptr, nullptr, 0.0f, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
+    vin = v;
+    TRY(indm_rowreduce_f32(v, a->eps, k == 0 ? a->logdet : tr, c.N, (long)c.H * c.W * c.C, 0, a->coeffs[k], rws, stream));
+    if (k > 0) TRY(indm_axpby_f32(a->logdet, tr, a->logdet, 1.0f, 1.0f, 0.0f, c.N, stream));
+  }
+  if (K == 0 && hipMemsetAsync(a->logdet, 0, c.N * sizeof(float), (hipStream_t)stream) != hipSuccess) return INDM_E_LAUNCH;
+  return INDM_OK;
+}
+}  // namespace
+
 INDM_API int indm_iresblock_fwd_logdet(const indm_iresblock_fwd_args* a, void* stream) {
   if (!a) return INDM_E_ARG;
   if (a->N <= 0) return INDM_OK;
+  if (a->bf16 == 2) return fwd_logdet_f16(a, stream);
   if (!covered(a->N, a->H, a->W, a->C, a->idim) || !a->panel) return 1;
   if (!a->x || !a->cb || !a->W1 || !a->W2T || !a->W3_ci_tapco || !a->W3_tapco_ci || !a->b1 || !a->b2 || !a->b3 ||
       !a->eps || !a->y || !a->logdet || (a->ncoeff > 0 && !a->coeffs) || a->ncoeff < 0)

@@ -7,6 +7,7 @@
 // Layout: activations are [N, HW, C] with C contiguous, so every wave reads whole 256 B+
 // rows (float4 per lane); group statistics use wavefront shuffles + one LDS hop.
 #include "indm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -477,6 +478,8 @@ __global__ __launch_bounds__(256) void gn_cpart_reduce_kernel(const float* __res
 struct GnFused { int gs, bs, nf4; };
 static GnFused gn_fused_geom(int HW, int C, int G) {
   GnFused f = {0, 0, 0};
+  static const int mode = getenv("INDM_GN_FUSED") ? atoi(getenv("INDM_GN_FUSED")) : 1;   // 0: three-kernel passes (probes)
+  if (!mode) return f;
   const int cpg = C / G;
   if (cpg < 4 || (cpg & 3)) return f;
   int gs = cpg >= 12 ? 1 : (16 / cpg);

@@ -179,7 +179,8 @@ class IResBlock(nn.Module):
             # the whole block as ONE C-ABI call (indm_iresblock_fwd_logdet, eval mode); same kernels as below
             c1, c2, c3 = self.convs
             out = hip.iresblock_fwd(_cc(x), _cc(cb), _cc(W[0]), _cc(W[3]), W[2], W[4], c1.bias, c2.bias, c3.bias, eps,
-                                    [(-1) ** (k + 1) / k * coeff(k) for k in range(1, K + 1)], self.preact, False)
+                                    [(-1) ** (k + 1) / k * coeff(k) for k in range(1, K + 1)], self.preact, False,
+                                    W2=_cc(W[1]))
             if out is not None:
                 return out[0], out[1]
         g, gates = self.g(x, cb, W, True)
@@ -245,7 +246,7 @@ class _IResTrain(torch.autograd.Function):
         ctx.driver = False
         if hip.block_drivers() and x.is_cuda and panel is not None:
             # the whole block as ONE C-ABI call (indm_iresblock_fwd_logdet): the launch sequence below, enqueued from C++
-            out = hip.iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, blk.preact, True)
+            out = hip.iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, blk.preact, True, W2=W2)
             if out is not None:
                 y, logdet, (a0, d0, a1, d1, a2, d2, t3, t2, c1, w) = out
                 ctx.save_for_backward(a0, d0, a1, d1, a2, d2, t3, t2, c1, w, eps, W1, W2, W3, W2T)
@@ -291,6 +292,11 @@ class _IResTrain(torch.autograd.Function):
         a0, d0, a1, d1, a2, d2, t3, t2, c1, w, eps, W1, W2, W3, W2T = ctx.saved_tensors
         preact, hw = ctx.cfg
         N, H, Wd, C = eps.shape
+        if a1.dtype == torch.bfloat16:
+            # bf16 storage (F16 buffers from the forward driver): until the backward has its own F16 kernels the saved
+            # tensors are unpacked to fp32 here
+            Cw_ = W2.shape[0]
+            a1, d1, a2, d2, t3, t2 = (hip.f16_unpack(t, N * H * Wd, Cw_).view(N, H, Wd, Cw_) for t in (a1, d1, a2, d2, t3, t2))
         Cw = a1.shape[-1]
         rps = H * Wd
         seg_ok = rps % 64 == 0
@@ -401,6 +407,8 @@ class ResidualFlow(nn.Module):
         w2ts = w2.transpose(1, 2).contiguous().unbind(0)   # W2^T of every block, one launch (used by the VJP chains)
         if hip.compute_dtype() == "bf16":
             hip.pack_w2t_bf16(list(w2ts))   # bf16 fragment-order copies for the chain kernel (two launches)
+            if hip.storage_dtype() == "bf16":
+                hip.pack_w2t_bf16([W[1] for W in Ws])   # ... and of W2 for the F16 kernels (csrc/flow_f16.hip)
         # W1 of every block as the [idim, 32 | 128] zero-padded panel of the back-to-back chain kernel (no-grad series
         # iterations only): one stack + transpose + pad per scale
         panels = {}
@@ -415,8 +423,12 @@ class ResidualFlow(nn.Module):
                 if hip._skinny(3, 3, 1, 1, C_, I_) and 9 * C_ <= 128:
                     pn = torch.nn.functional.pad(w1.reshape(nb_, 9 * C_, I_).transpose(1, 2),
                                                  (0, (32 if 9 * C_ <= 32 else 128) - 9 * C_)).contiguous()
-                    for b, q in zip(sc, pn.unbind(0)):
+                    qs = pn.unbind(0)
+                    for b, q in zip(sc, qs):
                         panels[b] = q
+                    if hip.storage_dtype() == "bf16":   # the thin-N panels of the F16 kernels: W1^T and W3 as [idim, 9C]
+                        hip.pack_w2t_bf16(list(qs))
+                        hip.pack_w2t_bf16([hip._packed_weight(Ws[blks.index(b)][2], "ci_tapco") for b in sc])
         return {b: (list(W) + [w2ts[i], panels.get(b)], cbs[i]) for i, (b, W) in enumerate(zip(blks, Ws))}
 
     def fwdpass(self, x, h, eval_logdet, rng, stats=None):

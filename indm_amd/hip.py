@@ -342,9 +342,19 @@ def compute_dtype():
     return _MFMA["dtype"]
 
 
+F16_STORAGE = {"on": os.environ.get("INDM_F16_STORAGE", "1") != "0"}   # tools / tests: bf16 compute on fp32 tensors
+
+
 def storage_dtype():
-    """'bf16' when the flow's 512-wide tensors live in HBM as bf16 (bf16 compute mode on the block drivers), else 'f32'"""
-    return _MFMA.get("storage", "f32") if _MFMA["dtype"] == "bf16" else "f32"
+    """'bf16' when the flow's 512-wide tensors live in HBM as bf16 (bf16 compute mode on the block drivers: F16 fragment
+    order, csrc/flow_f16.hip), else 'f32'"""
+    return "bf16" if (_MFMA["dtype"] == "bf16" and F16_STORAGE["on"] and BLOCK_DRIVERS["on"]) else "f32"
+
+
+def f16_storage(on=None):
+    if on is not None:
+        F16_STORAGE["on"] = bool(on)
+    return F16_STORAGE["on"]
 
 
 def _dense(name):
@@ -743,21 +753,35 @@ _w2t_packed = {}  # id(w2t) -> (weakref, version, packed bf16 copy)
 
 
 def pack_w2t_bf16(w2ts):
-    """bf16 MFMA-fragment-order copies of a list of same-shape [K, 512] fp32 weights (two launches for the whole list),
-    registered for ires_chain's bf16 path:  out[s][b][lane][e] = bf16(w[16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 b + (lane & 31)])."""
+    """bf16 MFMA-fragment-order copies of a list of same-shape [K, N] fp32 weights (two launches for the whole list; N is
+    zero-padded to a multiple of 32), registered for the bf16 chain / F16 kernels:
+    out[s][b][lane][e] = bf16(w[16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 b + (lane & 31)])."""
     import weakref
     if not w2ts:
         return
     K, N = w2ts[0].shape
-    if K % 16 or N % 32:
+    if K % 16:
         return
     with torch.no_grad():
-        st = torch.stack([w.detach() for w in w2ts]).to(torch.bfloat16)                      # [n, K, N]
+        st = torch.stack([w.detach() for w in w2ts])
+        if N % 32:
+            st = torch.nn.functional.pad(st, (0, 32 - N % 32))
+            N = st.shape[-1]
+        st = st.to(torch.bfloat16)                                                            # [n, K, N]
         pk = st.view(len(w2ts), K // 16, 2, 2, 4, N // 32, 32).permute(0, 1, 5, 3, 6, 2, 4).contiguous()
     for k in [k for k, v in _w2t_packed.items() if v[0]() is None]:   # drop the copies of weights that no longer exist
         del _w2t_packed[k]
     for i, w in enumerate(w2ts):
         _w2t_packed[id(w)] = (weakref.ref(w), w._version, pk[i])
+
+
+def packed_bf16(w):
+    """the registered packed copy of w (pack_w2t_bf16), packing it now if the flow's prepare() did not"""
+    hit = _w2t_packed.get(id(w))
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        pack_w2t_bf16([w])
+        hit = _w2t_packed[id(w)]
+    return hit[2]
 
 
 def ires_chain(t3, d2, w2t, d1, w1p, J, want_t2=False):
@@ -1321,7 +1345,8 @@ class _IResFwdArgs(ctypes.Structure):
                                       "b3", "eps", "coeffs")]
                 + [("ncoeff", c_i)]
                 + [(n, c_p) for n in ("y", "logdet", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w")]
-                + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("timer", c_p)])
+                + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("timer", c_p)]
+                + [(n, c_p) for n in ("W2_bf16w", "panel_bf16w", "W3_bf16w")])
 
 
 class _IResBwdArgs(ctypes.Structure):
@@ -1329,7 +1354,8 @@ class _IResBwdArgs(ctypes.Structure):
     _fields_ = ([(n, c_i) for n in ("N", "H", "W", "C", "idim", "preact", "bf16")]
                 + [(n, c_p) for n in ("gy", "gld", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w", "eps", "W1", "W2",
                                       "W2T", "W3_tapco_ci", "dx", "dcb", "dW1", "dW2", "dW3", "dW2T", "db1", "db2", "db3")]
-                + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l)])
+                + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l)]
+                + [(n, c_p) for n in ("W2_bf16w", "W2T_bf16w", "panel_bf16w")])
 
 
 BLOCK_DRIVERS = {"on": os.environ.get("INDM_BLOCK_DRIVERS", "1") != "0"}   # tools / tests switch to the op-level composition
@@ -1397,23 +1423,35 @@ def _w2t_bf16w(w2t):
     return None
 
 
-def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, training):
+def _f16_geometry(N, H, W, C, idim):
+    M = N * H * W
+    return (idim == 512 and (C <= 3 or (C <= 12 and C % 4 == 0)) and M >= 1024 and M % 128 == 0 and (H * W) % 64 == 0
+            and M * 9 * C < (1 << 31))
+
+
+def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, training, W2=None):
     """One iResBlock forward + log-det estimate through indm_iresblock_fwd_logdet.
     -> None if the geometry is not covered, else (y, logdet, saved) with saved = the tensors the backward needs
-    (training) or None (eval)."""
+    (training) or None (eval).  With bf16 storage (storage_dtype() == 'bf16', W2 given, geometry covered) the saved
+    [N,H,W,idim] tensors are F16 buffers (flat bfloat16 tensors in MFMA-fragment order)."""
     N, H, W, C = x.shape
     idim = W2T.shape[0]
     if panel is None:
         return None
     dev = x.device
     M = N * H * W
+    f16 = storage_dtype() == "bf16" and W2 is not None and _f16_geometry(N, H, W, C, idim)
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
     a = _IResFwdArgs()
     a.N, a.H, a.W, a.C, a.idim, a.preact, a.training = N, H, W, C, idim, int(preact), int(training)
-    a.bf16 = int(_MFMA["dtype"] == "bf16")
+    a.bf16 = 2 if f16 else int(_MFMA["dtype"] == "bf16")
     a.x, a.cb, a.W1, a.W2T = _ptr(x), _ptr(cb), _ptr(W1), _ptr(W2T)
     a.W2T_bf16w = _w2t_bf16w(W2T)
-    a.W3_ci_tapco, a.W3_tapco_ci = _ptr(_packed_weight(W3, "ci_tapco")), _ptr(_packed_weight(W3, "tapco_ci"))
+    w3ct = _packed_weight(W3, "ci_tapco")
+    a.W3_ci_tapco, a.W3_tapco_ci = _ptr(w3ct), _ptr(_packed_weight(W3, "tapco_ci"))
+    if f16:
+        keep = [packed_bf16(W2T), packed_bf16(W2), packed_bf16(panel), packed_bf16(w3ct)]   # alive until the call returns
+        a.W2T_bf16w, a.W2_bf16w, a.panel_bf16w, a.W3_bf16w = (t.data_ptr() for t in keep)
     a.panel, a.b1, a.b2, a.b3, a.eps = _ptr(panel), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(eps)
     cf = (ctypes.c_float * max(1, len(coeffs)))(*coeffs)
     a.coeffs, a.ncoeff = ctypes.cast(cf, c_p), len(coeffs)
@@ -1422,13 +1460,16 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     saved = None
     if training:
         a0, d0, c1 = (new(N, H, W, C), new(N, H, W, C), new(N, H, W, C)) if preact else (x, None, None)
-        a1, d1, a2, d2, t3, t2 = (new(N, H, W, idim) for _ in range(6))
+        if f16:
+            a1, d1, a2, d2, t3, t2 = (torch.empty(M * idim, dtype=torch.bfloat16, device=dev) for _ in range(6))
+        else:
+            a1, d1, a2, d2, t3, t2 = (new(N, H, W, idim) for _ in range(6))
         w = new(N, H, W, C)
         if preact:
             a.a0, a.d0, a.c1 = a0.data_ptr(), d0.data_ptr(), c1.data_ptr()
         a.a1, a.d1, a.a2, a.d2, a.t3, a.t2, a.w = (t.data_ptr() for t in (a1, d1, a2, d2, t3, t2, w))
         saved = (a0, d0, a1, d1, a2, d2, t3, t2, c1, w)
-    ws, n = _ires_ws(N, H, W, C, idim, 0 if training else 1, dev)
+    ws, n = _ires_ws(N, H, W, C, idim, (0 if training else 1) + (16 if f16 else 0), dev)
     a.ws, a.ws_floats = ws.data_ptr(), n
     sk = _ws(SPLITK_WS_FLOATS, dev)
     a.splitk_ws, a.splitk_ws_floats = sk.data_ptr(), SPLITK_WS_FLOATS

@@ -45,11 +45,13 @@ def test_training_block_driver_is_bit_identical_to_op_level(drivers, dtype):
     cfg, fl = _flow()
     x = torch.rand(4, 3, 32, 32, device=DEV) * 2 - 1
     hip.set_compute_dtype(dtype)
+    was = hip.f16_storage(False)   # like with like: bf16 MFMA inputs on fp32 tensors (the F16 storage form has its own test)
     try:
         z1, ld1, g1 = _train_pass(cfg, fl, x, True)
         z0, ld0, g0 = _train_pass(cfg, fl, x, False)
     finally:
         hip.set_compute_dtype("f32")
+        hip.f16_storage(True)
     assert torch.equal(z1, z0) and torch.equal(ld1, ld0)
     assert set(g1) == set(g0) and len(g1) > 200
     for n in g0:
@@ -98,3 +100,42 @@ def test_eval_logdet_and_inverse_drivers_match_op_level(drivers):
     assert (ld1 - ld0).abs().max().item() <= 1e-5 * ld0.abs().max().item() + 1e-5
     assert it1 == it0
     assert (x1 - x0).abs().max().item() <= 1e-5
+
+
+def _rel(a, b):
+    return (a - b).norm().item() / (b.norm().item() + 1e-30)
+
+
+@pytest.mark.parametrize("B", [4, 16])
+def test_bf16_storage_block_tracks_bf16_compute_on_fp32_tensors(drivers, B):
+    """bf16 STORAGE of the flow's 512-wide tensors (F16 fragment order, csrc/flow_f16.hip: activations rounded to bf16
+    once more than the compute-only mode, hardware sine / cosine, gates applied at other points of the chain) against the
+    bf16-compute / fp32-tensor drivers and the fp32 drivers on the same weights and noise: outputs, log-dets and every
+    parameter gradient."""
+    cfg, fl = _flow()
+    x = torch.rand(B, 3, 32, 32, device=DEV) * 2 - 1
+    try:
+        hip.set_compute_dtype("bf16")
+        hip.f16_storage(True)
+        assert hip.storage_dtype() == "bf16"
+        z2, ld2, g2 = _train_pass(cfg, fl, x, True)
+        hip.f16_storage(False)
+        z1, ld1, g1 = _train_pass(cfg, fl, x, True)
+        hip.set_compute_dtype("f32")
+        z0, ld0, g0 = _train_pass(cfg, fl, x, True)
+    finally:
+        hip.set_compute_dtype("f32")
+        hip.f16_storage(True)
+    assert torch.isfinite(z2).all() and torch.isfinite(ld2).all()
+    # the flow's output is x + sum of 32 small residuals: absolute agreement far below a bf16 ulp of the values
+    assert (z2 - z0).abs().max().item() <= 2e-3, (z2 - z0).abs().max().item()
+    e1, e2 = (ld1 - ld0).abs().max().item(), (ld2 - ld0).abs().max().item()
+    scale = ld0.abs().max().item()
+    assert e2 <= max(3.0 * e1, 2e-2 * scale) + 1e-3, (e1, e2, scale)
+    assert set(g2) == set(g0)
+    worst = []
+    for n in g0:
+        r1, r2 = _rel(g1[n], g0[n]), _rel(g2[n], g0[n])
+        worst.append((r2, r1, n))
+        assert r2 <= max(4.0 * r1, 3e-2), (n, r1, r2)
+    print("largest relative gradient errors (storage, compute-only, name):", sorted(worst, reverse=True)[:5])
