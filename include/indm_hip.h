@@ -109,6 +109,7 @@ int indm_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int Nimg,
 /* GroupNorm(G, C, eps) [+SiLU] [+Philox dropout], fused.  Replaces nn.GroupNorm + nn.SiLU + nn.Dropout at
  * models/layerspp.py:232,244,256,277-278, models/layers.py:38-39.  act 0 none / 1 SiLU. */
 long indm_groupnorm_ws_floats(int N, int HW, int C, int G);
+int indm_groupnorm_fused(int HW, int C, int G); /* 1: single-pass register-resident kernels for this geometry, 0: stats / finalize / apply */
 int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                            float* rstd, int N, int HW, int C, int G, float eps, int act, float drop_p,
                            unsigned long long seed, float* ws, void* stream);
@@ -209,6 +210,25 @@ int indm_f16_thin_conv(const float* x, const float* w, const float* bias, const 
  * Wp: packed [512, 512]; Pp: packed [512, 32 | 128] panel (J <= 32 | J <= 128), P fp32 row-major.  Returns 1 if not covered. */
 int indm_f16_rows(int mode, const void* A, const void* Wp, const void* D1, const void* Pp, float* P, void* out1, void* out2,
                   const float* bias, const float* bias2, int M, int J, int rows_per_group, void* stream);
+
+/* One Sin level of the hand-written iResBlock backward on F16 tensors (the F16 form of indm_ires_bwd_act_f32; replaces
+ * autograd over iresblock.py:253-273's double backward): dp = da .* d - 4 pi^2 a .* (du .* t); seg (optional, fp32
+ * [R / rows_per_seg][512]) = per-image column sums of dp.  rows_per_seg % 128 == 0 (indm_f16_bwd_act_ok), else returns 1. */
+long indm_f16_bwd_act_ok(long R, long rows_per_seg);
+int indm_f16_bwd_act(const void* da, const void* du, const void* d, const void* a, const void* t, void* dp, float* seg,
+                     long R, long rows_per_seg, void* stream);
+/* Weight gradients = contractions over the ROWS of F16 [M, 512] tensors (autograd of F.conv2d / the 1x1 convolutions of
+ * lipschitz.py:361-363,429-435 w.r.t. their weights), deterministic split over the rows into ws (indm_f16_wgrad_ws_floats(M, T),
+ * T = 0 for the GEMM form):
+ *   thin:  out[t][n] = alpha sum_m thin[m][t] (wide .* gate)[m][n]   thin fp32 [M, T] (T <= 128: the tap-spread skinny side),
+ *          wide / gate F16; transpose = 1 writes out[n][t]; ldo = row stride of out
+ *   gemm:  out[n1][n2] = alpha sum_m (X .* gateX)[m][n1] Y[m][n2]     (transpose = 1: out[n2][n1])
+ * M % 32 == 0; returns 1 if not covered. */
+long indm_f16_wgrad_ws_floats(long M, int T);
+int indm_f16_thin_wgrad(const float* thin, const void* wide, const void* gate, float* out, long M, int T, float alpha,
+                        int transpose, long ldo, float* ws, long ws_floats, void* stream);
+int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y, float* out, long M, float alpha, int transpose,
+                        float* ws, long ws_floats, void* stream);
 
 /* act 1 SiLU (models/layers.py:38-39), 2 ELU (resnet_batchnorm.py:27) */
 int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);

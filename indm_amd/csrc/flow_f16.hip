@@ -482,6 +482,292 @@ int launch_thin_conv_e(const ThinConvArgs& a, dim3 grid, hipStream_t st) {
   return launch_thin_conv<EPI, 7, true>(a, grid, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// f16_bwd_act_kernel: one Sin level of the iResBlock's hand-written backward on F16 tensors (the F16 form of
+// indm_ires_bwd_act_f32):  dp = da .* d - 4 pi^2 a .* (du .* t), seg[img][n] = sum over the rows of image img of dp.
+// All five inputs and dp share the F16 layout, so the kernel walks 16-byte groups; a workgroup owns (image, column block,
+// half s) and its four waves a quarter of the image's 32-row blocks each; the column sums come out of registers
+// (butterfly over the 32 row lanes, then the four waves in a fixed order: deterministic).
+struct BwdActArgs {
+  const u16 *da, *du, *d, *a, *t;
+  u16* dp;
+  float* seg;     // [nseg][512] or null
+  int mts;        // 32-row blocks per segment (rows_per_seg / 32), a multiple of 4
+};
+__global__ __launch_bounds__(256) void f16_bwd_act_kernel(BwdActArgs p) {
+  __shared__ float red[4][2][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = blockIdx.x >> 5, nb = (blockIdx.x >> 1) & 15, s = blockIdx.x & 1;
+  const int per = p.mts >> 2;
+  const float K = TWO_PI_F * TWO_PI_F;
+  float sum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+  long mt = (long)img * p.mts + wave * per;
+#pragma unroll 2
+  for (int i = 0; i < per; ++i, ++mt) {
+    const long g = (((mt * 16 + nb) * 2 + s) * 64 + lane) * 8;
+    float da[8], du[8], dd[8], aa[8], tt[8], o[8];
+    unpack8(*(const u32x4*)(p.da + g), da);
+    unpack8(*(const u32x4*)(p.du + g), du);
+    unpack8(*(const u32x4*)(p.d + g), dd);
+    unpack8(*(const u32x4*)(p.a + g), aa);
+    unpack8(*(const u32x4*)(p.t + g), tt);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[e] = da[e] * dd[e] - K * aa[e] * (du[e] * tt[e]);
+      sum[e] += o[e];
+    }
+    *(u32x4*)(p.dp + g) = pack8(o);
+  }
+  if (!p.seg) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) sum[e] += __shfl_xor(sum[e], o, 64);   // over the 32 rows of a block: lanes of one lhi
+  if ((lane & 31) == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane >> 5][e] = sum[e];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int lhi = tid >> 3, e = tid & 7;
+    const float v = ((red[0][lhi][e] + red[1][lhi][e]) + red[2][lhi][e]) + red[3][lhi][e];
+    p.seg[(long)img * R_N + 32 * nb + 16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3)] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients: contractions over the ROWS m of F16 tensors.  A fragment of such a contraction needs 8 rows of one
+// column per lane, the transpose of what a chunk holds (8 columns of one row): the loaders read chunks into registers
+// (1 KB contiguous per wave instruction), apply the optional gate there, and write them TRANSPOSED into an LDS image
+// [column][32 rows (+8 pad)] with 2-byte stores; fragments come back with one conflict-free ds_read_b128 (row stride 80
+// bytes: 16 lanes x 16 bytes land on 16 distinct 4-bank groups).
+constexpr int WG_RS = 40;   // halfwords per image row: 32 rows of the slab + 8 pad
+
+// chunk registers (16 values of lane (m = l31, lhi): s, e -> column 16 s + 8 (e >> 2) + 4 lhi + (e & 3)) -> image[column][m]
+__device__ __forceinline__ void transpose_store(u16* img, const float (&v)[2][8], int l31, int lhi) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = 16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3);
+      img[n * WG_RS + l31] = __builtin_bit_cast(u16, (__bf16)v[s][e]);
+    }
+}
+
+// f16_thin_wgrad_kernel: part[split][t][n] = sum over the split's rows m of thin[m][t] * (wide .* gate)[m][n]
+// (thin: fp32 [M, T] row-major, T <= 128; wide, gate: F16 [M, 512]).  grid = 4 column tiles x S splits; wave w of a
+// workgroup owns the 32-column block 4 tile + w (its transposed image is wave-private), the thin image is shared.
+struct ThinWgradArgs {
+  const float* thin;
+  const u16 *wide, *gate;
+  float* part;
+  int T, mts, per;   // 32-row blocks in total / per split
+};
+template <int TB, bool GATED>
+__global__ __launch_bounds__(256, 2) void f16_thin_wgrad_kernel(ThinWgradArgs p) {
+  __shared__ __attribute__((aligned(16))) u16 At[2][TB * 32 * WG_RS];    // thin^T  [t][m]
+  __shared__ __attribute__((aligned(16))) u16 Bt[2][4][32 * WG_RS];      // wide^T  [wave][n][m]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int tile = blockIdx.x & 3, split = blockIdx.x >> 2;
+  const int nb = tile * 4 + wave, T = p.T;
+  const int mt0 = split * p.per, mt1 = min(p.mts, mt0 + p.per);
+  for (int i = tid; i < 2 * TB * 32 * WG_RS; i += 256) (&At[0][0])[i] = 0;   // rows t >= T stay zero
+  f32x16 acc[TB];
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tb][r] = 0.f;
+  constexpr int NTH = (TB * 32 * 32 + 255) / 256;   // thin elements per thread and slab (upper bound)
+  u32x4 wq[2], gq[2];
+  float th[NTH];
+  auto gload = [&](int mt) {
+    const long g = (((long)mt * 16 + nb) * 2) * 64 + lane;   // 16-byte group of half 0; half 1 is 64 groups on
+    wq[0] = ((const u32x4*)p.wide)[g];
+    wq[1] = ((const u32x4*)p.wide)[g + 64];
+    if constexpr (GATED) {
+      gq[0] = ((const u32x4*)p.gate)[g];
+      gq[1] = ((const u32x4*)p.gate)[g + 64];
+    }
+    const float* ts = p.thin + (long)mt * 32 * T;
+#pragma unroll
+    for (int i = 0; i < NTH; ++i) {
+      const int idx = tid + 256 * i;
+      th[i] = idx < 32 * T ? ts[idx] : 0.f;
+    }
+  };
+  auto sstore = [&](int buf) {
+    float v[2][8];
+    unpack8(wq[0], v[0]);
+    unpack8(wq[1], v[1]);
+    if constexpr (GATED) {
+      float gg[2][8];
+      unpack8(gq[0], gg[0]);
+      unpack8(gq[1], gg[1]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[s][e] *= gg[s][e];
+    }
+    transpose_store(Bt[buf][wave], v, l31, lhi);
+#pragma unroll
+    for (int i = 0; i < NTH; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 32 * T) {
+        const int m = idx / T, t = idx - m * T;
+        At[buf][t * WG_RS + m] = __builtin_bit_cast(u16, (__bf16)th[i]);
+      }
+    }
+  };
+  __syncthreads();   // the zero fill
+  if (mt0 < mt1) {
+    gload(mt0);
+    sstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int mt = mt0; mt < mt1; ++mt, buf ^= 1) {
+    if (mt + 1 < mt1) gload(mt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 hb = *(const bf16x8*)(Bt[buf][wave] + l31 * WG_RS + 16 * ks + 8 * lhi);
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        const bf16x8 ha = *(const bf16x8*)(At[buf] + (tb * 32 + l31) * WG_RS + 16 * ks + 8 * lhi);
+        acc[tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha, hb, acc[tb], 0, 0, 0);   // D[t][n]
+      }
+    }
+    if (mt + 1 < mt1) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  float* out = p.part + (long)split * T * R_N;
+#pragma unroll
+  for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (t < T) out[(long)t * R_N + nb * 32 + l31] = acc[tb][r];
+    }
+}
+
+// out = alpha * sum_s part[s][a][b] (fixed order), written as out[a][b] (ldo) or transposed out[b][a] (ldo)
+__global__ __launch_bounds__(256) void f16_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S,
+                                                               int A, int B, float alpha, int transpose, long ldo) {
+  const int total = A * B;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 3 < S; s += 4) {
+    s0 += part[(long)s * total + i];
+    s1 += part[(long)(s + 1) * total + i];
+    s2 += part[(long)(s + 2) * total + i];
+    s3 += part[(long)(s + 3) * total + i];
+  }
+  for (; s < S; ++s) s0 += part[(long)s * total + i];
+  const float v = alpha * ((s0 + s1) + (s2 + s3));
+  const int a = i / B, b = i - a * B;
+  if (transpose) out[(long)b * ldo + a] = v;
+  else out[(long)a * ldo + b] = v;
+}
+
+// f16_wgrad_gemm_kernel: part[split][n1][n2] = sum over the split's rows m of (X .* G)[m][n1] * Y[m][n2]; X, G, Y: F16
+// [M, 512].  128 x 128 output tiles (16 of them), four waves 2 x 2 of 64 x 64; the 16 tiles of one split run on ONE XCD
+// (block -> (split, tile) below), so that a slab's chunks come out of that XCD's L2 after the first tile has fetched them.
+struct WgradGemmArgs {
+  const u16 *X, *G, *Y;
+  float* part;
+  int mts, per, S;
+};
+template <bool GATED>
+__global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) u16 Xt[2][128 * WG_RS];
+  __shared__ __attribute__((aligned(16))) u16 Yt[2][128 * WG_RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // block b runs on XCD b % 8: splits xcd, xcd + 8, ... live there, 16 consecutive local blocks = the tiles of one split
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int tile = loc & 15, split = (loc >> 4) * 8 + xcd;
+  if (split >= p.S) return;
+  const int t1 = tile >> 2, t2 = tile & 3;           // 128-column tiles of X (rows of D) and of Y (columns of D)
+  const int w1 = wave >> 1, w2 = wave & 1;
+  const int mt0 = split * p.per, mt1 = min(p.mts, mt0 + p.per);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // loader: wave w stages the 32-column block w of the X tile and of the Y tile
+  u32x4 xq[2], gq[2], yq[2];
+  auto gload = [&](int mt) {
+    const long gx = (((long)mt * 16 + t1 * 4 + wave) * 2) * 64 + lane, gy = (((long)mt * 16 + t2 * 4 + wave) * 2) * 64 + lane;
+    xq[0] = ((const u32x4*)p.X)[gx];
+    xq[1] = ((const u32x4*)p.X)[gx + 64];
+    yq[0] = ((const u32x4*)p.Y)[gy];
+    yq[1] = ((const u32x4*)p.Y)[gy + 64];
+    if constexpr (GATED) {
+      gq[0] = ((const u32x4*)p.G)[gx];
+      gq[1] = ((const u32x4*)p.G)[gx + 64];
+    }
+  };
+  auto sstore = [&](int buf) {
+    float v[2][8];
+    unpack8(xq[0], v[0]);
+    unpack8(xq[1], v[1]);
+    if constexpr (GATED) {
+      float gg[2][8];
+      unpack8(gq[0], gg[0]);
+      unpack8(gq[1], gg[1]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[s][e] *= gg[s][e];
+    }
+    transpose_store(Xt[buf] + wave * 32 * WG_RS, v, l31, lhi);
+    unpack8(yq[0], v[0]);
+    unpack8(yq[1], v[1]);
+    transpose_store(Yt[buf] + wave * 32 * WG_RS, v, l31, lhi);
+  };
+  if (mt0 < mt1) {
+    gload(mt0);
+    sstore(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int mt = mt0; mt < mt1; ++mt, buf ^= 1) {
+    if (mt + 1 < mt1) gload(mt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ha[2], hb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) ha[i] = *(const bf16x8*)(Xt[buf] + ((w1 * 2 + i) * 32 + l31) * WG_RS + 16 * ks + 8 * lhi);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) hb[j] = *(const bf16x8*)(Yt[buf] + ((w2 * 2 + j) * 32 + l31) * WG_RS + 16 * ks + 8 * lhi);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);   // D[n1][n2]
+    }
+    if (mt + 1 < mt1) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  float* out = p.part + (long)split * R_N * R_N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n1 = t1 * 128 + (w1 * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const int n2 = t2 * 128 + (w2 * 2 + j) * 32 + l31;
+        out[(long)n1 * R_N + n2] = acc[i][j][r];
+      }
+}
+
 inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 }  // namespace
@@ -554,4 +840,74 @@ INDM_API int indm_f16_rows(int mode, const void* A, const void* Bp, const void* 
     default:
       return INDM_E_ARG;
   }
+}
+
+INDM_API long indm_f16_bwd_act_ok(long R, long rows_per_seg) {
+  return (R > 0 && rows_per_seg > 0 && !(rows_per_seg % 128) && !(R % rows_per_seg)) ? 1 : 0;
+}
+INDM_API int indm_f16_bwd_act(const void* da, const void* du, const void* d, const void* a, const void* t, void* dp,
+                              float* seg, long R, long rows_per_seg, void* stream) {
+  if (R < 0) return INDM_E_SHAPE;
+  if (R == 0) return INDM_OK;
+  if (!indm_f16_bwd_act_ok(R, rows_per_seg)) return 1;
+  if (!da || !du || !d || !a || !t || !dp) return INDM_E_ARG;
+  BwdActArgs p = {(const u16*)da, (const u16*)du, (const u16*)d, (const u16*)a, (const u16*)t, (u16*)dp, seg,
+                  (int)(rows_per_seg / 32)};
+  hipLaunchKernelGGL(f16_bwd_act_kernel, dim3((unsigned)(R / rows_per_seg) * 32), dim3(256), 0, (hipStream_t)stream, p);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
+static int wgrad_splits(int mts, int target) {
+  int S = mts < target ? mts : target;
+  const int per = (mts + S - 1) / S;
+  return (mts + per - 1) / per;
+}
+INDM_API long indm_f16_wgrad_ws_floats(long M, int T) {
+  const int mts = (int)(M / 32);
+  if (T > 0) return (long)wgrad_splits(mts, 128) * T * R_N;
+  return (long)wgrad_splits(mts, 32) * R_N * R_N;
+}
+INDM_API int indm_f16_thin_wgrad(const float* thin, const void* wide, const void* gate, float* out, long M, int T, float alpha,
+                                 int transpose, long ldo, float* ws, long ws_floats, void* stream) {
+  if (M < 0 || T <= 0) return INDM_E_SHAPE;
+  if (M == 0) return INDM_OK;
+  if ((M % 32) || T > 128 || M >= (1L << 36)) return 1;
+  if (!thin || !wide || !out || !ws || !al16(wide) || !al16(gate)) return INDM_E_ARG;
+  const int mts = (int)(M / 32), S = wgrad_splits(mts, 128), per = (mts + S - 1) / S;
+  if ((long)S * T * R_N > ws_floats) return INDM_E_ARG;
+  ThinWgradArgs p = {thin, (const u16*)wide, (const u16*)gate, ws, T, mts, per};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(4 * S);
+  if (T <= 32) {
+    if (gate) hipLaunchKernelGGL((f16_thin_wgrad_kernel<1, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((f16_thin_wgrad_kernel<1, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (gate) hipLaunchKernelGGL((f16_thin_wgrad_kernel<4, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((f16_thin_wgrad_kernel<4, false>), grid, dim3(256), 0, st, p);
+  }
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3(cdiv((long)T * R_N, 256)), dim3(256), 0, st, ws, out, S, T, R_N, alpha,
+                     transpose, ldo);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+INDM_API int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y, float* out, long M, float alpha, int transpose,
+                                 float* ws, long ws_floats, void* stream) {
+  if (M < 0) return INDM_E_SHAPE;
+  if (M == 0) return INDM_OK;
+  if ((M % 32) || M >= (1L << 36)) return 1;
+  if (!X || !Y || !out || !ws || !al16(X) || !al16(Y) || !al16(gateX)) return INDM_E_ARG;
+  const int mts = (int)(M / 32), S = wgrad_splits(mts, 32), per = (mts + S - 1) / S;
+  if ((long)S * R_N * R_N > ws_floats) return INDM_E_ARG;
+  WgradGemmArgs p = {(const u16*)X, (const u16*)gateX, (const u16*)Y, ws, mts, per, S};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(((S + 7) / 8) * 8 * 16);
+  if (gateX) hipLaunchKernelGGL((f16_wgrad_gemm_kernel<true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((f16_wgrad_gemm_kernel<false>), grid, dim3(256), 0, st, p);
+  INDM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3(cdiv((long)R_N * R_N, 256)), dim3(256), 0, st, ws, out, S, R_N, R_N, alpha,
+                     transpose, (long)R_N);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
 }

@@ -151,6 +151,11 @@ INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int
       return nH + nP + 4 * nC + red + 64;
     case 17:  // forward, eval, bf16 storage: + a0, d0 (fp32) and a1, d1, a2, d2 (F16) live here
       return nH + nP + 3 * nC + red + 2 * nC + 4 * nH + 64;
+    case 18: {  // backward, bf16 storage: five F16 [M, idim] buffers + the fp32 skinny side
+      const long small = 6 * pad64((long)idim * 9 * C) + pad64((long)N * idim) + pad64(idim);
+      const long redb = pad64(indm_colreduce_ws_floats(M, C)) + pad64(indm_colreduce_ws_floats(N, idim));
+      return 5 * nH + 2 * nP + 5 * nC + small + redb + 64;
+    }
     case 0:  // forward, training: p, Pn, g, v, wtmp, vj + reductions
       return nW + nP + 4 * nC + red + 64;
     case 1:  // forward, eval: + a0,d0,a1,d1,a2,d2,t3 live here
@@ -366,9 +371,86 @@ INDM_API int indm_iresblock_fwd_logdet(const indm_iresblock_fwd_args* a, void* s
   return INDM_OK;
 }
 
+namespace {
+// backward of the training-mode block on F16 tensors (args.bf16 == 2): the launch sequence of indm_iresblock_bwd with the
+// F16 kernels.  Differences in HOW: the thin convolution that produces q1 also writes q1 .* d1 (= dt2, the cotangent the
+// fp32 path takes from the Sin-level kernel), so the contraction behind it needs no gate; pre-gated operands replace
+// gates on GEMM loaders, the weight-gradient kernels gate while they transpose.
+static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
+  if (!covered16(a->N, a->H, a->W, a->C, a->idim) || !a->gld || !indm_f16_bwd_act_ok((long)a->N * a->H * a->W, (long)a->H * a->W))
+    return 1;
+  if (!a->gy || !a->a0 || !a->a1 || !a->d1 || !a->a2 || !a->d2 || !a->t3 || !a->t2 || !a->w || !a->eps || !a->W1 ||
+      !a->W3_tapco_ci || !a->W2_bf16w || !a->W2T_bf16w || !a->panel_bf16w || (a->preact && (!a->d0 || !a->c1)) || !a->dx ||
+      !a->dcb || !a->dW1 || !a->dW2 || !a->dW3 || !a->dW2T || !a->db1 || !a->db2 || !a->db3 || !a->splitk_ws)
+    return INDM_E_ARG;
+  Ctx16 c = {a->N, a->H, a->W, a->C, a->idim, (long)a->N * a->H * a->W, stream, nullptr};
+  const int C = c.C, Cw = c.Cw, Mi = (int)c.M, rps = c.H * c.W, J = 9 * C;
+  const long nC = c.M * C, nP = c.M * 9 * C, nH = c.M * Cw / 2;
+  Bump ws = {a->ws, a->ws_floats, 0};
+  void *bufA = ws.get(nH), *bufB = ws.get(nH), *bufC = ws.get(nH), *bufD = ws.get(nH), *bufE = ws.get(nH);
+  float *col = ws.get(nP), *Pn = ws.get(nP);
+  float *dvj = ws.get(nC), *q0 = ws.get(nC), *dd0 = ws.get(nC), *da0 = ws.get(nC), *tmpc = ws.get(nC);
+  float *qa = ws.get((long)Cw * J), *qb = ws.get((long)Cw * J), *qc = ws.get((long)Cw * J), *qd = ws.get((long)Cw * J);
+  float* seg1 = ws.get((long)c.N * Cw);
+  float *cr_c = ws.get(indm_colreduce_ws_floats(c.M, C)), *cr_n = ws.get(indm_colreduce_ws_floats(c.N, Cw));
+  if (!bufA || !bufB || !bufC || !bufD || !bufE || !col || !Pn || !dvj || !q0 || !dd0 || !da0 || !tmpc || !qa || !qb || !qc ||
+      !qd || !seg1 || !cr_c || !cr_n)
+    return INDM_E_ARG;
+  float* sk = a->splitk_ws;
+  const long skn = a->splitk_ws_floats;
+  // ---- g path, level 3:  g = conv(a2, W3) + b3 ----
+  void* da2 = bufA;
+  TRY(c.thin(a->gy, a->W3_tapco_ci, nullptr, nullptr, da2, nullptr, 1, F16_PLAIN));                       // da2 = C3^T gy
+  TRY(indm_tap_spread_f32(a->gy, col, c.N, c.H, c.W, C, 1, 1.0f, stream));
+  TRY(indm_f16_thin_wgrad(col, a->a2, nullptr, qa, c.M, J, 1.0f, 1, J, sk, skn, stream));                   // a2^T spread(gy): [Cw, 9C]
+  TRY(indm_colreduce_f32(a->gy, nullptr, a->db3, c.M, C, 0, 1.0f, 0.0f, cr_c, stream));
+  // ---- reverse sweep of the last VJP chain ----
+  TRY(indm_scale_rows_f32(a->eps, a->gld, dvj, c.N, (long)rps * C, stream));
+  const float* q0p = dvj;
+  if (a->preact) {
+    TRY(indm_mul2_f32(dvj, a->d0, a->c1, q0, dd0, nC, stream));
+    q0p = q0;
+  }
+  void *q1 = bufB, *q1g = bufC;
+  TRY(c.thin(q0p, a->W1, nullptr, a->d1, q1g, q1, -1, F16_GATE));                                          // q1 = conv(q0, W1); q1g = q1 .* d1 (= dt2)
+  TRY(indm_tap_spread_f32(q0p, col, c.N, c.H, c.W, C, -1, 1.0f, stream));
+  TRY(indm_f16_thin_wgrad(col, a->t2, a->d1, qb, c.M, J, 1.0f, 1, J, sk, skn, stream));                     // (t2 .* d1)^T spread(q0)
+  void* du2 = bufD;
+  TRY(indm_f16_rows(F16R_GEMM, q1g, a->W2_bf16w, nullptr, nullptr, nullptr, du2, nullptr, nullptr, nullptr, Mi, 0, 1, stream));   // du2 = (q1 .* d1) W2
+  TRY(indm_tap_spread_f32(a->w, col, c.N, c.H, c.W, C, 1, 1.0f, stream));
+  TRY(indm_f16_thin_wgrad(col, du2, a->d2, qc, c.M, J, 1.0f, 1, J, sk, skn, stream));                       // (du2 .* d2)^T spread(w)
+  TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream));
+  void* dp2 = bufE;
+  TRY(indm_f16_bwd_act(da2, du2, a->d2, a->a2, a->t3, dp2, a->dcb, c.M, rps, stream));
+  TRY(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  // ---- level 2:  p2 = a1 W2 + b2 + cb[image] ----
+  void* da1 = bufA;
+  TRY(indm_f16_rows(F16R_GEMM, dp2, a->W2T_bf16w, nullptr, nullptr, nullptr, da1, nullptr, nullptr, nullptr, Mi, 0, 1, stream));  // da1 = dp2 W2^T
+  TRY(indm_f16_wgrad_gemm(a->a1, nullptr, dp2, a->dW2, c.M, 1.0f, 0, sk, skn, stream));                      // dW2 = a1^T dp2
+  void* dp1 = bufD;
+  TRY(indm_f16_bwd_act(da1, q1, a->d1, a->a1, a->t2, dp1, seg1, c.M, rps, stream));
+  TRY(indm_f16_wgrad_gemm(a->t3, a->d2, q1g, a->dW2T, c.M, 1.0f, 0, sk, skn, stream));                       // dW2T = (t3 .* d2)^T (q1 .* d1)
+  TRY(indm_colreduce_f32(seg1, nullptr, a->db1, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  // ---- level 1:  p1 = conv(a0, W1) + b1 ----
+  TRY(indm_f16_rows(F16R_THINN, dp1, nullptr, nullptr, a->panel_bf16w, Pn, nullptr, nullptr, nullptr, nullptr, Mi, J, 1, stream));
+  TRY(indm_tap_gather_f32(Pn, nullptr, da0, c.N, c.H, c.W, C, -1, 1.0f, stream));
+  TRY(indm_tap_spread_f32(a->a0, col, c.N, c.H, c.W, C, -1, 1.0f, stream));
+  TRY(indm_f16_thin_wgrad(col, dp1, nullptr, qd, c.M, J, 1.0f, 0, Cw, sk, skn, stream));                    // spread(a0)^T dp1: [9C, Cw]
+  TRY(permute021_add(qb, nullptr, qd, a->dW1, Cw, J, 1, stream));
+  if (a->preact) {
+    TRY(indm_sincos_act_bwd_f32(da0, dd0, a->a0, a->d0, tmpc, nC, stream));
+    TRY(indm_axpby_f32(a->gy, tmpc, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+  } else {
+    TRY(indm_axpby_f32(a->gy, da0, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+  }
+  return INDM_OK;
+}
+}  // namespace
+
 INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) {
   if (!a) return INDM_E_ARG;
   if (a->N <= 0) return INDM_OK;
+  if (a->bf16 == 2) return bwd_f16(a, stream);
   if (!covered(a->N, a->H, a->W, a->C, a->idim) || !a->gld) return 1;
   if (!a->gy || !a->a0 || !a->a1 || !a->d1 || !a->a2 || !a->d2 || !a->t3 || !a->t2 || !a->w || !a->eps || !a->W1 ||
       !a->W2 || !a->W2T || !a->W3_tapco_ci || (a->preact && (!a->d0 || !a->c1)) || !a->dx || !a->dcb || !a->dW1 ||

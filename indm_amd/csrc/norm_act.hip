@@ -298,6 +298,103 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
                                                             float* __restrict__ mean, float* __restrict__ rstd, int N, int HW,
                                                             int C, int G, int GS, float eps, int act, float drop_p,
                                                             uint64_t seed) {
+  __shared__ float sh[4 * GNF_MAXG * 2];   // [wave][group][sum, sum of squares]
+  const int bs = blockDim.x, tid = threadIdx.x;
+  int n, gb;
+  gnf_decode(blockIdx.x, G / GS, N, n, gb);
+  const int cpg = C / G, CS = GS * cpg, CS4 = CS >> 2, C4 = C >> 2;
+  const int q = tid % CS4;                       // this thread's channel quad inside the slab (bs % CS4 == 0)
+  const int gl = (q * 4) / cpg;                  // ... and its group inside the block
+  const int total = HW * CS4;
+  const long img4 = (long)n * HW * C4;           // float4 index of the image
+  const int c4_0 = gb * CS4;
+  float4 v[NF4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int f = tid + k * bs;
+    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < total) {
+      const int pix = f / CS4;
+      v[k] = *(const float4*)(x + (img4 + (long)pix * C4 + c4_0 + q) * 4);
+      s1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      s2 += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+    }
+  }
+  // statistics of the slab's groups: per-wave butterfly sums (fixed order) -> one LDS word per (wave, group) -> every thread
+  // adds the waves' partials of its own group in wave order.  (Round 3 folded 256 per-thread partials serially on GS threads
+  // behind a barrier; see DESIGN.md on the reproducibility flake.)  blockDim is a multiple of 64: all lanes take part.
+  const int wave = tid >> 6, nw = bs >> 6;
+#pragma unroll
+  for (int g = 0; g < GNF_MAXG; ++g) {
+    if (g < GS) {
+      const float a = wave_sum(gl == g ? s1 : 0.f), b = wave_sum(gl == g ? s2 : 0.f);
+      if ((tid & 63) == 0) {
+        sh[(wave * GNF_MAXG + g) * 2] = a;
+        sh[(wave * GNF_MAXG + g) * 2 + 1] = b;
+      }
+    }
+  }
+  __syncthreads();
+  float m, r;
+  {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < nw; ++w) {
+      a += sh[(w * GNF_MAXG + gl) * 2];
+      b += sh[(w * GNF_MAXG + gl) * 2 + 1];
+    }
+    const float inv_cnt = 1.f / ((float)HW * (float)cpg);
+    m = a * inv_cnt;
+    float var = b * inv_cnt - m * m;
+    var = fmaxf(var, 0.f);
+    r = rsqrtf(var + eps);
+  }
+  if (tid < GS) {   // thread tid's own group may differ from group tid: fold that one for the saved statistics
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < nw; ++w) {
+      a += sh[(w * GNF_MAXG + tid) * 2];
+      b += sh[(w * GNF_MAXG + tid) * 2 + 1];
+    }
+    const float inv_cnt = 1.f / ((float)HW * (float)cpg);
+    const float mm = a * inv_cnt;
+    float var = b * inv_cnt - mm * mm;
+    var = fmaxf(var, 0.f);
+    mean[n * G + gb * GS + tid] = mm;
+    rstd[n * G + gb * GS + tid] = rsqrtf(var + eps);
+  }
+  const float4 gm = *(const float4*)(gamma + (c4_0 + q) * 4);
+  const float4 bt = *(const float4*)(beta + (c4_0 + q) * 4);
+  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int f = tid + k * bs;
+    if (f < total) {
+      const int pix = f / CS4;
+      const long i4 = img4 + (long)pix * C4 + c4_0 + q;
+      const float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+      float out[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float u = (in[j] - m) * r * gmv[j] + btv[j];
+        if (act == 1) u = silu_f(u);
+        if (drop_p > 0.f) u *= dropout_keep(seed, (uint64_t)i4, j, drop_p);
+        out[j] = u;
+      }
+      *(float4*)(y + i4 * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+  }
+}
+
+// Round 3's form of the forward kernel, kept ONLY as the stress reproducer of the reproducibility flake (INDM_GN_FUSED=2,
+// tools/flake_pattern.py): 256 per-thread partials in LDS, one barrier, GS threads fold them serially while the other waves
+// wait at the next barrier.  On a GPU shared by more processes than it has queue slots this kernel occasionally returned
+// statistics with part of the partials missing; the butterfly form above has not.
+template <int NF4>
+__global__ __launch_bounds__(256) void gn_fused_fwd_serial_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int N, int HW,
+                                                            int C, int G, int GS, float eps, int act, float drop_p,
+                                                            uint64_t seed) {
   __shared__ float sh[2 * 256];
   __shared__ float st[2 * GNF_MAXG];
   const int bs = blockDim.x, tid = threadIdx.x;
@@ -370,7 +467,7 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ dx, float* __restrict__ cpart, int N, int HW,
                                                             int C, int G, int GS, int act, float drop_p, uint64_t seed) {
-  __shared__ float sh[8 * 256];           // per-thread channel partials: [j (4: sum d, 4: sum d*xh)][thread]
+  __shared__ float sh[4 * 8 * 8];         // [wave][quad][4: sum d, 4: sum d*xh]
   __shared__ float chs[2 * 32];           // channel sums of the slab (CS <= 32)
   __shared__ float gs_[2 * GNF_MAXG];     // group sums
   const int bs = blockDim.x, tid = threadIdx.x;
@@ -411,16 +508,32 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
       dd[k] = make_float4(d[0], d[1], d[2], d[3]);
     }
   }
+  // channel sums of the slab: per-wave butterfly sums over the lanes that own the same channel quad (fixed order), one LDS
+  // row per (wave, quad), then the waves' rows are added in wave order
+  const int wave = tid >> 6, nw = bs >> 6;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    sh[j * 256 + tid] = a1[j];
-    sh[(4 + j) * 256 + tid] = a2[j];
+  for (int qq = 0; qq < 8; ++qq) {
+    if (qq < CS4) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v8[j] = wave_sum(q == qq ? a1[j] : 0.f);
+        v8[4 + j] = wave_sum(q == qq ? a2[j] : 0.f);
+      }
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[(wave * 8 + qq) * 8 + j] = v8[j];
+      }
+    }
   }
   __syncthreads();
-  if (tid < CS) {   // channel sums of the slab, fixed order over the threads that own the channel's quad
+  if (tid < CS) {   // channel tid = quad cq, component cj
     const int cq = tid >> 2, cj = tid & 3;
     float a = 0.f, b = 0.f;
-    for (int t = cq; t < bs; t += CS4) { a += sh[cj * 256 + t]; b += sh[(4 + cj) * 256 + t]; }
+    for (int w = 0; w < nw; ++w) {
+      a += sh[(w * 8 + cq) * 8 + cj];
+      b += sh[(w * 8 + cq) * 8 + 4 + cj];
+    }
     chs[tid] = a;
     chs[32 + tid] = b;
     cpart[(long)n * 2 * C + gb * CS + tid] = a;          // dbeta partial of image n
@@ -491,9 +604,9 @@ static GnFused gn_fused_geom(int HW, int C, int G) {
   if (gs > GNF_MAXG || gs * cpg > 32 || (cs4 != 1 && cs4 != 2 && cs4 != 3 && cs4 != 4 && cs4 != 6 && cs4 != 8)) return f;
   const long total = (long)HW * cs4;
   const bool three = (cs4 % 3) == 0;                   // blockDim must be a multiple of cs4
-  int bs = three ? 192 : 256;
-  if (total <= 64) bs = three ? 48 : 64;               // 4 x 4 maps: one wavefront
-  else if (total <= 128) bs = three ? 96 : 128;
+  int bs = three ? 192 : 256;                          // whole wavefronts (the reductions are wave butterflies)
+  if (!three && total <= 64) bs = 64;                  // 4 x 4 maps: one wavefront
+  else if (!three && total <= 128) bs = 128;
   const int need = (int)((total + bs - 1) / bs);
   const int nf4 = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 16 ? 16 : 0;
   if (!nf4) return f;
@@ -715,6 +828,12 @@ INDM_API long indm_groupnorm_ws_floats(int N, int HW, int C, int G) {
   return (long)N * S * (2 * G + 2 * C) + 2L * N * G + 16;
 }
 
+// 1 if indm_groupnorm_fwd/bwd_f32 run the single-pass register-resident kernels for this geometry, 0 if the three-kernel passes
+INDM_API int indm_groupnorm_fused(int HW, int C, int G) {
+  if (C % 4 != 0 || G <= 0 || C % G != 0) return 0;
+  return gn_fused_geom(HW, C, G).nf4 ? 1 : 0;
+}
+
 // y = dropout(act(GroupNorm(x)));  x,y: [N, HW, C];  mean,rstd: [N, G] (saved for backward)
 INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                     float* mean, float* rstd, int N, int HW, int C, int G, float eps, int act,
@@ -725,8 +844,14 @@ INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const fl
   const GnFused ff = gn_fused_geom(HW, C, G);
   if (ff.nf4) {   // single pass: one workgroup per (image, group block) keeps its slab in registers
     const dim3 grid((G / ff.gs) * N), block(ff.bs);
-#define GNF_FWD(NF) hipLaunchKernelGGL(gn_fused_fwd_kernel<NF>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, N, HW, C, G, \
-                                       ff.gs, eps, act, drop_p, (uint64_t)seed)
+    static const int serial = getenv("INDM_GN_FUSED") && atoi(getenv("INDM_GN_FUSED")) == 2;   // the round-3 reproducer
+#define GNF_FWD(NF)                                                                                                          \
+  do {                                                                                                                       \
+    if (serial) hipLaunchKernelGGL(gn_fused_fwd_serial_kernel<NF>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, N, HW, \
+                                   C, G, ff.gs, eps, act, drop_p, (uint64_t)seed);                                           \
+    else hipLaunchKernelGGL(gn_fused_fwd_kernel<NF>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, N, HW, C, G, ff.gs,  \
+                            eps, act, drop_p, (uint64_t)seed);                                                               \
+  } while (0)
     switch (ff.nf4) {
       case 1: GNF_FWD(1); break;
       case 2: GNF_FWD(2); break;

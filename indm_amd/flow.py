@@ -252,6 +252,7 @@ class _IResTrain(torch.autograd.Function):
                 ctx.save_for_backward(a0, d0, a1, d1, a2, d2, t3, t2, c1, w, eps, W1, W2, W3, W2T)
                 ctx.cfg = (blk.preact, hw)
                 ctx.driver = True
+                ctx.panel = panel
                 return y, logdet
         a0, d0 = hip.sincos_fwd(x, True) if blk.preact else (x, None)
         p1 = hip.conv2d(a0, W1, bias=b1)
@@ -292,9 +293,15 @@ class _IResTrain(torch.autograd.Function):
         a0, d0, a1, d1, a2, d2, t3, t2, c1, w, eps, W1, W2, W3, W2T = ctx.saved_tensors
         preact, hw = ctx.cfg
         N, H, Wd, C = eps.shape
-        if a1.dtype == torch.bfloat16:
-            # bf16 storage (F16 buffers from the forward driver): until the backward has its own F16 kernels the saved
-            # tensors are unpacked to fp32 here
+        f16 = a1.dtype == torch.bfloat16   # bf16 storage: F16 buffers from the forward driver
+        gy = torch.zeros_like(eps) if gy is None else (gy if gy.is_contiguous() else gy.contiguous())
+        if f16 and ctx.driver and gld is not None and hip.block_drivers():
+            out = hip.iresblock_bwd(gy, _cc(gld), (a0, d0, a1, d1, a2, d2, t3, t2, c1, w), eps, W1, W2, W2T, W3, preact,
+                                    panel=ctx.panel)
+            if out is not None:
+                dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3 = out
+                return dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3, None, None, None, None
+        if f16:   # a backward the F16 driver does not cover (no log-det cotangent): unpack and use the fp32-tensor path
             Cw_ = W2.shape[0]
             a1, d1, a2, d2, t3, t2 = (hip.f16_unpack(t, N * H * Wd, Cw_).view(N, H, Wd, Cw_) for t in (a1, d1, a2, d2, t3, t2))
         Cw = a1.shape[-1]

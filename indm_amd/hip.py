@@ -43,6 +43,7 @@ _SIGS = {
     "indm_conv2d_wgrad_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_f,
                                c_p, c_l, c_p],
     "indm_groupnorm_ws_floats": [c_i, c_i, c_i, c_i],
+    "indm_groupnorm_fused": [c_i, c_i, c_i],
     "indm_groupnorm_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p],
     "indm_groupnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64,
                                c_p, c_p],
@@ -123,6 +124,11 @@ _SIGS = {
     "indm_f16_unpack_f32": [c_p, c_p, c_l, c_i, c_p],
     "indm_f16_thin_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "indm_f16_bwd_act_ok": [c_l, c_l],
+    "indm_f16_bwd_act": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
+    "indm_f16_wgrad_ws_floats": [c_l, c_i],
+    "indm_f16_thin_wgrad": [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_l, c_p, c_l, c_p],
+    "indm_f16_wgrad_gemm": [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p, c_l, c_p],
     "indm_timer_create": [c_i, c_p],
     "indm_timer_destroy": [c_p],
     "indm_timer_reset": [c_p, c_i],
@@ -130,7 +136,7 @@ _SIGS = {
 }
 _LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_segreduce_ws_floats", "indm_rowreduce_ws_floats",
              "indm_dsm_ws_floats", "indm_sqnorm_ws_floats", "indm_ires_bwd_act_ws_floats", "indm_iresblock_ws_floats",
-             "indm_pc_step_ws_floats", "indm_hutch_div_ws_floats"}
+             "indm_pc_step_ws_floats", "indm_hutch_div_ws_floats", "indm_f16_bwd_act_ok", "indm_f16_wgrad_ws_floats"}
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 
@@ -1337,6 +1343,43 @@ def f16_rows(mode, A, M, Wp=None, D1=None, Pp=None, J=0, bias=None, bias2=None, 
     return P
 
 
+def f16_bwd_act(da, du, d, a, t, R, rows_per_seg=None):
+    """indm_f16_bwd_act -> (dp F16, seg fp32 [R / rows_per_seg, 512] or None); None if not covered"""
+    dp = torch.empty(R * 512, dtype=torch.bfloat16, device=a.device)
+    seg = torch.empty((R // rows_per_seg, 512), dtype=torch.float32, device=a.device) if rows_per_seg else None
+    st = lib().indm_f16_bwd_act(_ptr16(da), _ptr16(du), _ptr16(d), _ptr16(a), _ptr16(t), dp.data_ptr(), _ptr(seg), R,
+                                rows_per_seg or R, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_bwd_act")
+    return dp, seg
+
+
+def f16_thin_wgrad(thin, wide, M, gate=None, alpha=1.0, transpose=False):
+    """out[t][n] = alpha sum_m thin[m][t] (wide .* gate)[m][n] (transpose: out[n][t]); thin fp32 [M, T], wide / gate F16"""
+    T = thin.shape[1]
+    out = torch.empty((512, T) if transpose else (T, 512), dtype=torch.float32, device=thin.device)
+    ws = _ws(SPLITK_WS_FLOATS, thin.device)
+    st = lib().indm_f16_thin_wgrad(_ptr(thin), _ptr16(wide), _ptr16(gate), _ptr(out), M, T, alpha, int(transpose),
+                                   T if transpose else 512, _ptr(ws), SPLITK_WS_FLOATS, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_thin_wgrad")
+    return out
+
+
+def f16_wgrad_gemm(X, Y, M, gate=None, alpha=1.0, transpose=False):
+    """out[n1][n2] = alpha sum_m (X .* gate)[m][n1] Y[m][n2]; X, gate, Y F16 [M, 512]"""
+    out = torch.empty((512, 512), dtype=torch.float32, device=X.device)
+    ws = _ws(SPLITK_WS_FLOATS, X.device)
+    st = lib().indm_f16_wgrad_gemm(_ptr16(X), _ptr16(gate), _ptr16(Y), _ptr(out), M, alpha, int(transpose), _ptr(ws),
+                                   SPLITK_WS_FLOATS, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_wgrad_gemm")
+    return out
+
+
 # --------------------------------------------------------------------------- block-level drivers (csrc/iresblock.hip)
 class _IResFwdArgs(ctypes.Structure):
     """indm_iresblock_fwd_args (include/indm_hip.h)"""
@@ -1482,25 +1525,34 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     return y, logdet, saved
 
 
-def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact):
+def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact, panel=None):
     """Backward of the training-mode block through indm_iresblock_bwd -> (dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3)
     or None if not covered."""
     a0, d0, a1, d1, a2, d2, t3, t2, c1, w = saved
     N, H, W, C = eps.shape
-    idim = a1.shape[-1]
+    f16 = a1.dtype == torch.bfloat16        # F16 buffers saved by the bf16-storage forward
+    idim = W2.shape[0]
     dev = eps.device
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
     a = _IResBwdArgs()
     a.N, a.H, a.W, a.C, a.idim, a.preact = N, H, W, C, idim, int(preact)
-    a.bf16 = int(_MFMA["dtype"] == "bf16")
+    a.bf16 = 2 if f16 else int(_MFMA["dtype"] == "bf16")
     a.gy, a.gld = _ptr(gy), _ptr(gld)
     a.a0, a.d0, a.c1 = _ptr(a0), _ptr(d0), _ptr(c1)
-    a.a1, a.d1, a.a2, a.d2, a.t3, a.t2, a.w, a.eps = (_ptr(t) for t in (a1, d1, a2, d2, t3, t2, w, eps))
+    if f16:
+        a.a1, a.d1, a.a2, a.d2, a.t3, a.t2 = (_ptr16(t) for t in (a1, d1, a2, d2, t3, t2))
+        a.w, a.eps = _ptr(w), _ptr(eps)
+        if panel is None:
+            return None
+        keep = [packed_bf16(W2), packed_bf16(W2T), packed_bf16(panel)]
+        a.W2_bf16w, a.W2T_bf16w, a.panel_bf16w = (t.data_ptr() for t in keep)
+    else:
+        a.a1, a.d1, a.a2, a.d2, a.t3, a.t2, a.w, a.eps = (_ptr(t) for t in (a1, d1, a2, d2, t3, t2, w, eps))
     a.W1, a.W2, a.W2T, a.W3_tapco_ci = _ptr(W1), _ptr(W2), _ptr(W2T), _ptr(_packed_weight(W3, "tapco_ci"))
     out = (new(N, H, W, C), new(N, idim), new(3, 3, C, idim), new(idim, idim), new(3, 3, idim, C), new(idim, idim),
            new(idim), new(idim), new(C))
     a.dx, a.dcb, a.dW1, a.dW2, a.dW3, a.dW2T, a.db1, a.db2, a.db3 = (t.data_ptr() for t in out)
-    ws, n = _ires_ws(N, H, W, C, idim, 2, dev)
+    ws, n = _ires_ws(N, H, W, C, idim, 2 + (16 if f16 else 0), dev)
     a.ws, a.ws_floats = ws.data_ptr(), n
     sk = _ws(SPLITK_WS_FLOATS, dev)
     a.splitk_ws, a.splitk_ws_floats = sk.data_ptr(), SPLITK_WS_FLOATS

@@ -966,6 +966,86 @@ def flow_step_fn_nll_chunked(cfg, sde, state, flow_state, batch, events, chunk=1
     return tuple(torch.cat([p[i] for p in parts]) for i in range(4))
 
 
+def flow_step_fn_fid_chunked(cfg, sde, state, flow_state, batch, events, chunk=16):
+    """flow_step_fn_fid (losses.py:322-406; training.st off, num_micro_batch = 1) in a bounded amount of host memory, the
+    two-phase analogue of flow_step_fn_nll_chunked: phase 1 = the NLL objective with importance_sampling=True, chunk by
+    chunk, stepping the flow only; phase 2 = the flow's forward without log-det on the UPDATED flow (train mode: the
+    encoder's BatchNorm statistics are whole-batch, so the encoder runs once), the score loss per chunk, stepping the score
+    network.  `events`: the whole-batch draws of the step in the reference's call order -- phase 1: posterior noise, then
+    per-block (eps, poisson) draws, the loss's (rand, randn), the prior's randn; phase 2: posterior noise, (rand, randn).
+    Pinned against the reference's two-step goldens (tests/test_oracle_golden.py)."""
+    assert int(cfg.optim.num_micro_batch) == 1 and not cfg.training.st
+    state.zero_grad()
+    flow_state.zero_grad()
+    B = batch.shape[0]
+    P = flow_state.P
+    x_in = squeeze(batch, 2) if cfg.flow.squeeze else batch
+    D = np.prod(batch.shape[1:])
+    # ---- phase 1 (losses.py:354-376) ----
+    bn = {}
+    enc_rng = ReplayRng(events[:1])
+    zh, kl = sampling_and_kl(P, x_in, True, enc_rng, bn)
+    h_leaf = zh.view(-1, zh.size(2)).detach().requires_grad_(True)
+    kl_leaf = kl.detach().requires_grad_(True)
+    # how many events phase 1 consumes after the posterior noise: replay chunk 0 on a counting source
+    probe = ReplayRng([(k, v if k == "poisson" else v[0:min(B, chunk)]) for k, v in events[1:]])
+    parts, used = [], None
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        rng = probe if lo == 0 else ReplayRng([(k, v if k == "poisson" else v[lo:hi]) for k, v in events[1:1 + used]])
+        e, logpx = residual_flow_fwd(P, x_in[lo:hi], h_leaf[lo:hi], True, True, rng)
+        z, lf = e, -logpx - kl_leaf[lo:hi]
+        if cfg.flow.squeeze:
+            z = torch.pixel_shuffle(z, 2)
+        ls = sde_loss(state.P, cfg, sde, z, True, rng, importance_sampling=True)
+        lp = calculate_logp(sde, z, rng)
+        if lo == 0:
+            used = rng.i
+        else:
+            assert rng.done()
+        if cfg.training.reduce_mean:
+            lf, lp = -lf / D, -lp / D
+        else:
+            lf, lp = -lf, -lp
+        losses = ls + lf + lp
+        (losses.sum() / B).backward()
+        parts.append((losses.detach(), lf.detach(), lp.detach()))
+    torch.autograd.backward([zh.view(-1, zh.size(2)), kl], [h_leaf.grad, kl_leaf.grad])
+    with torch.no_grad():
+        for k, v in bn.items():
+            P[k] = v
+    flow_state.optimize()
+    flow_state.ema_update()
+    state.zero_grad()
+    # ---- phase 2 (losses.py:396-404): z from the updated flow, no log-det, no graph ----
+    rest = events[1 + used:]
+    bn = {}
+    adds = []
+    with torch.no_grad():
+        enc_rng = ReplayRng(rest[:1])
+        zh2, _ = sampling_and_kl(P, x_in, True, enc_rng, bn)
+        h2 = zh2.view(-1, zh2.size(2))
+        for k, v in bn.items():
+            P[k] = v
+    for lo in range(0, B, chunk):
+        hi = min(B, lo + chunk)
+        rng = ReplayRng([(k, v if k == "poisson" else v[lo:hi]) for k, v in rest[1:]])
+        with torch.no_grad():
+            z2 = residual_flow_fwd(P, x_in[lo:hi], h2[lo:hi], False, True, rng)
+            if cfg.flow.squeeze:
+                z2 = torch.pixel_shuffle(z2, 2)
+        la = sde_loss(state.P, cfg, sde, z2.detach(), True, rng, recon_loss=False)
+        assert rng.done()
+        (la.sum() / B).backward()
+        adds.append(la.detach())
+    state.optimize()
+    state.ema_update()
+    state.step += 1
+    flow_state.step += 1
+    return (torch.cat([p[0] for p in parts]), torch.cat(adds), torch.cat([p[1] for p in parts]),
+            torch.cat([p[2] for p in parts]))
+
+
 def flow_step_fn_fid(cfg, sde, state, flow_state, batch, rng, stats=None):
     """losses.py:322-406, training.st included (:378-395)"""
     st = bool(cfg.training.st)

@@ -122,3 +122,54 @@ def test_rows_chain_and_thin_n(M, J):
     refT = r16(A)[idx].double() @ r16(panel).double()
     T = hip.f16_rows(hip.F16_THINN, A16, M, Pp=Pp, J=J)
     assert (T[idx.to(DEV)].cpu().double() - refT).abs().max().item() <= 1e-4 * refT.abs().max().item() + 1e-5, "thin-N"
+
+
+@pytest.mark.parametrize("R,rps", [(4096, 1024), (1024, 256), (131072, 1024), (8192, 4096)])
+def test_bwd_act(R, rps):
+    N = 512
+    ts = [rnd(R, N, seed=i) for i in range(5)]
+    da, du, d, a, t = (hip.f16_pack(x.to(DEV)) for x in ts)
+    rda, rdu, rd, ra, rt = (r16(x).double() for x in ts)
+    ref = rda * rd - 4 * math.pi ** 2 * ra * (rdu * rt)
+    dp, seg = hip.f16_bwd_act(da, du, d, a, t, R, rps)
+    idx = torch.arange(0, R, max(1, R // 1024))
+    close16(hip.f16_unpack(dp, R, N)[idx.to(DEV)], ref[idx], "bwd_act dp", ulps=1.0, atol=1e-4)
+    # the column sums are taken of the fp32 values BEFORE the bf16 rounding of dp
+    sref = ref.view(R // rps, rps, N).sum(1)
+    err = (seg.cpu().double() - sref).abs().max().item()
+    assert err <= 2e-4 * sref.abs().max().item() + 1e-3, err
+    dp2, none = hip.f16_bwd_act(da, du, d, a, t, R, None) if R % 128 == 0 else (dp, None)
+    assert none is None and torch.equal(dp2, dp)
+    assert hip.f16_bwd_act(da, du, d, a, t, R, 64) is None
+
+
+@pytest.mark.parametrize("M,T", [(4096, 27), (1024, 108), (131072, 27), (32768, 108), (96, 5)])
+def test_thin_wgrad(M, T):
+    N = 512
+    thin, wide, gate = rnd(M, T, seed=1), rnd(M, N, seed=2), rnd(M, N, seed=3)
+    w16, g16 = hip.f16_pack(wide.to(DEV)), hip.f16_pack(gate.to(DEV))
+    ref = r16(thin).double().t() @ r16(wide).double()
+    out = hip.f16_thin_wgrad(thin.to(DEV), w16, M, alpha=0.5)
+    assert (out.cpu().double() - 0.5 * ref).abs().max().item() <= 2e-5 * math.sqrt(M) + 1e-4 * ref.abs().max().item()
+    out = hip.f16_thin_wgrad(thin.to(DEV), w16, M, transpose=True)
+    assert out.shape == (N, T)
+    assert (out.cpu().double() - ref.t()).abs().max().item() <= 4e-5 * math.sqrt(M) + 1e-4 * ref.abs().max().item()
+    refg = r16(thin).double().t() @ r16((r16(wide) * r16(gate))).double()      # the gated product is rounded to bf16
+    out = hip.f16_thin_wgrad(thin.to(DEV), w16, M, gate=g16)
+    assert (out.cpu().double() - refg).abs().max().item() <= 4e-5 * math.sqrt(M) + 1e-4 * refg.abs().max().item()
+
+
+@pytest.mark.parametrize("M", [64, 4096, 131072])
+def test_wgrad_gemm(M):
+    N = 512
+    X, Y, G = rnd(M, N, seed=1), rnd(M, N, seed=2), rnd(M, N, seed=3)
+    x16, y16, g16 = (hip.f16_pack(v.to(DEV)) for v in (X, Y, G))
+    ref = r16(X).double().t() @ r16(Y).double()
+    out = hip.f16_wgrad_gemm(x16, y16, M)
+    tol = 4e-5 * math.sqrt(M) + 1e-4 * ref.abs().max().item()
+    assert (out.cpu().double() - ref).abs().max().item() <= tol
+    out = hip.f16_wgrad_gemm(x16, y16, M, alpha=2.0, transpose=True)
+    assert (out.cpu().double() - 2.0 * ref.t()).abs().max().item() <= 2 * tol
+    refg = r16(r16(X) * r16(G)).double().t() @ r16(Y).double()
+    out = hip.f16_wgrad_gemm(x16, y16, M, gate=g16)
+    assert (out.cpu().double() - refg).abs().max().item() <= tol

@@ -427,6 +427,26 @@ def test_chunked_step_matches_reference_goldens():
         gu.assert_close(fstate.P[k].float(), v.float(), 1e-5, 1e-6, "chunked " + k)
 
 
+@pytest.mark.parametrize("fx,steps", [("mini_vp_fid", 2), ("mini_celeba", 1)])
+def test_chunked_fid_step_matches_reference_goldens(fx, steps):
+    """flow_step_fn_fid_chunked (the bounded-memory two-phase step the full-size CelebA shard test uses) against the
+    reference's own step goldens (two steps on the VP-fid net, one on the CelebA-squeeze net), one image per chunk"""
+    d, cfg = gu.load(fx), gu.mini_config(fx)
+    sde = O.get_sde(cfg)
+    state = O.OracleState(gu.state_dict(d, "score"), cfg.optim.lr, cfg.model.ema_rate, cfg)
+    fstate = O.OracleState(gu.state_dict(d, "flow"), cfg.flow.lr, cfg.flow.ema_rate, cfg)
+    for it in range(steps):
+        out = O.flow_step_fn_fid_chunked(cfg, sde, state, fstate, torch.from_numpy(d[f"step{it}/x"]),
+                                         gu.events(d, f"step{it}"), chunk=1)
+        for nm, v in zip(("loss", "loss_score", "loss_flow", "loss_logp"), out):
+            gu.assert_close(v, d[f"step{it}/{nm}"], 2e-4, 1e-5, f"chunked fid step{it} {nm}")
+    for pre, st in (("score", state), ("flow", fstate)):
+        for k in st.trainable:
+            gu.assert_close(gu.stat(st.P[k]), d[f"after{steps}/{pre}/stat/{k}"], 1e-5, 1e-6, "chunked fid param " + k)
+    for k, v in gu.sub(d, f"after{steps}/flow/buffers").items():
+        gu.assert_close(fstate.P[k].float(), v.float(), 1e-5, 1e-6, "chunked fid " + k)
+
+
 # ----------------------------------------------------------------------------- round-3 fixtures (mini_r3.npz)
 R3_CASES = {"vp_recon": ("mini_vp_nll", "scoreflow", False), "vp_recon_ddpm": ("mini_vp_nll", "ddpm", False),
             "vp_recon_st": ("mini_vp_nll", "scoreflow", True), "vp_fid_recon": ("mini_vp_fid", "scoreflow", False),
