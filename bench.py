@@ -423,8 +423,11 @@ def run_training(args, cfg_name, batch, dtype, steps, warmup, rank, world, dev, 
         # algorithmic bytes per launch of a chain class (hip.ires_chain's figure): t3 + d2 + d1 + W2T + P (+ t2 when stored)
         M = batch * (1024 if "x32" in variant else 256)
         J = 27 if "x32" in variant else 108
-        eb = 2.0 if hip.storage_dtype() == "bf16" else 4.0   # bytes per element of the 512-wide flow tensors
-        nb = eb * 3 * M * 512 + eb * 512 * 512 + 4.0 * M * J + (eb * M * 512 if "t2out" in variant else 0)
+        if hip.storage_dtype() == "bf16":
+            # F16 storage: the chain kernel reads the PRE-GATED operand (t3 .* d2, written by the thin convolution) and d1
+            nb = 2.0 * 2 * M * 512 + 2.0 * 512 * 512 + 4.0 * M * J + (2.0 * M * 512 if "t2out" in variant else 0)
+        else:
+            nb = 4.0 * 3 * M * 512 + 4.0 * 512 * 512 + 4.0 * M * J + (4.0 * M * 512 if "t2out" in variant else 0)
         prof[dominant] = dict(launches=p0["launches"] + r["launches"], flops=p0["flops"] + r["flops"],
                               bytes=p0["bytes"] + nb * r["launches"], ms=p0["ms"] + r["ms"])
     exposed_ms = None

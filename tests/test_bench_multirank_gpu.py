@@ -39,6 +39,17 @@ def test_two_rank_bench_weak_and_strong():
     assert weak["config"]["global_batch"] == 16 and weak["config"]["parallelism"] == "dp2"
     assert weak["value"] > 0 and abs(weak["value"] - 16 * 1000.0 / weak["ms_per_step"]) < 1e-6 * weak["value"] + 1e-3
     assert weak["roofline"]["bound"] == "mfma" and weak["roofline"]["achieved"] > 0
+    # BASELINE.md section 3's whole-step roofline at the realised mean series length
+    st = weak["roofline"]["step"]
+    assert st["n_bar"] >= 0 and abs(st["gflop_per_image"] - (12.73 * (st["n_bar"] + 8) + 65.08)) < 1e-6
+    assert 0 < st["frac"] < 1 and abs(st["achieved_tflops"] - st["gflop_per_image"] * weak["value"] / 2 / 1e3) < 1e-6 * st["achieved_tflops"] + 1e-9
+    assert weak["config"]["n_bar"] == st["n_bar"]
+    # who ran: two ranks, ONE device here (both ranks share GPU 0 in this test), exchanged over gloo; and what the
+    # collective costs on the critical path
+    assert weak["ranks_seen"] == 2 and weak["distinct_devices"] == 1 and weak["backend"] == "gloo"
+    assert len(weak["devices"]) == 2 and all("name" in d for d in weak["devices"])
+    assert isinstance(weak["allreduce_exposed_ms"], float) and weak["ms_per_step_without_collective"] > 0
+    assert weak["collective_elements_per_step"] and len(weak["collective_elements_per_step"]) == 2
     assert weak["cpu_baseline"] is None            # rank 0 at N = 1 only
     strong = _run(["--global-batch", "16"], port + 1)
     assert strong["scaling"] == "strong" and strong["config"]["global_batch"] == 16 and strong["n_gpus"] == 2

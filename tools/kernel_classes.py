@@ -5,6 +5,11 @@ import sys
 
 path, steps = sys.argv[1], float(sys.argv[2])
 CLASSES = [
+    ("F16 flow: 64-row GEMM / chain / thin-N", lambda n: "f16_rows_kernel" in n),
+    ("F16 flow: thin conv", lambda n: "f16_thin_conv" in n),
+    ("F16 flow: weight grads", lambda n: "f16_thin_wgrad" in n or "f16_wgrad" in n),
+    ("F16 flow: Sin-level backward", lambda n: "f16_bwd_act" in n),
+    ("F16 flow: converters", lambda n: "f16_pack" in n or "f16_unpack" in n),
     ("mfma: glds gated", lambda n: "igemm_glds_kernel" in n and ", true," in n),
     ("mfma: glds", lambda n: "igemm_glds_kernel" in n),
     ("mfma: big tile", lambda n: "igemm_big_kernel" in n),
