@@ -82,3 +82,10 @@ __device__ __forceinline__ uint4 philox4x32(uint2 key, uint4 ctr) {
 __device__ __forceinline__ float u32_to_unit(uint32_t x) {  // (0,1]
   return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
+
+// Force kernel arguments into SGPRs at the point of the macro (an empty asm that "modifies" them: the compiler must have
+// loaded them before it and cannot re-load them from the kernarg segment after it).  hipcc loads an argument with a scalar
+// load where it is first needed, which in a kernel with a long first phase is many microseconds after the launch.
+#define INDM_PIN1(a) asm volatile("" : "+s"(a))
+#define INDM_PIN_ARGS9(a, b, c, d, e, f, g, h, i) \
+  do { INDM_PIN1(a); INDM_PIN1(b); INDM_PIN1(c); INDM_PIN1(d); INDM_PIN1(e); INDM_PIN1(f); INDM_PIN1(g); INDM_PIN1(h); INDM_PIN1(i); } while (0)

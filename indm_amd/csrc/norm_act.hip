@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
                                                             int C, int G, int GS, float eps, int act, float drop_p,
                                                             uint64_t seed) {
   __shared__ float sh[4 * GNF_MAXG * 2];   // [wave][group][sum, sum of squares]
+  // every kernel argument is loaded HERE, not where it is first used (hipcc otherwise issues the scalar loads of gamma /
+  // beta / y / mean / rstd after the statistics phase; see tools/late_kernarg_scan.py and DESIGN.md section 6)
+  INDM_PIN_ARGS9(gamma, beta, y, mean, rstd, eps, act, drop_p, seed);
   const int bs = blockDim.x, tid = threadIdx.x;
   int n, gb;
   gnf_decode(blockIdx.x, G / GS, N, n, gb);
@@ -389,12 +392,13 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
 // tools/flake_pattern.py): 256 per-thread partials in LDS, one barrier, GS threads fold them serially while the other waves
 // wait at the next barrier.  On a GPU shared by more processes than it has queue slots this kernel occasionally returned
 // statistics with part of the partials missing; the butterfly form above has not.
-template <int NF4>
+template <int NF4, bool PIN>
 __global__ __launch_bounds__(256) void gn_fused_fwd_serial_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int N, int HW,
                                                             int C, int G, int GS, float eps, int act, float drop_p,
                                                             uint64_t seed) {
+  if constexpr (PIN) INDM_PIN_ARGS9(gamma, beta, y, mean, rstd, eps, act, drop_p, seed);   // INDM_GN_FUSED=3: the A/B arm "serial fold, arguments loaded at the start"
   __shared__ float sh[2 * 256];
   __shared__ float st[2 * GNF_MAXG];
   const int bs = blockDim.x, tid = threadIdx.x;
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
                                                             float* __restrict__ dx, float* __restrict__ cpart, int N, int HW,
                                                             int C, int G, int GS, int act, float drop_p, uint64_t seed) {
   __shared__ float sh[4 * 8 * 8];         // [wave][quad][4: sum d, 4: sum d*xh]
+  INDM_PIN_ARGS9(gamma, beta, mean, rstd, dx, cpart, act, drop_p, seed);
   __shared__ float chs[2 * 32];           // channel sums of the slab (CS <= 32)
   __shared__ float gs_[2 * GNF_MAXG];     // group sums
   const int bs = blockDim.x, tid = threadIdx.x;
@@ -844,11 +849,13 @@ INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const fl
   const GnFused ff = gn_fused_geom(HW, C, G);
   if (ff.nf4) {   // single pass: one workgroup per (image, group block) keeps its slab in registers
     const dim3 grid((G / ff.gs) * N), block(ff.bs);
-    static const int serial = getenv("INDM_GN_FUSED") && atoi(getenv("INDM_GN_FUSED")) == 2;   // the round-3 reproducer
+    static const int serial = getenv("INDM_GN_FUSED") ? atoi(getenv("INDM_GN_FUSED")) : 1;   // 2 / 3: the round-3 reproducer
 #define GNF_FWD(NF)                                                                                                          \
   do {                                                                                                                       \
-    if (serial) hipLaunchKernelGGL(gn_fused_fwd_serial_kernel<NF>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, N, HW, \
-                                   C, G, ff.gs, eps, act, drop_p, (uint64_t)seed);                                           \
+    if (serial == 2) hipLaunchKernelGGL((gn_fused_fwd_serial_kernel<NF, false>), grid, block, 0, st, x, gamma, beta, y, mean,  \
+                                        rstd, N, HW, C, G, ff.gs, eps, act, drop_p, (uint64_t)seed);                         \
+    else if (serial == 3) hipLaunchKernelGGL((gn_fused_fwd_serial_kernel<NF, true>), grid, block, 0, st, x, gamma, beta, y,   \
+                                             mean, rstd, N, HW, C, G, ff.gs, eps, act, drop_p, (uint64_t)seed);              \
     else hipLaunchKernelGGL(gn_fused_fwd_kernel<NF>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, N, HW, C, G, ff.gs,  \
                             eps, act, drop_p, (uint64_t)seed);                                                               \
   } while (0)

@@ -53,3 +53,21 @@ def test_scanner_sees_a_planted_hazard(tmp_path):
                  "\tv_mov_b32_e32 v3, v2\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n"
                  "\tv_mov_b64_e32 v[68:69], v[84:85]\n\ts_endpgm\n")
     assert not asm_async_scan.scan(str(s))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_fused_groupnorm_loads_its_arguments_before_its_first_barrier(tmp_path):
+    """Round 4 traced the suite's reproducibility flake to round 3's fused GroupNorm forward, which hipcc compiled with the
+    scalar loads of gamma / beta / y / mean / rstd AFTER its statistics phase (tools/late_kernarg_scan.py).  The production
+    kernels pin every argument at their first instruction; the round-3 form kept as the stress reproducer
+    (gn_fused_fwd_serial_kernel<*, false>, INDM_GN_FUSED=2) must still show the pattern -- the scanner's positive control."""
+    import late_kernarg_scan
+    out = tmp_path / "norm_act.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                    "-ffp-contract=off", "--cuda-device-only", "-S", os.path.join(CSRC, "norm_act.hip"), "-o", str(out)],
+                   check=True, capture_output=True, timeout=900)
+    hits = late_kernarg_scan.scan(str(out))
+    names = [h[0] for h in hits]
+    assert not [n for n in names if "gn_fused_fwd_kernel" in n or "gn_fused_bwd_kernel" in n], names
+    assert not [n for n in names if "gn_fused_fwd_serial_kernel" in n and "ELb1E" in n], names       # the pinned A/B arm
+    assert [n for n in names if "gn_fused_fwd_serial_kernel" in n and "ELb0E" in n], "the reproducer lost its late loads"
