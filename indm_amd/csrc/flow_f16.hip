@@ -336,8 +336,7 @@ int launch_rows(const RowsArgs& a, hipStream_t st) {
 // 128 pixels x 128 columns per tile, 4 waves (wave w: pixels 32 w .. 32 w + 31, four 32-column blocks), persistent over
 // the pixel tiles of one column tile (its weights are packed into LDS once).  K = 9 C is padded to S = ceil(K / 16)
 // k-steps; the operand fragments use consecutive k per lane (k = 16 s + 8 lhi + e) on both sides.  A lane GATHERS the
-// fragment it multiplies (lane l31 = its pixel, its 8 k per step): the im2col values never pass through LDS, and the
-// next tile's gather is in flight under this tile's MFMAs and stores.
+// fragment it multiplies (lane l31 = its pixel, its 8 k per step): the im2col values never pass through LDS.
 enum { TC_PLAIN = 0, TC_ACT = 1, TC_GATE = 2 };
 constexpr int TC_TM = 128, TC_TN = 128;
 
@@ -351,21 +350,32 @@ struct ThinConvArgs {
   int N, H, W, C, Cout, sign;
 };
 
-// SMAX: k-steps the instantiation holds registers for; VEC4: C % 4 == 0, four consecutive k share a tap (float4 loads)
+// SMAX: upper bound of the k-steps (loop unrolling); VEC4: C % 4 == 0, four consecutive k share a tap (float4 loads).
+// One workgroup per (128-pixel tile, 128-column tile), column tiles fastest (the four workgroups that gather the same
+// pixels are neighbours: the image patch comes out of L2); three workgroups per CU hide each other's phases.  The gate
+// chunks of the epilogue (TC_GATE) are requested FIRST, before the weights are packed and the pixels gathered.
 template <int EPI, int SMAX, bool VEC4>
-__global__ __launch_bounds__(256, 2) void f16_thin_conv_kernel(ThinConvArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char tc_smem[];
-  u16* wf = (u16*)tc_smem;   // weights [s][nblk][lane][8]
+__global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
+  __shared__ __attribute__((aligned(16))) u16 wf[SMAX * 4 * 64 * 8];   // weights [s][nblk][lane][8]
+  __shared__ float bsh[TC_TN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int C = p.C, K = 9 * C, S = (K + 15) >> 4;
   const int tiles_n = p.Cout / TC_TN;
-  const long M = (long)p.N * p.H * p.W;
-  const int tiles_m = (int)(M / TC_TM);
-  const int tn = blockIdx.x % tiles_n, mstep = gridDim.x / tiles_n;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
   const int n0 = tn * TC_TN;
   const int HW = p.H * p.W;
+  const long mt = (long)tm * 4 + wave;
+  const int nbn = p.Cout >> 5;
+  auto chunk = [&](int jn, int s) -> long { return (((mt * nbn + (n0 >> 5) + jn) * 2 + s) * 64 + lane) * 8; };
 
+  u32x4 gq[4][2];
+  if constexpr (EPI == TC_GATE) {
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) gq[jn][s] = *(const u32x4*)(p.G + chunk(jn, s));
+  }
   // ---- weights of this column tile -> fragment order (A role: lane l31 = output column, k = 16 s + 8 lhi + e)
   for (int u = tid; u < S * 4 * 64; u += 256) {
     const int ln = u & 63, nb = (u >> 6) & 3, s = u >> 8;
@@ -377,103 +387,92 @@ __global__ __launch_bounds__(256, 2) void f16_thin_conv_kernel(ThinConvArgs p) {
     }
     *(u32x4*)(wf + u * 8) = pack8(v);
   }
-  float bv[4][16];
+  if (tid < TC_TN) bsh[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+
+  // ---- this lane's pixel and its im2col fragments (B role: lane l31 = pixel, k = 16 s + 8 lhi + e), gathered k-step by
+  // k-step straight into the MFMA operand registers
+  const long pix = (long)tm * TC_TM + wave * 32 + l31;
+  const int img = (int)(pix / HW), r = (int)(pix - (long)img * HW);
+  const int h = r / p.W, w = r - h * p.W;
+  const float* base = p.X + pix * C;
+  bf16x8 hx[SMAX];
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) {
+    float gv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+    if (s < S) {
+      if constexpr (VEC4) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int k = 16 * s + 8 * lhi + 4 * q;
+          const int tap = k / C, c = k - tap * C;
+          const int kh = tap / 3, kw = tap - 3 * kh;
+          const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
+          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
+            const float4 v = *(const float4*)(base + ((hh - h) * p.W + (ww - w)) * C + c);
+            gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 16 * s + 8 * lhi + e;
+          const int tap = k / C, c = k - tap * C;
+          const int kh = tap / 3, kw = tap - 3 * kh;
+          const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
+          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) gv[e] = base[((hh - h) * p.W + (ww - w)) * C + c];
+        }
+      }
+    }
+    hx[s] = __builtin_bit_cast(bf16x8, pack8(gv));
+  }
+  __syncthreads();   // wf, bsh complete
+  f32x16 acc[4];
 #pragma unroll
   for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) b = *(const float4*)(p.bias + n0 + jn * 32 + 8 * a + 4 * lhi);
-      bv[jn][4 * a] = b.x; bv[jn][4 * a + 1] = b.y; bv[jn][4 * a + 2] = b.z; bv[jn][4 * a + 3] = b.w;
-    }
-
-  // ---- per-thread tap table (tile-invariant): for load unit q (one k, or four k of one tap) the element offset
-  // relative to the pixel's own element offset, and (dh + 1) | (dw + 1) << 2 | exists << 4
-  constexpr int NU = VEC4 ? SMAX * 2 : SMAX * 8;
-  int toff[NU], tmeta[NU];
+    for (int rr = 0; rr < 16; ++rr) acc[jn][rr] = 0.f;
 #pragma unroll
-  for (int q = 0; q < NU; ++q) {
-    const int k = VEC4 ? 16 * (q >> 1) + 8 * lhi + 4 * (q & 1) : 16 * (q >> 3) + 8 * lhi + (q & 7);
-    const int tap = k / C, c = k - tap * C;
-    const int kh = tap / 3, kw = tap - 3 * kh;
-    const int dh = -p.sign * (kh - 1), dw = -p.sign * (kw - 1);
-    toff[q] = (dh * p.W + dw) * C + c;
-    tmeta[q] = k < K ? ((dh + 1) | ((dw + 1) << 2) | 16) : 0;
+  for (int s = 0; s < SMAX; ++s) {
+    if (s < S) {
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+        const bf16x8 hw = *(const bf16x8*)(wf + ((s * 4 + jn) * 64 + lane) * 8);
+        acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw, hx[s], acc[jn], 0, 0, 0);   // D[co][pixel]
+      }
+    }
   }
-  auto gather = [&](int tm, float (&gv)[SMAX][8]) {
-    const long pix = (long)tm * TC_TM + wave * 32 + l31;
-    const int img = (int)(pix / HW), r = (int)(pix - (long)img * HW);
-    const int h = r / p.W, w = r - h * p.W;
-    const float* base = p.X + pix * C;
+  // ---- epilogue: acc[jn][r] = out[pixel = 32 mt + l31][co = n0 + 32 jn + (r & 3) + 8 (r >> 2) + 4 lhi]
 #pragma unroll
-    for (int q = 0; q < NU; ++q) {
-      const int hh = h + (tmeta[q] & 3) - 1, ww = w + ((tmeta[q] >> 2) & 3) - 1;
-      const bool ok = (tmeta[q] & 16) && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
-      if constexpr (VEC4) {
-        const float4 v = ok ? *(const float4*)(base + toff[q]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        gv[q >> 1][4 * (q & 1)] = v.x; gv[q >> 1][4 * (q & 1) + 1] = v.y;
-        gv[q >> 1][4 * (q & 1) + 2] = v.z; gv[q >> 1][4 * (q & 1) + 3] = v.w;
-      } else {
-        gv[q >> 3][q & 7] = ok ? base[toff[q]] : 0.f;
+  for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const long ci = chunk(jn, s);
+      float v[8], w8[8];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const float4 b = *(const float4*)(bsh + jn * 32 + 16 * s + 8 * a + 4 * lhi);
+        v[4 * a] = acc[jn][8 * s + 4 * a] + b.x; v[4 * a + 1] = acc[jn][8 * s + 4 * a + 1] + b.y;
+        v[4 * a + 2] = acc[jn][8 * s + 4 * a + 2] + b.z; v[4 * a + 3] = acc[jn][8 * s + 4 * a + 3] + b.w;
       }
+      if constexpr (EPI == TC_ACT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sin_act(v[e], v[e], w8[e]);
+        *(u32x4*)(p.O2 + ci) = pack8(w8);
+      } else if constexpr (EPI == TC_GATE) {
+        if (p.O2) *(u32x4*)(p.O2 + ci) = pack8(v);
+        unpack8(gq[jn][s], w8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= w8[e];
+      }
+      *(u32x4*)(p.O1 + ci) = pack8(v);
     }
-  };
-
-  float gv[SMAX][8];
-  int tm = blockIdx.x / tiles_n;
-  if (tm < tiles_m) gather(tm, gv);
-  __syncthreads();   // wf is complete
-  for (; tm < tiles_m; tm += mstep) {
-    bf16x8 hx[SMAX];
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) hx[s] = __builtin_bit_cast(bf16x8, pack8(gv[s]));
-    const int tnext = tm + mstep;
-    if (tnext < tiles_m) gather(tnext, gv);   // in flight under the MFMAs and the stores of this tile
-    f32x16 acc[4];
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[jn][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) {
-      if (s < S) {
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-          const bf16x8 hw = *(const bf16x8*)(wf + ((s * 4 + jn) * 64 + lane) * 8);
-          acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw, hx[s], acc[jn], 0, 0, 0);   // D[co][pixel]
-        }
-      }
-    }
-    // ---- epilogue: acc[jn][r] = out[pixel = 32 (4 tm + wave) + l31][co = n0 + 32 jn + (r & 3) + 8 (r >> 2) + 4 lhi]
-    const long mt = (long)tm * 4 + wave;
-    const int nbn = p.Cout >> 5;
-#pragma unroll
-    for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const long ci = (((mt * nbn + (n0 >> 5) + jn) * 2 + s) * 64 + lane) * 8;
-        float v[8], w[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[jn][8 * s + e] + bv[jn][8 * s + e];
-        if constexpr (EPI == TC_ACT) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) sin_act(v[e], v[e], w[e]);
-          *(u32x4*)(p.O2 + ci) = pack8(w);
-        } else if constexpr (EPI == TC_GATE) {
-          if (p.O2) *(u32x4*)(p.O2 + ci) = pack8(v);
-          unpack8(*(const u32x4*)(p.G + ci), w);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= w[e];
-        }
-        *(u32x4*)(p.O1 + ci) = pack8(v);
-      }
-  }
 }
 
 template <int EPI, int SMAX, bool VEC4>
 int launch_thin_conv(const ThinConvArgs& a, dim3 grid, hipStream_t st) {
-  constexpr int bytes = SMAX * 4 * 64 * 8 * 2;
-  hipLaunchKernelGGL((f16_thin_conv_kernel<EPI, SMAX, VEC4>), grid, dim3(256), bytes, st, a);
+  hipLaunchKernelGGL((f16_thin_conv_kernel<EPI, SMAX, VEC4>), grid, dim3(256), 0, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 template <int EPI>
@@ -801,10 +800,8 @@ INDM_API int indm_f16_thin_conv(const float* x, const float* w, const float* bia
   if (!al16(bias) || !al16(out1) || !al16(out2) || !al16(gate)) return INDM_E_ARG;
   ThinConvArgs a = {x, w, bias, (const u16*)gate, (u16*)out1, (u16*)out2, Nimg, H, W, C, Cout, sign};
   const int tiles_n = Cout / TC_TN, tiles_m = (int)(M / TC_TM);
-  int groups = 512 / tiles_n;   // two workgroups per CU
-  if (groups > tiles_m) groups = tiles_m;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(groups * tiles_n);
+  dim3 grid(tiles_m * tiles_n);
   if (epilogue == TC_PLAIN) return launch_thin_conv_e<TC_PLAIN>(a, grid, st);
   if (epilogue == TC_ACT) return launch_thin_conv_e<TC_ACT>(a, grid, st);
   if (epilogue == TC_GATE) return launch_thin_conv_e<TC_GATE>(a, grid, st);
