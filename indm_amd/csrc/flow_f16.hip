@@ -140,30 +140,32 @@ struct RowsArgs {
   int M, J, rpg;
 };
 
-template <int MODE, int JB, bool T2OUT>
+// TMV = 64 rows per workgroup, or 32 when M is too small to give every CU its two 64-row workgroups (per-rank shards)
+template <int MODE, int JB, bool T2OUT, int TMV>
 __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
+  constexpr int MB = TMV / 32;   // 32-row blocks per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const long tile = blockIdx.x;
-  const long m0 = tile * R_TM;
+  const long m0 = tile * TMV;
 
-  // ---- the A tile: 64 rows x 512 columns of F16 memory = 64 consecutive 1 KB chunks; chunk c = 32 j + ks is fragment
-  // (m-block j, k-step ks).  Eight chunks per wave, two copy groups.
+  // ---- the A tile: TMV rows x 512 columns of F16 memory = 32 MB consecutive 1 KB chunks; chunk c = 32 j + ks is fragment
+  // (m-block j, k-step ks).  4 MB chunks per wave.
   {
-    const char* src = (const char*)p.A + tile * (long)R_LDS_BYTES + (long)wave * 8192;
+    const char* src = (const char*)p.A + tile * (long)(TMV * R_N * 2) + (long)wave * (MB * 4096);
     const unsigned voff = 16u * lane;
-    dma_x4(lds_addr(smem + wave * 8192), voff, src);
-    dma_x4(lds_addr(smem + wave * 8192 + 4096), voff, src + 4096);
+#pragma unroll
+    for (int g = 0; g < MB; ++g) dma_x4(lds_addr(smem + wave * (MB * 4096) + g * 4096), voff, src + g * 4096);
   }
-  f32x16 acc[2][2];
-  bf16x8 hm2[2][2][2];   // stage-2 operand fragments [i][j][s] (CHAIN: gated accumulators; THIN_N: A fragments)
+  f32x16 acc[2][MB];
+  bf16x8 hm2[2][MB][2];   // stage-2 operand fragments [i][j][s] (CHAIN: gated accumulators; THIN_N: A fragments)
   if constexpr (MODE != R_THINN) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < MB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // weights of this wave's two 32-column blocks, k-step ks: Bp[(ks * 16 + 2 wave + i) * 64 + lane] (16 bytes)
@@ -181,9 +183,9 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int ks = k0 + d;
-        bf16x8 hm[2];
+        bf16x8 hm[MB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) hm[j] = *(const bf16x8*)(smem + (j * 32 + ks) * 1024 + lane * 16);
+        for (int j = 0; j < MB; ++j) hm[j] = *(const bf16x8*)(smem + (j * 32 + ks) * 1024 + lane * 16);
         bf16x8 hn[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) hn[i] = __builtin_bit_cast(bf16x8, q[d][i]);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < MB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hn[i], hm[j], acc[i][j], 0, 0, 0);  // D[n][m]
       }
     }
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < MB; ++j)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
           hm2[i][j][s] = *(const bf16x8*)(smem + (j * 32 + 2 * (2 * wave + i) + s) * 1024 + lane * 16);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
 
   // chunk (m-block j, column block 2 wave + i, half s) of an F16 [M, 512] tensor, this lane's 16 bytes
   auto chunk = [&](int i, int j, int s) -> long {
-    return ((((tile * 2 + j) * 16 + 2 * wave + i) * 2 + s) * 64 + lane) * 8;   // bf16 index
+    return ((((tile * MB + j) * 16 + 2 * wave + i) * 2 + s) * 64 + lane) * 8;   // bf16 index
   };
 
   if constexpr (MODE == R_GEMM || MODE == R_GEMM_ACT) {
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
         bv[4 * a] = b.x; bv[4 * a + 1] = b.y; bv[4 * a + 2] = b.z; bv[4 * a + 3] = b.w;
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < MB; ++j)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           float v[8], w[8];
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < MB; ++j)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           float v[8], g[8];
@@ -273,13 +275,13 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
   if constexpr (MODE == R_THINN) __syncthreads();
 
   // ---- stage 2: out[m][jp] = sum over this wave's 64 k of u[m][k] Wp[k][jp]; 8-way reduction over the waves through LDS
-  float* red = (float*)smem;   // [8 waves][64 m][32 jp]
+  float* red = (float*)smem;   // [8 waves][TMV m][32 jp]
   const u32x4* pp = (const u32x4*)p.Pp + lane;
 #pragma unroll 1
   for (int jb = 0; jb < JB; ++jb) {
-    f32x16 out[2];
+    f32x16 out[MB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) out[j][r] = 0.f;
 #pragma unroll
@@ -288,24 +290,24 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
       for (int s = 0; s < 2; ++s) {
         const bf16x8 hp = __builtin_bit_cast(bf16x8, pp[((long)(2 * (2 * wave + i) + s) * JB + jb) * 64]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MB; ++j)
           out[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hm2[i][j][s], hp, out[j], 0, 0, 0);   // D[m][jp]
       }
     if (jb > 0) __syncthreads();   // the previous round's reduction has read `red`
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = j * 32 + 8 * (r >> 2) + (r & 3) + 4 * lhi;
-        red[(wave * R_TM + m) * 32 + l31] = out[j][r];
+        red[(wave * TMV + m) * 32 + l31] = out[j][r];
       }
     __syncthreads();
-    {  // 64 x 32 outputs, 4 per thread: thread -> (m = tid / 8, jp = (tid % 8) * 4 .. +3)
+    if (tid < TMV * 8) {  // TMV x 32 outputs, 4 per thread: thread -> (m = tid / 8, jp = (tid % 8) * 4 .. +3)
       const int m = tid >> 3, j0 = (tid & 7) * 4;
       float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int wv = 0; wv < R_NW; ++wv) {
-        const float4 v = *(const float4*)(red + (wv * R_TM + m) * 32 + j0);
+        const float4 v = *(const float4*)(red + (wv * TMV + m) * 32 + j0);
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
       }
       float* dst = p.P + (m0 + m) * p.J + jb * 32 + j0;
@@ -318,17 +320,24 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
   }
 }
 
-template <int MODE, int JB, bool T2OUT>
-int launch_rows(const RowsArgs& a, hipStream_t st) {
+template <int MODE, int JB, bool T2OUT, int TMV>
+int launch_rows_tm(const RowsArgs& a, hipStream_t st) {
+  constexpr int bytes = TMV * R_N * 2;
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)f16_rows_kernel<MODE, JB, T2OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            R_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)f16_rows_kernel<MODE, JB, T2OUT, TMV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            bytes) != hipSuccess)
       return INDM_E_LAUNCH;
     ready = true;
   }
-  hipLaunchKernelGGL((f16_rows_kernel<MODE, JB, T2OUT>), dim3(a.M / R_TM), dim3(R_NW * 64), R_LDS_BYTES, st, a);
+  hipLaunchKernelGGL((f16_rows_kernel<MODE, JB, T2OUT, TMV>), dim3(a.M / TMV), dim3(R_NW * 64), bytes, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+template <int MODE, int JB, bool T2OUT>
+int launch_rows(const RowsArgs& a, hipStream_t st) {
+  // fewer than two 64-row workgroups per CU (M < 32768): 32-row workgroups, twice as many
+  if (a.M / R_TM < 512) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
+  return launch_rows_tm<MODE, JB, T2OUT, 64>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
