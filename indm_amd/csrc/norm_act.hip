@@ -516,18 +516,34 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
   // channel sums of the slab: per-wave butterfly sums over the lanes that own the same channel quad (fixed order), one LDS
   // row per (wave, quad), then the waves' rows are added in wave order
   const int wave = tid >> 6, nw = bs >> 6;
+  if ((CS4 & (CS4 - 1)) == 0) {
+    // 1, 2, 4 or 8 quads: the lanes that own one quad are CS4 apart (64 % CS4 == 0) -> strided butterfly, log2(64 / CS4)
+    // steps per value; afterwards every lane holds its own quad's wave sum and lanes 0 .. CS4-1 (quad = lane) publish it
+    float v8[8];
 #pragma unroll
-  for (int qq = 0; qq < 8; ++qq) {
-    if (qq < CS4) {
-      float v8[8];
+    for (int j = 0; j < 4; ++j) { v8[j] = a1[j]; v8[4 + j] = a2[j]; }
+    for (int off = CS4; off < 64; off <<= 1) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v8[j] = wave_sum(q == qq ? a1[j] : 0.f);
-        v8[4 + j] = wave_sum(q == qq ? a2[j] : 0.f);
-      }
-      if ((tid & 63) == 0) {
+      for (int j = 0; j < 8; ++j) v8[j] += __shfl_xor(v8[j], off, 64);
+    }
+    if ((tid & 63) < CS4) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sh[(wave * 8 + qq) * 8 + j] = v8[j];
+      for (int j = 0; j < 8; ++j) sh[(wave * 8 + (tid & 63)) * 8 + j] = v8[j];
+    }
+  } else {
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {   // 3 or 6 quads (bs = 192): masked full-wave sums
+      if (qq < CS4) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v8[j] = wave_sum(q == qq ? a1[j] : 0.f);
+          v8[4 + j] = wave_sum(q == qq ? a2[j] : 0.f);
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sh[(wave * 8 + qq) * 8 + j] = v8[j];
+        }
       }
     }
   }
