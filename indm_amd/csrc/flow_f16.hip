@@ -335,8 +335,9 @@ int launch_rows_tm(const RowsArgs& a, hipStream_t st) {
 }
 template <int MODE, int JB, bool T2OUT>
 int launch_rows(const RowsArgs& a, hipStream_t st) {
-  // fewer than two 64-row workgroups per CU (M < 32768): 32-row workgroups, twice as many
-  if (a.M / R_TM < 512) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
+  // fewer than two 64-row workgroups per CU (M < 32768): 32-row workgroups, twice as many.  The thin-N mode has no main
+  // loop to amortise a tile's load latency over: always 32-row tiles (32 KB of LDS: four workgroups per CU overlap).
+  if (a.M / R_TM < 512 || MODE == R_THINN) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
   return launch_rows_tm<MODE, JB, T2OUT, 64>(a, st);
 }
 
@@ -357,6 +358,7 @@ struct ThinConvArgs {
   u16* O1;            // PLAIN: out; ACT: a; GATE: out .* G
   u16* O2;            // ACT: cos; GATE: raw out (optional)
   int N, H, W, C, Cout, sign;
+  int tpw;            // consecutive pixel tiles per workgroup
 };
 
 // SMAX: upper bound of the k-steps (loop unrolling); VEC4: C % 4 == 0, four consecutive k share a tap (float4 loads).
@@ -371,11 +373,11 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
   const int l31 = lane & 31, lhi = lane >> 5;
   const int C = p.C, K = 9 * C, S = (K + 15) >> 4;
   const int tiles_n = p.Cout / TC_TN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int tn = blockIdx.x % tiles_n, tm0 = (blockIdx.x / tiles_n) * p.tpw;
   const int n0 = tn * TC_TN;
   const int HW = p.H * p.W;
-  const long mt = (long)tm * 4 + wave;
   const int nbn = p.Cout >> 5;
+  long mt = (long)tm0 * 4 + wave;
   auto chunk = [&](int jn, int s) -> long { return (((mt * nbn + (n0 >> 5) + jn) * 2 + s) * 64 + lane) * 8; };
 
   u32x4 gq[4][2];
@@ -398,12 +400,27 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
   }
   if (tid < TC_TN) bsh[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
 
+  __syncthreads();   // wf, bsh complete
+  // ---- p.tpw consecutive pixel tiles per workgroup (the packed weights are built once)
+#pragma unroll 1
+  for (int it = 0; it < p.tpw; ++it, mt += 4) {
+  const int tm = tm0 + it;
+  int Cq = C;                          // opaque per iteration: keeps the tap decode of the gather INSIDE the loop (hoisted, it
+  asm volatile("" : "+s"(Cq));         // costs ~100 live registers and spills)
+  if (it > 0) {
+    if constexpr (EPI == TC_GATE) {
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) gq[jn][s] = *(const u32x4*)(p.G + chunk(jn, s));
+    }
+  }
   // ---- this lane's pixel and its im2col fragments (B role: lane l31 = pixel, k = 16 s + 8 lhi + e), gathered k-step by
   // k-step straight into the MFMA operand registers
   const long pix = (long)tm * TC_TM + wave * 32 + l31;
   const int img = (int)(pix / HW), r = (int)(pix - (long)img * HW);
   const int h = r / p.W, w = r - h * p.W;
-  const float* base = p.X + pix * C;
+  const float* base = p.X + pix * Cq;
   bf16x8 hx[SMAX];
 #pragma unroll
   for (int s = 0; s < SMAX; ++s) {
@@ -415,11 +432,11 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int k = 16 * s + 8 * lhi + 4 * q;
-          const int tap = k / C, c = k - tap * C;
+          const int tap = k / Cq, c = k - tap * Cq;
           const int kh = tap / 3, kw = tap - 3 * kh;
           const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
           if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
-            const float4 v = *(const float4*)(base + ((hh - h) * p.W + (ww - w)) * C + c);
+            const float4 v = *(const float4*)(base + ((hh - h) * p.W + (ww - w)) * Cq + c);
             gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
           }
         }
@@ -427,16 +444,15 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int k = 16 * s + 8 * lhi + e;
-          const int tap = k / C, c = k - tap * C;
+          const int tap = k / Cq, c = k - tap * Cq;
           const int kh = tap / 3, kw = tap - 3 * kh;
           const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
-          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) gv[e] = base[((hh - h) * p.W + (ww - w)) * C + c];
+          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) gv[e] = base[((hh - h) * p.W + (ww - w)) * Cq + c];
         }
       }
     }
     hx[s] = __builtin_bit_cast(bf16x8, pack8(gv));
   }
-  __syncthreads();   // wf, bsh complete
   f32x16 acc[4];
 #pragma unroll
   for (int jn = 0; jn < 4; ++jn)
@@ -477,6 +493,7 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
       }
       *(u32x4*)(p.O1 + ci) = pack8(v);
     }
+  }
 }
 
 template <int EPI, int SMAX, bool VEC4>
@@ -689,10 +706,12 @@ struct WgradGemmArgs {
   float* part;
   int mts, per, S;
 };
+constexpr int WG2_RS = 72;   // image row of the GEMM form: TWO 32-row slabs per barrier (64 rows) + 8 pad halfwords
 template <bool GATED>
 __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p) {
-  __shared__ __attribute__((aligned(16))) u16 Xt[2][128 * WG_RS];
-  __shared__ __attribute__((aligned(16))) u16 Yt[2][128 * WG_RS];
+  extern __shared__ __attribute__((aligned(16))) char wg_smem[];     // 72 KB: above the 64 KB a kernel gets without opt-in
+  u16 (*Xt)[128 * WG2_RS] = (u16 (*)[128 * WG2_RS])wg_smem;
+  u16 (*Yt)[128 * WG2_RS] = (u16 (*)[128 * WG2_RS])(wg_smem + 2 * 128 * WG2_RS * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   // block b runs on XCD b % 8: splits xcd, xcd + 8, ... live there, 16 consecutive local blocks = the tiles of one split
@@ -709,36 +728,57 @@ __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // loader: wave w stages the 32-column block w of the X tile and of the Y tile
-  u32x4 xq[2], gq[2], yq[2];
+  // loader: wave w stages the 32-column block w of the X tile and of the Y tile, two 32-row slabs per step
+  u32x4 xq[2][2], gq[2][2], yq[2][2];
+  const u32x4 zero = {0u, 0u, 0u, 0u};
   auto gload = [&](int mt) {
-    const long gx = (((long)mt * 16 + t1 * 4 + wave) * 2) * 64 + lane, gy = (((long)mt * 16 + t2 * 4 + wave) * 2) * 64 + lane;
-    xq[0] = ((const u32x4*)p.X)[gx];
-    xq[1] = ((const u32x4*)p.X)[gx + 64];
-    yq[0] = ((const u32x4*)p.Y)[gy];
-    yq[1] = ((const u32x4*)p.Y)[gy + 64];
-    if constexpr (GATED) {
-      gq[0] = ((const u32x4*)p.G)[gx];
-      gq[1] = ((const u32x4*)p.G)[gx + 64];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (mt + u < mt1) {
+        const long gx = (((long)(mt + u) * 16 + t1 * 4 + wave) * 2) * 64 + lane, gy = (((long)(mt + u) * 16 + t2 * 4 + wave) * 2) * 64 + lane;
+        xq[u][0] = ((const u32x4*)p.X)[gx];
+        xq[u][1] = ((const u32x4*)p.X)[gx + 64];
+        yq[u][0] = ((const u32x4*)p.Y)[gy];
+        yq[u][1] = ((const u32x4*)p.Y)[gy + 64];
+        if constexpr (GATED) {
+          gq[u][0] = ((const u32x4*)p.G)[gx];
+          gq[u][1] = ((const u32x4*)p.G)[gx + 64];
+        }
+      } else {   // odd tail of the split: a slab of zeros
+        xq[u][0] = xq[u][1] = yq[u][0] = yq[u][1] = zero;
+        if constexpr (GATED) gq[u][0] = gq[u][1] = zero;
+      }
     }
   };
+  auto tstore = [&](u16* img, const float (&v)[2][8], int u) {   // chunk registers -> image[column][32 u + m]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int n = 16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3);
+        img[n * WG2_RS + 32 * u + l31] = __builtin_bit_cast(u16, (__bf16)v[s][e]);
+      }
+  };
   auto sstore = [&](int buf) {
-    float v[2][8];
-    unpack8(xq[0], v[0]);
-    unpack8(xq[1], v[1]);
-    if constexpr (GATED) {
-      float gg[2][8];
-      unpack8(gq[0], gg[0]);
-      unpack8(gq[1], gg[1]);
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+    for (int u = 0; u < 2; ++u) {
+      float v[2][8];
+      unpack8(xq[u][0], v[0]);
+      unpack8(xq[u][1], v[1]);
+      if constexpr (GATED) {
+        float gg[2][8];
+        unpack8(gq[u][0], gg[0]);
+        unpack8(gq[u][1], gg[1]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[s][e] *= gg[s][e];
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[s][e] *= gg[s][e];
+      }
+      tstore(Xt[buf] + wave * 32 * WG2_RS, v, u);
+      unpack8(yq[u][0], v[0]);
+      unpack8(yq[u][1], v[1]);
+      tstore(Yt[buf] + wave * 32 * WG2_RS, v, u);
     }
-    transpose_store(Xt[buf] + wave * 32 * WG_RS, v, l31, lhi);
-    unpack8(yq[0], v[0]);
-    unpack8(yq[1], v[1]);
-    transpose_store(Yt[buf] + wave * 32 * WG_RS, v, l31, lhi);
   };
   if (mt0 < mt1) {
     gload(mt0);
@@ -746,21 +786,21 @@ __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p)
   }
   __syncthreads();
   int buf = 0;
-  for (int mt = mt0; mt < mt1; ++mt, buf ^= 1) {
-    if (mt + 1 < mt1) gload(mt + 1);
+  for (int mt = mt0; mt < mt1; mt += 2, buf ^= 1) {
+    if (mt + 2 < mt1) gload(mt + 2);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       bf16x8 ha[2], hb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) ha[i] = *(const bf16x8*)(Xt[buf] + ((w1 * 2 + i) * 32 + l31) * WG_RS + 16 * ks + 8 * lhi);
+      for (int i = 0; i < 2; ++i) ha[i] = *(const bf16x8*)(Xt[buf] + ((w1 * 2 + i) * 32 + l31) * WG2_RS + 16 * ks + 8 * lhi);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) hb[j] = *(const bf16x8*)(Yt[buf] + ((w2 * 2 + j) * 32 + l31) * WG_RS + 16 * ks + 8 * lhi);
+      for (int j = 0; j < 2; ++j) hb[j] = *(const bf16x8*)(Yt[buf] + ((w2 * 2 + j) * 32 + l31) * WG2_RS + 16 * ks + 8 * lhi);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);   // D[n1][n2]
     }
-    if (mt + 1 < mt1) sstore(buf ^ 1);
+    if (mt + 2 < mt1) sstore(buf ^ 1);
     __syncthreads();
   }
   float* out = p.part + (long)split * R_N * R_N;
@@ -807,10 +847,13 @@ INDM_API int indm_f16_thin_conv(const float* x, const float* w, const float* bia
   if (!al16(x)) return 1;
   if (!x || !w || !out1 || (epilogue == TC_ACT && !out2) || (epilogue == TC_GATE && !gate)) return INDM_E_ARG;
   if (!al16(bias) || !al16(out1) || !al16(out2) || !al16(gate)) return INDM_E_ARG;
-  ThinConvArgs a = {x, w, bias, (const u16*)gate, (u16*)out1, (u16*)out2, Nimg, H, W, C, Cout, sign};
+  ThinConvArgs a = {x, w, bias, (const u16*)gate, (u16*)out1, (u16*)out2, Nimg, H, W, C, Cout, sign, 1};
   const int tiles_n = Cout / TC_TN, tiles_m = (int)(M / TC_TM);
+  // several pixel tiles per workgroup (one weight pack for all of them) as long as the grid still fills 256 CUs x 3
+  for (int t = 4; t > 1; t >>= 1)
+    if (tiles_m % t == 0 && (long)(tiles_m / t) * tiles_n >= 768) { a.tpw = t; break; }
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(tiles_m * tiles_n);
+  dim3 grid((tiles_m / a.tpw) * tiles_n);
   if (epilogue == TC_PLAIN) return launch_thin_conv_e<TC_PLAIN>(a, grid, st);
   if (epilogue == TC_ACT) return launch_thin_conv_e<TC_ACT>(a, grid, st);
   if (epilogue == TC_GATE) return launch_thin_conv_e<TC_GATE>(a, grid, st);
@@ -909,8 +952,16 @@ INDM_API int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y
   WgradGemmArgs p = {(const u16*)X, (const u16*)gateX, (const u16*)Y, ws, mts, per, S};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(((S + 7) / 8) * 8 * 16);
-  if (gateX) hipLaunchKernelGGL((f16_wgrad_gemm_kernel<true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((f16_wgrad_gemm_kernel<false>), grid, dim3(256), 0, st, p);
+  constexpr int lds = 4 * 128 * WG2_RS * 2;
+  static bool ready = false;
+  if (!ready) {
+    if (hipFuncSetAttribute((const void*)f16_wgrad_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)f16_wgrad_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return INDM_E_LAUNCH;
+    ready = true;
+  }
+  if (gateX) hipLaunchKernelGGL((f16_wgrad_gemm_kernel<true>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((f16_wgrad_gemm_kernel<false>), grid, dim3(256), lds, st, p);
   INDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3(cdiv((long)R_N * R_N, 256)), dim3(256), 0, st, ws, out, S, R_N, R_N, alpha,
                      transpose, (long)R_N);

@@ -1,5 +1,5 @@
 """Training-step time of config #2 at the per-rank shards of a strong-scaling run (16 / 32 / 64 / 128 images) on one
-MI355X, with the host-return time next to the GPU-done time (run on the GPU box).  usage: shard_bench.py [batches...]
+MI355X, with the host-return time next to the GPU-done time (run on the GPU box).  usage: shard_bench.py [f32|bf16] [batches...]
 INDM_BLOCK_DRIVERS=0 runs the op-level composition for comparison."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,9 +10,12 @@ from indm_amd.rng import DeviceRng
 from bench import synthetic_batch
 
 dev = torch.device("cuda")
-batches = [int(v) for v in sys.argv[1:]] or [16, 32, 64, 128]
+args = sys.argv[1:]
+dtype = args.pop(0) if args and args[0] in ("f32", "bf16") else "f32"
+batches = [int(v) for v in args] or [16, 32, 64, 128]
 cfg = configs.get_config("vp/CIFAR10/indm_nll")
 cfg.device = dev
+cfg.compute_dtype = dtype
 torch.manual_seed(42)
 score = utils.create_model(cfg, dev)
 flow = create_flow_model(cfg).to(dev)
@@ -32,4 +35,5 @@ for B in batches:
     torch.cuda.synchronize()
     t2 = time.time()
     print(f"batch {B:4d}: {(t2 - t0) / 8 * 1e3:7.1f} ms/step ({B * 8 / (t2 - t0):7.1f} img/s)   host returns after "
-          f"{(t1 - t0) / 8 * 1e3:7.1f} ms/step   drivers={'on' if hip.block_drivers() else 'off'}", flush=True)
+          f"{(t1 - t0) / 8 * 1e3:7.1f} ms/step   drivers={'on' if hip.block_drivers() else 'off'} {dtype} storage={hip.storage_dtype()}", flush=True)
+hip.set_compute_dtype("f32")
