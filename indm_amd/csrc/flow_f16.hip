@@ -624,19 +624,24 @@ __global__ __launch_bounds__(256, 2) void f16_thin_wgrad_kernel(ThinWgradArgs p)
     }
   };
   auto sstore = [&](int buf) {
-    float v[2][8];
-    unpack8(wq[0], v[0]);
-    unpack8(wq[1], v[1]);
     if constexpr (GATED) {
-      float gg[2][8];
+      float v[2][8], gg[2][8];
+      unpack8(wq[0], v[0]);
+      unpack8(wq[1], v[1]);
       unpack8(gq[0], gg[0]);
       unpack8(gq[1], gg[1]);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[s][e] *= gg[s][e];
+      transpose_store(Bt[buf][wave], v, l31, lhi);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          Bt[buf][wave][(16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3)) * WG_RS + l31] = (u16)(wq[s][e >> 1] >> (16 * (e & 1)));
     }
-    transpose_store(Bt[buf][wave], v, l31, lhi);
 #pragma unroll
     for (int i = 0; i < NTH; ++i) {
       const int idx = tid + 256 * i;
@@ -706,12 +711,17 @@ struct WgradGemmArgs {
   float* part;
   int mts, per, S;
 };
-constexpr int WG2_RS = 72;   // image row of the GEMM form: TWO 32-row slabs per barrier (64 rows) + 8 pad halfwords
-template <bool GATED>
+// halfword e of a chunk's four words, as stored (no float round trip for operands that are not gated)
+__device__ __forceinline__ u16 half_of(const u32x4& q, int e) { return (u16)(q[e >> 1] >> (16 * (e & 1))); }
+
+// SL = 32-row slabs per barrier: 2 for the plain form (half the barriers: 145 -> 133 us at M = 131072), 1 for the gated form
+// (with two slabs in flight its chunk registers spill and it ran 172 -> 215 us)
+template <bool GATED, int SL>
 __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char wg_smem[];     // 72 KB: above the 64 KB a kernel gets without opt-in
-  u16 (*Xt)[128 * WG2_RS] = (u16 (*)[128 * WG2_RS])wg_smem;
-  u16 (*Yt)[128 * WG2_RS] = (u16 (*)[128 * WG2_RS])(wg_smem + 2 * 128 * WG2_RS * 2);
+  constexpr int RS = 32 * SL + 8;   // halfwords per image row (80- / 144-byte rows: ds_read_b128 conflict-free)
+  extern __shared__ __attribute__((aligned(16))) char wg_smem[];     // up to 72 KB: above the 64 KB a kernel gets without opt-in
+  u16 (*Xt)[128 * RS] = (u16 (*)[128 * RS])wg_smem;
+  u16 (*Yt)[128 * RS] = (u16 (*)[128 * RS])(wg_smem + 2 * 128 * RS * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   // block b runs on XCD b % 8: splits xcd, xcd + 8, ... live there, 16 consecutive local blocks = the tiles of one split
@@ -728,12 +738,12 @@ __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // loader: wave w stages the 32-column block w of the X tile and of the Y tile, two 32-row slabs per step
-  u32x4 xq[2][2], gq[2][2], yq[2][2];
+  // loader: wave w stages the 32-column block w of the X tile and of the Y tile, SL 32-row slabs per step
+  u32x4 xq[SL][2], gq[SL][2], yq[SL][2];
   const u32x4 zero = {0u, 0u, 0u, 0u};
   auto gload = [&](int mt) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < SL; ++u) {
       if (mt + u < mt1) {
         const long gx = (((long)(mt + u) * 16 + t1 * 4 + wave) * 2) * 64 + lane, gy = (((long)(mt + u) * 16 + t2 * 4 + wave) * 2) * 64 + lane;
         xq[u][0] = ((const u32x4*)p.X)[gx];
@@ -750,34 +760,32 @@ __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p)
       }
     }
   };
-  auto tstore = [&](u16* img, const float (&v)[2][8], int u) {   // chunk registers -> image[column][32 u + m]
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int n = 16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3);
-        img[n * WG2_RS + 32 * u + l31] = __builtin_bit_cast(u16, (__bf16)v[s][e]);
-      }
-  };
   auto sstore = [&](int buf) {
+    u16* xi = Xt[buf] + wave * 32 * RS;
+    u16* yi = Yt[buf] + wave * 32 * RS;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float v[2][8];
-      unpack8(xq[u][0], v[0]);
-      unpack8(xq[u][1], v[1]);
+    for (int u = 0; u < SL; ++u) {
       if constexpr (GATED) {
-        float gg[2][8];
+        float v[2][8], gg[2][8];
+        unpack8(xq[u][0], v[0]);
+        unpack8(xq[u][1], v[1]);
         unpack8(gq[u][0], gg[0]);
         unpack8(gq[u][1], gg[1]);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[s][e] *= gg[s][e];
+          for (int e = 0; e < 8; ++e)
+            xi[(16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3)) * RS + 32 * u + l31] = __builtin_bit_cast(u16, (__bf16)(v[s][e] * gg[s][e]));
+      } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xi[(16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3)) * RS + 32 * u + l31] = half_of(xq[u][s], e);
       }
-      tstore(Xt[buf] + wave * 32 * WG2_RS, v, u);
-      unpack8(yq[u][0], v[0]);
-      unpack8(yq[u][1], v[1]);
-      tstore(Yt[buf] + wave * 32 * WG2_RS, v, u);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) yi[(16 * s + 8 * (e >> 2) + 4 * lhi + (e & 3)) * RS + 32 * u + l31] = half_of(yq[u][s], e);
     }
   };
   if (mt0 < mt1) {
@@ -786,21 +794,21 @@ __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p)
   }
   __syncthreads();
   int buf = 0;
-  for (int mt = mt0; mt < mt1; mt += 2, buf ^= 1) {
-    if (mt + 2 < mt1) gload(mt + 2);
+  for (int mt = mt0; mt < mt1; mt += SL, buf ^= 1) {
+    if (mt + SL < mt1) gload(mt + SL);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 2 * SL; ++ks) {
       bf16x8 ha[2], hb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) ha[i] = *(const bf16x8*)(Xt[buf] + ((w1 * 2 + i) * 32 + l31) * WG2_RS + 16 * ks + 8 * lhi);
+      for (int i = 0; i < 2; ++i) ha[i] = *(const bf16x8*)(Xt[buf] + ((w1 * 2 + i) * 32 + l31) * RS + 16 * ks + 8 * lhi);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) hb[j] = *(const bf16x8*)(Yt[buf] + ((w2 * 2 + j) * 32 + l31) * WG2_RS + 16 * ks + 8 * lhi);
+      for (int j = 0; j < 2; ++j) hb[j] = *(const bf16x8*)(Yt[buf] + ((w2 * 2 + j) * 32 + l31) * RS + 16 * ks + 8 * lhi);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);   // D[n1][n2]
     }
-    if (mt + 2 < mt1) sstore(buf ^ 1);
+    if (mt + SL < mt1) sstore(buf ^ 1);
     __syncthreads();
   }
   float* out = p.part + (long)split * R_N * R_N;
@@ -849,9 +857,8 @@ INDM_API int indm_f16_thin_conv(const float* x, const float* w, const float* bia
   if (!al16(bias) || !al16(out1) || !al16(out2) || !al16(gate)) return INDM_E_ARG;
   ThinConvArgs a = {x, w, bias, (const u16*)gate, (u16*)out1, (u16*)out2, Nimg, H, W, C, Cout, sign, 1};
   const int tiles_n = Cout / TC_TN, tiles_m = (int)(M / TC_TM);
-  // several pixel tiles per workgroup (one weight pack for all of them) as long as the grid still fills 256 CUs x 3
-  for (int t = 4; t > 1; t >>= 1)
-    if (tiles_m % t == 0 && (long)(tiles_m / t) * tiles_n >= 768) { a.tpw = t; break; }
+  // (a.tpw > 1 = several pixel tiles per weight pack: measured SLOWER at every production shape -- 64 -> 74 us gated,
+  // 90 -> 106 us gated + raw at M = 131072 -- fewer, longer workgroups overlap each other's phases less; kept at 1)
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((tiles_m / a.tpw) * tiles_n);
   if (epilogue == TC_PLAIN) return launch_thin_conv_e<TC_PLAIN>(a, grid, st);
@@ -952,16 +959,15 @@ INDM_API int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y
   WgradGemmArgs p = {(const u16*)X, (const u16*)gateX, (const u16*)Y, ws, mts, per, S};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(((S + 7) / 8) * 8 * 16);
-  constexpr int lds = 4 * 128 * WG2_RS * 2;
+  constexpr int lds2 = 4 * 128 * (32 * 2 + 8) * 2, lds1 = 4 * 128 * (32 + 8) * 2;
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute((const void*)f16_wgrad_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)f16_wgrad_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)f16_wgrad_gemm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess)
       return INDM_E_LAUNCH;
     ready = true;
   }
-  if (gateX) hipLaunchKernelGGL((f16_wgrad_gemm_kernel<true>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((f16_wgrad_gemm_kernel<false>), grid, dim3(256), lds, st, p);
+  if (gateX) hipLaunchKernelGGL((f16_wgrad_gemm_kernel<true, 1>), grid, dim3(256), lds1, st, p);
+  else hipLaunchKernelGGL((f16_wgrad_gemm_kernel<false, 2>), grid, dim3(256), lds2, st, p);
   INDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3(cdiv((long)R_N * R_N, 256)), dim3(256), 0, st, ws, out, S, R_N, R_N, alpha,
                      transpose, (long)R_N);
