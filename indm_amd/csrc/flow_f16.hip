@@ -33,6 +33,7 @@
 //
 // Reference: flows/resflow/layers/iresblock.py:60-174,253-273 (what is computed); DESIGN.md section 3.1.2 (why).
 #include "indm_common.h"
+#include <stdlib.h>
 #pragma clang diagnostic ignored "-Winline-asm"   // M0 clobber declared on the copy helpers (see igemm.hip)
 
 #pragma GCC visibility push(default)
@@ -140,25 +141,14 @@ struct RowsArgs {
   int M, J, rpg;
 };
 
-// TMV = 64 rows per workgroup, or 32 when M is too small to give every CU its two 64-row workgroups (per-rank shards)
-template <int MODE, int JB, bool T2OUT, int TMV>
-__global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
+// One tile of the 64-row kernel family: everything after the A tile has landed in `smem` (the caller has synchronised).
+// D = k-steps of weight fragments in flight (L2 latency / MFMA time of a k-step round).  Barriers executed: GEMM modes 0,
+// CHAIN / THIN_N 2 JB (the persistent kernel's loader wave has to match them).
+template <int MODE, int JB, bool T2OUT, int TMV, int D>
+__device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const long tile, const int tid, const int lane,
+                                          const int wave, const int l31, const int lhi) {
   constexpr int MB = TMV / 32;   // 32-row blocks per workgroup
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lhi = lane >> 5;
-  const long tile = blockIdx.x;
   const long m0 = tile * TMV;
-
-  // ---- the A tile: TMV rows x 512 columns of F16 memory = 32 MB consecutive 1 KB chunks; chunk c = 32 j + ks is fragment
-  // (m-block j, k-step ks).  4 MB chunks per wave.
-  {
-    const char* src = (const char*)p.A + tile * (long)(TMV * R_N * 2) + (long)wave * (MB * 4096);
-    const unsigned voff = 16u * lane;
-#pragma unroll
-    for (int g = 0; g < MB; ++g) dma_x4(lds_addr(smem + wave * (MB * 4096) + g * 4096), voff, src + g * 4096);
-  }
   f32x16 acc[2][MB];
   bf16x8 hm2[2][MB][2];   // stage-2 operand fragments [i][j][s] (CHAIN: gated accumulators; THIN_N: A fragments)
   if constexpr (MODE != R_THINN) {
@@ -170,14 +160,11 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // weights of this wave's two 32-column blocks, k-step ks: Bp[(ks * 16 + 2 wave + i) * 64 + lane] (16 bytes)
     const u32x4* bp = (const u32x4*)p.Bp + (long)(2 * wave) * 64 + lane;
-    constexpr int D = 4;   // k-steps of weight fragments in flight (L2 latency / MFMA time of a k-step round)
     u32x4 q[D][2];
 #pragma unroll
     for (int d = 0; d < D; ++d)
 #pragma unroll
       for (int i = 0; i < 2; ++i) q[d][i] = bp[(long)d * 1024 + i * 64];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's copies have landed ...
-    __syncthreads();                                    // ... and everybody else's
 #pragma unroll 1
     for (int k0 = 0; k0 < 32; k0 += D) {
 #pragma unroll
@@ -201,8 +188,6 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
       }
     }
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -320,6 +305,66 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
   }
 }
 
+// TMV = 64 rows per workgroup, or 32 when M is too small to give every CU its two 64-row workgroups (per-rank shards)
+template <int MODE, int JB, bool T2OUT, int TMV>
+__global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
+  constexpr int MB = TMV / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const long tile = blockIdx.x;
+  // ---- the A tile: TMV rows x 512 columns of F16 memory = 32 MB consecutive 1 KB chunks; chunk c = 32 j + ks is fragment
+  // (m-block j, k-step ks).  4 MB chunks per wave.
+  {
+    const char* src = (const char*)p.A + tile * (long)(TMV * R_N * 2) + (long)wave * (MB * 4096);
+    const unsigned voff = 16u * lane;
+#pragma unroll
+    for (int g = 0; g < MB; ++g) dma_x4(lds_addr(smem + wave * (MB * 4096) + g * 4096), voff, src + g * 4096);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's copies have landed ...
+  __syncthreads();                                    // ... and everybody else's
+  rows_tile<MODE, JB, T2OUT, TMV, 4>(p, smem, tile, tid, lane, wave, l31, lhi);
+}
+
+// Persistent form for long M (>= 512 tiles): ONE workgroup per CU walks the 64-row tiles with TWO 64 KB tile buffers; a ninth
+// wave does nothing but copy the NEXT tile into the other buffer (its own vmcnt: the compute waves' weight-fragment loads
+// are not held back by a 64 KB copy in flight) while the eight compute waves work on the current one.  The two-workgroups-
+// per-CU form above loads, multiplies and stores in phase on both workgroups: 2.5 - 3.2 TB/s of tile traffic; here the HBM
+// stream never stops.
+template <int MODE, int JB, bool T2OUT, int D>
+__global__ __launch_bounds__((R_NW + 1) * 64, 2) void f16_rows_persist_kernel(RowsArgs p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][64 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  constexpr int NB = (MODE == R_CHAIN || MODE == R_THINN) ? 2 * JB : 0;   // barriers inside rows_tile
+  auto copy_tile = [&](long t, char* dst) {   // the loader wave copies all 64 chunks
+    const char* src = (const char*)p.A + t * (long)R_LDS_BYTES;
+    const unsigned voff = 16u * lane;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dma_x4(lds_addr(dst + g * 4096), voff, src + g * 4096);
+  };
+  long t = blockIdx.x;
+  if (wave == R_NW) {
+    copy_tile(t, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    char* cur = smem + (it & 1) * R_LDS_BYTES;
+    if (wave == R_NW) {
+      if (t + gridDim.x < ntiles) copy_tile(t + gridDim.x, smem + ((it & 1) ^ 1) * R_LDS_BYTES);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) __builtin_amdgcn_s_barrier();   // the compute waves' barriers: do not hold them up
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... the copy has landed before the hand-over below
+    } else {
+      rows_tile<MODE, JB, T2OUT, 64, D>(p, cur, t, tid, lane, wave, l31, lhi);
+    }
+    __syncthreads();   // the next tile has landed, every compute wave is done with this one (and its overlay)
+  }
+}
+
 template <int MODE, int JB, bool T2OUT, int TMV>
 int launch_rows_tm(const RowsArgs& a, hipStream_t st) {
   constexpr int bytes = TMV * R_N * 2;
@@ -333,11 +378,32 @@ int launch_rows_tm(const RowsArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((f16_rows_kernel<MODE, JB, T2OUT, TMV>), dim3(a.M / TMV), dim3(R_NW * 64), bytes, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
+template <int MODE, int JB, bool T2OUT, int D>
+int launch_rows_persist(const RowsArgs& a, hipStream_t st) {
+  constexpr int bytes = 2 * R_LDS_BYTES;
+  static bool ready = false;
+  if (!ready) {
+    if (hipFuncSetAttribute((const void*)f16_rows_persist_kernel<MODE, JB, T2OUT, D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            bytes) != hipSuccess)
+      return INDM_E_LAUNCH;
+    ready = true;
+  }
+  const int ntiles = a.M / R_TM;
+  hipLaunchKernelGGL((f16_rows_persist_kernel<MODE, JB, T2OUT, D>), dim3(ntiles < 256 ? ntiles : 256), dim3((R_NW + 1) * 64), bytes,
+                     st, a, ntiles);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
 template <int MODE, int JB, bool T2OUT>
 int launch_rows(const RowsArgs& a, hipStream_t st) {
+  static const int persist = getenv("INDM_F16_PERSIST") ? atoi(getenv("INDM_F16_PERSIST")) : 1;   // probes: 0 = two workgroups per CU
+  if (MODE != R_THINN && a.M / R_TM >= 1024) {
+    if (persist == 1) return launch_rows_persist<MODE, JB, T2OUT, 8>(a, st);
+    if (persist == 2) return launch_rows_persist<MODE, JB, T2OUT, 4>(a, st);
+  }
   // fewer than two 64-row workgroups per CU (M < 32768): 32-row workgroups, twice as many.  The thin-N mode has no main
   // loop to amortise a tile's load latency over: always 32-row tiles (32 KB of LDS: four workgroups per CU overlap).
-  if (a.M / R_TM < 512 || MODE == R_THINN) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
+  static const int force = getenv("INDM_F16_TM") ? atoi(getenv("INDM_F16_TM")) : 0;   // probes: 32 | 64
+  if (force == 32 || (force != 64 && (a.M / R_TM < 512 || MODE == R_THINN))) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
   return launch_rows_tm<MODE, JB, T2OUT, 64>(a, st);
 }
 
@@ -358,7 +424,6 @@ struct ThinConvArgs {
   u16* O1;            // PLAIN: out; ACT: a; GATE: out .* G
   u16* O2;            // ACT: cos; GATE: raw out (optional)
   int N, H, W, C, Cout, sign;
-  int tpw;            // consecutive pixel tiles per workgroup
 };
 
 // SMAX: upper bound of the k-steps (loop unrolling); VEC4: C % 4 == 0, four consecutive k share a tap (float4 loads).
@@ -373,11 +438,11 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
   const int l31 = lane & 31, lhi = lane >> 5;
   const int C = p.C, K = 9 * C, S = (K + 15) >> 4;
   const int tiles_n = p.Cout / TC_TN;
-  const int tn = blockIdx.x % tiles_n, tm0 = (blockIdx.x / tiles_n) * p.tpw;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
   const int n0 = tn * TC_TN;
   const int HW = p.H * p.W;
+  const long mt = (long)tm * 4 + wave;
   const int nbn = p.Cout >> 5;
-  long mt = (long)tm0 * 4 + wave;
   auto chunk = [&](int jn, int s) -> long { return (((mt * nbn + (n0 >> 5) + jn) * 2 + s) * 64 + lane) * 8; };
 
   u32x4 gq[4][2];
@@ -400,27 +465,12 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
   }
   if (tid < TC_TN) bsh[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
 
-  __syncthreads();   // wf, bsh complete
-  // ---- p.tpw consecutive pixel tiles per workgroup (the packed weights are built once)
-#pragma unroll 1
-  for (int it = 0; it < p.tpw; ++it, mt += 4) {
-  const int tm = tm0 + it;
-  int Cq = C;                          // opaque per iteration: keeps the tap decode of the gather INSIDE the loop (hoisted, it
-  asm volatile("" : "+s"(Cq));         // costs ~100 live registers and spills)
-  if (it > 0) {
-    if constexpr (EPI == TC_GATE) {
-#pragma unroll
-      for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) gq[jn][s] = *(const u32x4*)(p.G + chunk(jn, s));
-    }
-  }
   // ---- this lane's pixel and its im2col fragments (B role: lane l31 = pixel, k = 16 s + 8 lhi + e), gathered k-step by
   // k-step straight into the MFMA operand registers
   const long pix = (long)tm * TC_TM + wave * 32 + l31;
   const int img = (int)(pix / HW), r = (int)(pix - (long)img * HW);
   const int h = r / p.W, w = r - h * p.W;
-  const float* base = p.X + pix * Cq;
+  const float* base = p.X + pix * C;
   bf16x8 hx[SMAX];
 #pragma unroll
   for (int s = 0; s < SMAX; ++s) {
@@ -432,11 +482,11 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int k = 16 * s + 8 * lhi + 4 * q;
-          const int tap = k / Cq, c = k - tap * Cq;
+          const int tap = k / C, c = k - tap * C;
           const int kh = tap / 3, kw = tap - 3 * kh;
           const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
           if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
-            const float4 v = *(const float4*)(base + ((hh - h) * p.W + (ww - w)) * Cq + c);
+            const float4 v = *(const float4*)(base + ((hh - h) * p.W + (ww - w)) * C + c);
             gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
           }
         }
@@ -444,15 +494,16 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int k = 16 * s + 8 * lhi + e;
-          const int tap = k / Cq, c = k - tap * Cq;
+          const int tap = k / C, c = k - tap * C;
           const int kh = tap / 3, kw = tap - 3 * kh;
           const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
-          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) gv[e] = base[((hh - h) * p.W + (ww - w)) * Cq + c];
+          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) gv[e] = base[((hh - h) * p.W + (ww - w)) * C + c];
         }
       }
     }
     hx[s] = __builtin_bit_cast(bf16x8, pack8(gv));
   }
+  __syncthreads();   // wf, bsh complete
   f32x16 acc[4];
 #pragma unroll
   for (int jn = 0; jn < 4; ++jn)
@@ -493,7 +544,6 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
       }
       *(u32x4*)(p.O1 + ci) = pack8(v);
     }
-  }
 }
 
 template <int EPI, int SMAX, bool VEC4>
@@ -855,12 +905,12 @@ INDM_API int indm_f16_thin_conv(const float* x, const float* w, const float* bia
   if (!al16(x)) return 1;
   if (!x || !w || !out1 || (epilogue == TC_ACT && !out2) || (epilogue == TC_GATE && !gate)) return INDM_E_ARG;
   if (!al16(bias) || !al16(out1) || !al16(out2) || !al16(gate)) return INDM_E_ARG;
-  ThinConvArgs a = {x, w, bias, (const u16*)gate, (u16*)out1, (u16*)out2, Nimg, H, W, C, Cout, sign, 1};
+  ThinConvArgs a = {x, w, bias, (const u16*)gate, (u16*)out1, (u16*)out2, Nimg, H, W, C, Cout, sign};
   const int tiles_n = Cout / TC_TN, tiles_m = (int)(M / TC_TM);
-  // (a.tpw > 1 = several pixel tiles per weight pack: measured SLOWER at every production shape -- 64 -> 74 us gated,
-  // 90 -> 106 us gated + raw at M = 131072 -- fewer, longer workgroups overlap each other's phases less; kept at 1)
+  // (several pixel tiles per workgroup and weight pack were measured SLOWER at every production shape -- 64 -> 74 us gated,
+  // 90 -> 106 us gated + raw at M = 131072: fewer, longer workgroups overlap each other's phases less)
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((tiles_m / a.tpw) * tiles_n);
+  dim3 grid(tiles_m * tiles_n);
   if (epilogue == TC_PLAIN) return launch_thin_conv_e<TC_PLAIN>(a, grid, st);
   if (epilogue == TC_ACT) return launch_thin_conv_e<TC_ACT>(a, grid, st);
   if (epilogue == TC_GATE) return launch_thin_conv_e<TC_GATE>(a, grid, st);
