@@ -143,7 +143,7 @@ struct RowsArgs {
 
 // One tile of the 64-row kernel family: everything after the A tile has landed in `smem` (the caller has synchronised).
 // D = k-steps of weight fragments in flight (L2 latency / MFMA time of a k-step round).  Barriers executed: GEMM modes 0,
-// CHAIN / THIN_N 2 JB (the persistent kernel's loader wave has to match them).
+// CHAIN / THIN_N 2 JB.
 template <int MODE, int JB, bool T2OUT, int TMV, int D>
 __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const long tile, const int tid, const int lane,
                                           const int wave, const int l31, const int lhi) {
@@ -327,44 +327,6 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
   rows_tile<MODE, JB, T2OUT, TMV, 4>(p, smem, tile, tid, lane, wave, l31, lhi);
 }
 
-// Persistent form for long M (>= 512 tiles): ONE workgroup per CU walks the 64-row tiles with TWO 64 KB tile buffers; a ninth
-// wave does nothing but copy the NEXT tile into the other buffer (its own vmcnt: the compute waves' weight-fragment loads
-// are not held back by a 64 KB copy in flight) while the eight compute waves work on the current one.  The two-workgroups-
-// per-CU form above loads, multiplies and stores in phase on both workgroups: 2.5 - 3.2 TB/s of tile traffic; here the HBM
-// stream never stops.
-template <int MODE, int JB, bool T2OUT, int D>
-__global__ __launch_bounds__((R_NW + 1) * 64, 2) void f16_rows_persist_kernel(RowsArgs p, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][64 KB]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lhi = lane >> 5;
-  constexpr int NB = (MODE == R_CHAIN || MODE == R_THINN) ? 2 * JB : 0;   // barriers inside rows_tile
-  auto copy_tile = [&](long t, char* dst) {   // the loader wave copies all 64 chunks
-    const char* src = (const char*)p.A + t * (long)R_LDS_BYTES;
-    const unsigned voff = 16u * lane;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) dma_x4(lds_addr(dst + g * 4096), voff, src + g * 4096);
-  };
-  long t = blockIdx.x;
-  if (wave == R_NW) {
-    copy_tile(t, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
-    char* cur = smem + (it & 1) * R_LDS_BYTES;
-    if (wave == R_NW) {
-      if (t + gridDim.x < ntiles) copy_tile(t + gridDim.x, smem + ((it & 1) ^ 1) * R_LDS_BYTES);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) __builtin_amdgcn_s_barrier();   // the compute waves' barriers: do not hold them up
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // ... the copy has landed before the hand-over below
-    } else {
-      rows_tile<MODE, JB, T2OUT, 64, D>(p, cur, t, tid, lane, wave, l31, lhi);
-    }
-    __syncthreads();   // the next tile has landed, every compute wave is done with this one (and its overlay)
-  }
-}
-
 template <int MODE, int JB, bool T2OUT, int TMV>
 int launch_rows_tm(const RowsArgs& a, hipStream_t st) {
   constexpr int bytes = TMV * R_N * 2;
@@ -378,39 +340,23 @@ int launch_rows_tm(const RowsArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((f16_rows_kernel<MODE, JB, T2OUT, TMV>), dim3(a.M / TMV), dim3(R_NW * 64), bytes, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
-template <int MODE, int JB, bool T2OUT, int D>
-int launch_rows_persist(const RowsArgs& a, hipStream_t st) {
-  constexpr int bytes = 2 * R_LDS_BYTES;
-  static bool ready = false;
-  if (!ready) {
-    if (hipFuncSetAttribute((const void*)f16_rows_persist_kernel<MODE, JB, T2OUT, D>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            bytes) != hipSuccess)
-      return INDM_E_LAUNCH;
-    ready = true;
-  }
-  const int ntiles = a.M / R_TM;
-  hipLaunchKernelGGL((f16_rows_persist_kernel<MODE, JB, T2OUT, D>), dim3(ntiles < 256 ? ntiles : 256), dim3((R_NW + 1) * 64), bytes,
-                     st, a, ntiles);
-  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
-}
 template <int MODE, int JB, bool T2OUT>
 int launch_rows(const RowsArgs& a, hipStream_t st) {
-  static const int persist = getenv("INDM_F16_PERSIST") ? atoi(getenv("INDM_F16_PERSIST")) : 1;   // probes: 0 = two workgroups per CU
-  if (MODE != R_THINN && a.M / R_TM >= 1024) {
-    if (persist == 1) return launch_rows_persist<MODE, JB, T2OUT, 8>(a, st);
-    if (persist == 2) return launch_rows_persist<MODE, JB, T2OUT, 4>(a, st);
-  }
   // fewer than two 64-row workgroups per CU (M < 32768): 32-row workgroups, twice as many.  The thin-N mode has no main
   // loop to amortise a tile's load latency over: always 32-row tiles (32 KB of LDS: four workgroups per CU overlap).
-  static const int force = getenv("INDM_F16_TM") ? atoi(getenv("INDM_F16_TM")) : 0;   // probes: 32 | 64
-  if (force == 32 || (force != 64 && (a.M / R_TM < 512 || MODE == R_THINN))) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
+  // Measured and dropped (round 4, M = 131072): 32-row tiles for the other modes (chain 104 -> 131 us: twice the weight
+  // traffic out of L2), and a persistent form -- one workgroup per CU, two 64 KB tile buffers, a ninth wave that only
+  // copies the next tile -- 112 us with four k-steps of weight fragments in flight, 140 us with eight (spills at the
+  // 168-register cap of a nine-wave workgroup): with two waves per SIMD the weight-fragment latency is exposed; the
+  // two-workgroups-per-CU form hides it behind four waves per SIMD.
+  if (a.M / R_TM < 512 || MODE == R_THINN) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
   return launch_rows_tm<MODE, JB, T2OUT, 64>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // f16_thin_conv_kernel: out[pixel, co] = sum_{tap, c} x[pixel shifted by tap, c] * w[(tap, c), co], co < 512, C <= 12.
-// 128 pixels x 128 columns per tile, 4 waves (wave w: pixels 32 w .. 32 w + 31, four 32-column blocks), persistent over
-// the pixel tiles of one column tile (its weights are packed into LDS once).  K = 9 C is padded to S = ceil(K / 16)
+// 128 pixels x 128 columns per workgroup, 4 waves (wave w: pixels 32 w .. 32 w + 31, four 32-column blocks); the column
+// tile's weights are packed into LDS by the workgroup.  K = 9 C is padded to S = ceil(K / 16)
 // k-steps; the operand fragments use consecutive k per lane (k = 16 s + 8 lhi + e) on both sides.  A lane GATHERS the
 // fragment it multiplies (lane l31 = its pixel, its 8 k per step): the im2col values never pass through LDS.
 enum { TC_PLAIN = 0, TC_ACT = 1, TC_GATE = 2 };
