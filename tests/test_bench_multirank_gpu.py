@@ -79,3 +79,29 @@ def test_world_size_must_match_gpus():
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode != 0
     assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.timeout(900)
+def test_single_gpu_line_carries_the_bf16_and_shard_legs():
+    """the default N = 1 line: the whole-step roofline at the realised series length, the bf16 (F16 storage) sub-leg with its own
+    roofline, and the training step at the per-rank shards of an 8-GPU job (16 / 32 / 64 images, fp32 and bf16)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "INDM_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--batch", "16", "--no-cpu-baseline",
+           "--no-sampling"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["distinct_devices"] == 1 and line["backend"] is None
+    assert "extra_legs_error" not in line, line.get("extra_legs_error")
+    assert line["roofline"]["step"]["n_bar"] == line["config"]["n_bar"]
+    b = line["bf16"]
+    assert b["value"] > 0 and b["roofline"]["kernel"].endswith(",bf16>") and 0 < b["roofline"]["step"]["frac"] < 1
+    sh = line["train_per_rank_shard_of_8"]
+    for key in ("batch16_f32", "batch16_bf16", "batch32_f32", "batch32_bf16", "batch64_f32", "batch64_bf16"):
+        assert sh[key]["ms_per_step"] > 0 and sh[key]["images_per_s"] > 0
+    # bf16 storage must not be slower than fp32 at any shard
+    assert sh["batch64_bf16"]["ms_per_step"] < sh["batch64_f32"]["ms_per_step"]
