@@ -99,7 +99,7 @@ def test_single_gpu_line_carries_the_bf16_and_shard_legs():
     assert "extra_legs_error" not in line, line.get("extra_legs_error")
     assert line["roofline"]["step"]["n_bar"] == line["config"]["n_bar"]
     b = line["bf16"]
-    assert b["value"] > 0 and b["roofline"]["kernel"].endswith(",bf16>") and 0 < b["roofline"]["step"]["frac"] < 1
+    assert b["value"] > 0 and "bf16" in b["roofline"]["kernel"] and 0 < b["roofline"]["step"]["frac"] < 1
     sh = line["train_per_rank_shard_of_8"]
     for key in ("batch16_f32", "batch16_bf16", "batch32_f32", "batch32_bf16", "batch64_f32", "batch64_bf16"):
         assert sh[key]["ms_per_step"] > 0 and sh[key]["images_per_s"] > 0
