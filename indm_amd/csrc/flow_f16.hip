@@ -139,7 +139,6 @@ struct RowsArgs {
   const float* bias;   // [512] (GEMM_ACT / GEMM, optional)
   const float* bias2;  // [M / rpg][512] (optional)
   int M, J, rpg;
-  int stagger;       // ticks of the 100 MHz clock that every second wave of workgroups (blockIdx / 256 odd) waits before its first tile
 };
 
 // One tile of the 64-row kernel family: everything after the A tile has landed in `smem` (the caller has synchronised).
@@ -315,13 +314,6 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const long tile = blockIdx.x;
-  if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-    // workgroups b and b + 256 share a CU (tools/probe/wg_placement.hip): start the second one half a tile period later, so
-    // that one of the two streams its tile / gate / results through HBM while the other multiplies -- without this every
-    // workgroup of the chip loads, multiplies and stores in phase and HBM idles during the main loops
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < p.stagger) {}
-  }
   // ---- the A tile: TMV rows x 512 columns of F16 memory = 32 MB consecutive 1 KB chunks; chunk c = 32 j + ks is fragment
   // (m-block j, k-step ks).  4 MB chunks per wave.
   {
@@ -356,7 +348,10 @@ int launch_rows(const RowsArgs& a, hipStream_t st) {
   // traffic out of L2), and a persistent form -- one workgroup per CU, two 64 KB tile buffers, a ninth wave that only
   // copies the next tile -- 112 us with four k-steps of weight fragments in flight, 140 us with eight (spills at the
   // 168-register cap of a nine-wave workgroup): with two waves per SIMD the weight-fragment latency is exposed; the
-  // two-workgroups-per-CU form hides it behind four waves per SIMD.
+  // two-workgroups-per-CU form hides it behind four waves per SIMD.  Starting the second workgroup of every CU 6 - 18 us late
+  // (so that one streams while the other multiplies) only added the delay: 101 -> 105 / 114 / 126 us.  What the numbers
+  // point at: every workgroup pulls the whole 512 KB of packed weights out of L2 per tile -- 1 GB per launch at 64-row tiles
+  // (10 TB/s of L2 -> CU traffic next to 2.6 TB/s of HBM traffic), 2 GB at 32-row tiles (15.6 TB/s, and slower).
   if (a.M / R_TM < 512 || MODE == R_THINN) return launch_rows_tm<MODE, JB, T2OUT, 32>(a, st);
   return launch_rows_tm<MODE, JB, T2OUT, 64>(a, st);
 }
@@ -878,9 +873,8 @@ INDM_API int indm_f16_rows(int mode, const void* A, const void* Bp, const void* 
   if (M % R_TM) return 1;
   if (!A || !al16(A) || !al16(Bp) || !al16(D1) || !al16(Pp) || !al16(out1) || !al16(out2) || !al16(bias) || !al16(bias2))
     return INDM_E_ARG;
-  static const int stagger_us = getenv("INDM_F16_STAGGER_US") ? atoi(getenv("INDM_F16_STAGGER_US")) : 0;
   RowsArgs a = {(const u16*)A, (const u16*)Bp, (const u16*)D1, (const u16*)Pp, P, (u16*)out1, (u16*)out2, bias, bias2,
-                M, J, rows_per_group > 0 ? rows_per_group : 1, (mode != R_THINN && M / R_TM >= 512) ? stagger_us * 100 : 0};
+                M, J, rows_per_group > 0 ? rows_per_group : 1};
   hipStream_t st = (hipStream_t)stream;
   switch (mode) {
     case R_GEMM:
