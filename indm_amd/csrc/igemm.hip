@@ -1640,13 +1640,23 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
 
 inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
+// Tuning hook of tools/splitk_sweep.py: with INDM_SPLITK_TUNE set, every split-K decision below takes its slice count from
+// INDM_SPLITK (read per call; 0 / unset = the rule's own choice).  The clamps to the K length and the workspace still apply.
+static long tuned(long want) {
+  static const bool on = getenv("INDM_SPLITK_TUNE") != nullptr;
+  if (!on) return want;
+  const char* v = getenv("INDM_SPLITK");
+  const long f = v ? atol(v) : 0;
+  return f > 0 ? f : want;
+}
+
 // Pick split-K so that tiles*splits fills the chip (>= ~2 waves of 256 CUs) when the
 // output is small and the reduction long (weight grads: K = B*H*W pixels).
 int choose_splitk(int M, int N, int K, int batch, long ws_floats) {
   long tiles = (long)cdiv(M, (N <= 32 && M > 32) ? 128 : (M <= 128 ? 32 : 128)) *
                cdiv(N, (N <= 32 && M > 32) ? 32 : 128) * batch;
   if (tiles >= 256 || K < 4 * BK * 8) return 1;
-  long want = (1024 + tiles - 1) / tiles;  // 512...1536 measured within noise of each other
+  long want = tuned((1024 + tiles - 1) / tiles);  // 512...1536 measured within noise of each other
   long maxs = K / (BK * 8);
   if (want > maxs) want = maxs;
   if (want > 256) want = 256;
@@ -1676,7 +1686,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     // bf16 mode: the weight-grad GEMMs are HBM streamers -- direct-to-LDS staging of the row-contiguous A (and its
     // gate) keeps 16 waves per CU in flight without a register-staged prefetch (the gated big tile spills there)
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
-    long want = 512 / tiles;
+    long want = tuned(512 / tiles);
     while (want > 1 && (p.K / want < 16 * BK || want * p.M * p.N > ws_floats)) --want;
     if (want > 1) {
       p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
@@ -1692,7 +1702,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, tnw) * p.batch;
     if (p.M >= 256 && p.N >= 256 && !(p.M & 3) && !(p.N & 3) && !(p.K & 15) && p.a_vec && p.b_vec &&
         tiles <= (tnw == 128 ? 128 : 64) && p.K >= 8192 && !(tnw == 128 && !p.bf16 && p.G)) {
-      long want = (tnw == 128 ? 512 : 256) / tiles;
+      long want = tuned((tnw == 128 ? 512 : 256) / tiles);
       while (want > 1 && (p.K / want < 512 || want * p.batch * p.M * p.N > ws_floats)) --want;
       // fewer than 128 blocks (e.g. the 256 x 256 NIN weight grads at K = 32768: 64 blocks, 31 TF) leave most of the
       // chip idle: those go to the 128 x 128 split-K path below
@@ -1723,7 +1733,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     // the direct-to-LDS kernel's row-contiguous A image with split-K instead of the generic 128 x 128 tile (round 3;
     // 72.9 -> 63.4 us; shorter K or 128-row outputs measured slower and stay on the generic tile)
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
-    long want = 512 / tiles;
+    long want = tuned(512 / tiles);
     if (want < 1) want = 1;
     while (want > 1 && (p.K / want < 8 * BK || want * p.M * p.N > ws_floats)) --want;
     p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
@@ -1736,7 +1746,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     // convolution weight grads on the direct-to-LDS kernel (round 3, A_WGRAD image): 256 x 128 tiles, split-K over the
     // output pixels so that every CU gets its two workgroups, chunks of at least 8 slabs
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
-    long want = 512 / tiles;
+    long want = tuned(512 / tiles);
     if (want < 1) want = 1;
     while (want > 1 && (p.K / want < 8 * BK || want * p.M * p.N > ws_floats)) --want;
     p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
@@ -1748,7 +1758,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     // convolution weight grads: same recipe on the implicit-GEMM A operand (256 x 256|128 tiles)
     const int tn = (p.N % 256 == 0 && !p.bf16) ? 256 : 128;
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, tn);
-    long want = (tn == 256 ? 256 : 512) / tiles;
+    long want = tuned((tn == 256 ? 256 : 512) / tiles);
     while (want > 1 && (p.K / want < 512 || want * p.M * p.N > ws_floats)) --want;
     if (tiles <= 128 && want > 1) {
       int kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
@@ -1772,7 +1782,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     // direct-to-LDS kernel, chunks of at least 8 slabs
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch;
     if (tiles < 224 && tiles >= 16) {
-      long want = 448 / tiles;
+      long want = tuned(448 / tiles);
       while (want > 1 && (p.K / want < 8 * BK || want * p.batch * p.M * p.N > ws_floats)) --want;
       if (want > 1) {
         p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
@@ -1788,7 +1798,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
     const long tiles = (long)cdiv(p.M, 256) * cdiv(p.N, 128);
     // (N <= 128 with a long M goes to the 64 x 128 tiles of launch_tiles instead: 66 vs 76 us on [32768,512]x[512,108])
     if (tiles < 224 && tiles >= 16 && !(p.N <= 128 && p.M >= 8192)) {
-      long want = 448 / tiles;
+      long want = tuned(448 / tiles);
       while (want > 1 && (p.K / want < 8 * BK || want * p.M * p.N > ws_floats)) --want;
       if (want > 1) {
         p.kps = cdiv(cdiv(p.K, (int)want), BK) * BK;
