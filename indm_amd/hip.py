@@ -778,15 +778,21 @@ def pack_w2t_bf16(w2ts):
     for k in [k for k, v in _w2t_packed.items() if v[0]() is None]:   # drop the copies of weights that no longer exist
         del _w2t_packed[k]
     for i, w in enumerate(w2ts):
-        _w2t_packed[id(w)] = (weakref.ref(w), w._version, pk[i])
+        # never register a Parameter: the fused optimiser rewrites parameter memory through the flat buffer, which no
+        # version counter sees (the same rule as _packed_weight; the flow's normalised weights are fresh tensors per call)
+        if not isinstance(w, torch.nn.Parameter):
+            _w2t_packed[id(w)] = (weakref.ref(w), w._version, pk[i])
+    return pk
 
 
 def packed_bf16(w):
     """the registered packed copy of w (pack_w2t_bf16), packing it now if the flow's prepare() did not"""
     hit = _w2t_packed.get(id(w))
     if hit is None or hit[0]() is not w or hit[1] != w._version:
-        pack_w2t_bf16([w])
-        hit = _w2t_packed[id(w)]
+        pk = pack_w2t_bf16([w])
+        if pk is None:
+            raise RuntimeError(f"packed_bf16: a [{w.shape[0]}, {w.shape[1]}] weight has no fragment-order form (K % 16 != 0)")
+        return pk[0]
     return hit[2]
 
 
