@@ -165,27 +165,29 @@ __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const l
     for (int d = 0; d < D; ++d)
 #pragma unroll
       for (int i = 0; i < 2; ++i) q[d][i] = bp[(long)d * 1024 + i * 64];
-#pragma unroll 1
-    for (int k0 = 0; k0 < 32; k0 += D) {
+    // The 32 k-steps are unrolled in full (ring slot ks % D, every condition a compile-time constant):
+    //  * the MFMAs read q[d] in place and the fetch of k-step ks + D is issued AFTER them into the same registers.  Round 4's
+    //    first form (a rolled loop that copied q[d] to a temporary and fetched before the MFMAs) made hipcc rotate the ring
+    //    with v_mov_b64 of just-loaded registers behind `s_waitcnt vmcnt(0)`: every k-step waited for the loads it had just
+    //    issued (PMC: MFMA pipe 36 - 44 % busy, half of the wave time in s_waitcnt);
+    //  * a scheduling barrier closes every k-step: without it hipcc's scheduler sinks the fetches down to their use D steps
+    //    later (the ISA then waits with vmcnt(0 / 1) again); with it the waits are vmcnt(2 D - 2 .. 2 D - 1).
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const int ks = k0 + d;
-        bf16x8 hm[MB];
+    for (int ks = 0; ks < 32; ++ks) {
+      const int d = ks % D;
+      bf16x8 hm[MB];
 #pragma unroll
-        for (int j = 0; j < MB; ++j) hm[j] = *(const bf16x8*)(smem + (j * 32 + ks) * 1024 + lane * 16);
-        bf16x8 hn[2];
+      for (int j = 0; j < MB; ++j) hm[j] = *(const bf16x8*)(smem + (j * 32 + ks) * 1024 + lane * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) hn[i] = __builtin_bit_cast(bf16x8, q[d][i]);
-        if (ks + D < 32) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) q[d][i] = bp[(long)(ks + D) * 1024 + i * 64];
-        }
+        for (int j = 0; j < MB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, q[d][i]), hm[j], acc[i][j], 0, 0, 0);  // D[n][m]
+      if (ks + D < 32) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < MB; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hn[i], hm[j], acc[i][j], 0, 0, 0);  // D[n][m]
+        for (int i = 0; i < 2; ++i) q[d][i] = bp[(long)(ks + D) * 1024 + i * 64];
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
 #pragma unroll
@@ -254,6 +256,7 @@ __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const l
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= g[e];
           hm2[i][j][s] = __builtin_bit_cast(bf16x8, pack8(v));
+          if (j == MB - 1 && s == 1) __builtin_amdgcn_sched_barrier(0);   // one column block's gate chunks in flight at a time (registers)
         }
     __syncthreads();   // every wave is done with the A tile: the reduction buffer overlays it
   }
