@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
   auto chunk = [&](int jn, int s) -> long { return (((mt * nbn + (n0 >> 5) + jn) * 2 + s) * 64 + lane) * 8; };
 
   u32x4 gq[4][2];
-  if constexpr (EPI == TC_GATE) {
+  constexpr bool GQ_LATE = SMAX <= 2;   // (the 12-channel form holds 14 float4 gathers: with 8 more chunks in flight it spills)
+  if constexpr (EPI == TC_GATE && !GQ_LATE) {
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn)
 #pragma unroll
@@ -411,7 +412,10 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = 16 * s + 8 * (ln >> 5) + e;
-      v[e] = k < K ? p.Wt[(long)k * p.Cout + n0 + nb * 32 + (ln & 31)] : 0.f;
+      // (unconditional load from a clamped row + select: a load under a condition costs a branch and, at the merge, an
+      // `s_waitcnt vmcnt(0)` -- hipcc serialised all of this kernel's gathers that way, one memory latency each)
+      const float t = p.Wt[(long)min(k, K - 1) * p.Cout + n0 + nb * 32 + (ln & 31)];
+      v[e] = k < K ? t : 0.f;
     }
     *(u32x4*)(wf + u * 8) = pack8(v);
   }
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
     float gv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gv[e] = 0.f;
-    if (s < S) {
+    {   // (no `if (s < S)`: k >= K already selects zeros, and without the branch all SMAX gathers are in flight together)
       if constexpr (VEC4) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -437,10 +441,9 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
           const int tap = k / C, c = k - tap * C;
           const int kh = tap / 3, kw = tap - 3 * kh;
           const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
-          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) {
-            const float4 v = *(const float4*)(base + ((hh - h) * p.W + (ww - w)) * C + c);
-            gv[4 * q] = v.x; gv[4 * q + 1] = v.y; gv[4 * q + 2] = v.z; gv[4 * q + 3] = v.w;
-          }
+          const bool ok = k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+          const float4 v = *(const float4*)(base + (ok ? ((hh - h) * p.W + (ww - w)) * C + c : 0));   // offset 0: this pixel itself
+          gv[4 * q] = ok ? v.x : 0.f; gv[4 * q + 1] = ok ? v.y : 0.f; gv[4 * q + 2] = ok ? v.z : 0.f; gv[4 * q + 3] = ok ? v.w : 0.f;
         }
       } else {
 #pragma unroll
@@ -449,11 +452,22 @@ __global__ __launch_bounds__(256, 3) void f16_thin_conv_kernel(ThinConvArgs p) {
           const int tap = k / C, c = k - tap * C;
           const int kh = tap / 3, kw = tap - 3 * kh;
           const int hh = h - p.sign * (kh - 1), ww = w - p.sign * (kw - 1);
-          if (k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) gv[e] = base[((hh - h) * p.W + (ww - w)) * C + c];
+          const bool ok = k < K && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+          const float t = base[ok ? ((hh - h) * p.W + (ww - w)) * C + c : 0];
+          gv[e] = ok ? t : 0.f;
         }
       }
     }
     hx[s] = __builtin_bit_cast(bf16x8, pack8(gv));
+  }
+  // the gate chunks (HBM) are requested AFTER the gathers (L2): vmcnt retires in order, so a wait for the gathers must not
+  // have the gate stream in front of it; the chunks then fly under the MFMAs and are waited for in the epilogue.  (Round 4's
+  // first form issued them first "so that both streams are in flight" -- and every gather wait included them.)
+  if constexpr (EPI == TC_GATE && GQ_LATE) {
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) gq[jn][s] = *(const u32x4*)(p.G + chunk(jn, s));
   }
   __syncthreads();   // wf, bsh complete
   f32x16 acc[4];
