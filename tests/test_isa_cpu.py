@@ -71,3 +71,43 @@ def test_fused_groupnorm_loads_its_arguments_before_its_first_barrier(tmp_path):
     assert not [n for n in names if "gn_fused_fwd_kernel" in n or "gn_fused_bwd_kernel" in n], names
     assert not [n for n in names if "gn_fused_fwd_serial_kernel" in n and "ELb1E" in n], names       # the pinned A/B arm
     assert [n for n in names if "gn_fused_fwd_serial_kernel" in n and "ELb0E" in n], "the reproducer lost its late loads"
+
+
+def test_load_pipeline_scanner_counts_serialised_loads(tmp_path):
+    import load_pipeline_scan
+    s = tmp_path / "serial.s"
+    s.write_text("\n_Zserial: ; @_Zserial\n" + "\tglobal_load_dword v1, v[2:3], off\n\ts_waitcnt vmcnt(0)\n" * 5
+                 + "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n.Lfunc_end0:\n"
+                 "\n_Zburst: ; @_Zburst\n" + "\tglobal_load_dword v1, v[2:3], off\n" * 5 + "\ts_waitcnt vmcnt(3)\n"
+                 "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n\tv_mov_b64_e32 v[4:5], v[6:7]\n"
+                 "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n.Lfunc_end1:\n")
+    r = load_pipeline_scan.scan(str(s))
+    assert r["_Zserial"] == {"serial_loads": 5, "max_burst": 1, "mfma_waits": [0], "ring_moves": 0}
+    assert r["_Zburst"] == {"serial_loads": 0, "max_burst": 5, "mfma_waits": [3], "ring_moves": 1}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_f16_kernels_keep_their_loads_in_flight(tmp_path):
+    """Round 4: the F16 thin convolution's gathers and the rows kernel's weight-fragment ring were pipelined
+    in the source and serialised in the ISA (a branch + `s_waitcnt vmcnt(0)` per conditional load; `v_mov_b64` rotation of
+    just-loaded registers behind vmcnt(0)).  The forms that ship keep 16 + 8 loads in flight / wait with vmcnt(6 - 7); a
+    compiler update or an innocent edit that brings the old ISA back must fail here, not show up as 20 % in a profile."""
+    import load_pipeline_scan
+    s = tmp_path / "flow_f16.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                    "-ffp-contract=off", "--cuda-device-only", "-S", os.path.join(CSRC, "flow_f16.hip"), "-o", str(s)],
+                   check=True, capture_output=True, timeout=900)
+    thin = load_pipeline_scan.scan(str(s), "f16_thin_conv_kernelILi2ELi2ELb0")     # gate epilogue, C <= 3
+    assert len(thin) == 1
+    t = next(iter(thin.values()))
+    assert t["serial_loads"] <= 2 and t["max_burst"] >= 16, t       # (24 serial loads, bursts of 9 before the rewrite)
+    assert t["mfma_waits"] and t["mfma_waits"][0] >= 8, t           # the first MFMAs do not wait for the gate chunks
+    rows = load_pipeline_scan.scan(str(s), "f16_rows_kernelILi0ELi1ELb0ELi64")     # GEMM mode, 64-row tiles
+    assert len(rows) == 1
+    r = next(iter(rows.values()))
+    assert r["ring_moves"] == 0, r                                  # (28 v_mov of ring registers before the rewrite)
+    steady = r["mfma_waits"][:-8]                                   # the last ring slots drain: vmcnt(5 .. 0)
+    assert len(steady) >= 40 and min(steady) >= 4, r                # (vmcnt(0 .. 2) before)
+    for name, k in load_pipeline_scan.scan(str(s), "f16_rows_kernel").items():
+        if "Li64E" in name and "ILi3E" not in name:                 # every 64-row mode with a main loop (the chain modes'
+            assert min(k["mfma_waits"][:40]) >= 4, (name, k)         # moves between the two MFMA stages are their epilogue)
