@@ -276,6 +276,58 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // a fragment is 8 k-values per lane (k = 8*(lane/32) + t), rounded to bf16 with v_cvt_pk_bf16_f32 after the LDS read,
 // and ONE v_mfma_f32_32x32x16_bf16 per 16-deep slab replaces eight fp32 MFMAs (16x the MFMA rate; the kernel is then
 // bound by its operand traffic, not by the matrix pipe).
+// General epilogue of one 32 x 32 accumulator block (residual R and / or per-image bias2 present, or a ragged tile): the 16 bias2
+// and the 16 residual values of the lane are requested TOGETHER, from clamped addresses, before the first of them is used.
+// Written as `if (m < M) { v += bias2[..]; v += beta * R[..]; store }` per element, every one of those loads became a branch
+// with `s_waitcnt vmcnt(0)` behind it (profiles/r04_isa_serial_load_census.txt): 32 memory latencies per block, one after the
+// other.  Same operations in the same order per element (R may alias C: a lane reads exactly the elements it then writes).
+template <class Acc>
+__device__ __forceinline__ void epilogue_block(const IgemmParams& p, const Acc& acc, float* C, long ldc, const float* R,
+                                               bool partial, int mbase, int n, int lhi) {
+  __builtin_amdgcn_sched_barrier(0);   // one block at a time: hipcc otherwise hoists every block's loads to the top and spills
+  const bool nok = n < p.N;
+  float v[16];
+  unsigned ok = 0;                     // bit r: element r of this lane is inside the matrix
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    v[r] = acc[r];
+    ok |= (nok && mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi < p.M) ? (1u << r) : 0u;
+  }
+  if (!partial) {
+    float bn = 0.f;
+    if (p.bias) bn = p.bias[nok ? n : 0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] += bn;
+    if (p.bias2) {   // 32-bit element offsets from the uniform base (scalar-base addressing: one register per address)
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        t[r] = p.bias2[((ok >> r) & 1) ? (unsigned)(m / p.rpg) * (unsigned)p.N + (unsigned)n : 0u];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += t[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] *= p.alpha;
+    if (R) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        t[r] = R[((ok >> r) & 1) ? (unsigned)m * (unsigned)p.ldr + (unsigned)n : 0u];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] += p.beta * t[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    if ((ok >> r) & 1) C[(long)m * ldc + n] = v[r];
+  }
+}
+
 template <int AM, int BMODE, int TM, int TN, int WAVES_M, int WAVES_N, bool BF16 = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3 : 4)) void igemm_kernel(IgemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -517,28 +569,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
   const long ldc = partial ? p.N : p.ldc;
   const float* R = p.R ? p.R + (long)bz * p.sR : nullptr;
 #pragma unroll
-  for (int i = 0; i < RM; ++i) {
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int j = 0; j < RN; ++j) {
-      const int n = n0 + nw + j * 32 + l31;
-      if (n >= p.N) continue;
-      float bn = 0.f;
-      if (!partial && p.bias) bn = p.bias[n];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r];
-        if (!partial) {
-          v += bn;
-          if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
-          v *= p.alpha;
-          if (R) v += p.beta * R[(long)m * p.ldr + n];
-        }
-        C[(long)m * ldc + n] = v;
-      }
-    }
-  }
+    for (int j = 0; j < RN; ++j)
+      epilogue_block(p, acc[i][j], C, ldc, R, partial, m0 + mw + i * 32, n0 + nw + j * 32 + l31, lhi);
 }
 
 template <int I, int N, class F>
@@ -962,24 +996,10 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
   float* C = p.C + (long)bz * p.sC;
   const float* R = p.R ? p.R + (long)bz * p.sR : nullptr;
 #pragma unroll
-  for (int i = 0; i < RM; ++i) {
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int j = 0; j < RN; ++j) {
-      const int n = n0 + nw + j * 32 + l31;
-      if (n >= p.N) continue;
-      const float bn = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bn;
-        if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
-        v *= p.alpha;
-        if (R) v += p.beta * R[(long)m * p.ldr + n];
-        C[(long)m * p.ldc + n] = v;
-      }
-    }
-  }
+    for (int j = 0; j < RN; ++j)
+      epilogue_block(p, acc[i][j], C, p.ldc, R, false, m0 + mw + i * 32, n0 + nw + j * 32 + l31, lhi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1437,27 +1457,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     return;
   }
 #pragma unroll
-  for (int i = 0; i < RM; ++i) {
+  for (int i = 0; i < RM; ++i)
 #pragma unroll
-    for (int j = 0; j < RN; ++j) {
-      const int n = n0 + nw + j * 32 + l31;
-      if (n >= p.N) continue;
-      const float bn = (!partial && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r];
-        if (!partial) {
-          v += bn;
-          if (p.bias2) v += p.bias2[(long)(m / p.rpg) * p.N + n];
-          v *= p.alpha;
-          if (R) v += p.beta * R[(long)m * p.ldr + n];
-        }
-        C[(long)m * ldc + n] = v;
-      }
-    }
-  }
+    for (int j = 0; j < RN; ++j)
+      epilogue_block(p, acc[i][j], C, ldc, R, partial, m0 + mw + i * 32, n0 + nw + j * 32 + l31, lhi);
 }
 
 __global__ void igemm_splitk_reduce(IgemmParams p);
@@ -1667,6 +1670,9 @@ int choose_splitk(int M, int N, int K, int batch, long ws_floats) {
 int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t st) {
   if (p.M <= 0 || p.N <= 0 || p.batch <= 0) return INDM_OK;
   if (p.K < 0) return INDM_E_SHAPE;
+  // the general epilogue addresses the residual and the per-image bias with 32-bit element offsets (epilogue_block)
+  if ((p.R && (long)p.M * p.ldr >= (1L << 32)) || (p.bias2 && ((long)p.M / (p.rpg > 0 ? p.rpg : 1) + 1) * p.N >= (1L << 32)))
+    return INDM_E_SHAPE;
   p.ws = ws;
   if ((am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
     // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip (bf16 mode: operands

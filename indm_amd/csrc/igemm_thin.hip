@@ -65,13 +65,18 @@ __global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
     const int kc = min(TK_KC, p.K - k0);
     if (k0) __syncthreads();  // previous chunk's fragments are consumed
     // ---- B chunk: [kc x 128] float4 row groups (zero beyond K / N)
+    // Two-phase staging: ALL loads of the chunk (B and A), from clamped addresses, then all LDS stores.  Written as
+    // `if (inside) v = load; store v` per group, every load was a branch with `s_waitcnt vmcnt(0)` behind it (8 memory
+    // latencies per chunk, one after the other); unconditional loads alone are not enough either -- hipcc keeps each
+    // load -> LDS-store pair together -- so the loads go into a register array first and a scheduling barrier ends the phase.
+    float4 vb[4], va[4];
+    bool okb[4], oka[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int g = tid + j * 256;
       const int k = g >> 5, c4 = (g & 31) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < kc && n0 + c4 < p.N) v = *(const float4*)(p.B + (long)(k0 + k) * p.ldb + n0 + c4);
-      *(float4*)(bs + k * TK_LDB + c4) = v;
+      okb[j] = k < kc && n0 + c4 < p.N;
+      vb[j] = *(const float4*)(p.B + (okb[j] ? (long)(k0 + k) * p.ldb + n0 + c4 : 0L));
     }
     // ---- A chunk
     if constexpr (FLAT) {
@@ -107,30 +112,39 @@ __global__ __launch_bounds__(256, 4) void igemm_thin_k_kernel(ThinGemmArgs p) {
       for (int j = 0; j < 4; ++j) {
         const int g = tid + j * 256;
         const int row = g >> 3, k4 = (g & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int pix = m0 + row, kk = k0 + k4;
-        if (pix < p.M && k4 < kc) {
-          const int tap = (int)(((float)kk + 0.5f) * rC);  // exact for kk < 128
-          const int c = kk - tap * C;
-          const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;  // tap / 3 for tap < 9
-          const int hw = H * W;
-          const int n = pix / hw, r = pix - n * hw;
-          const int h = r / W, w = r - h * W;
-          const int hh = h - p.csign * (kh - 1), ww = w - p.csign * (kw - 1);
-          if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = *(const float4*)(p.X + (((long)n * H + hh) * W + ww) * C + c);
-        }
-        as[(k4 + 0) * TK_LDA + row] = v.x;
-        as[(k4 + 1) * TK_LDA + row] = v.y;
-        as[(k4 + 2) * TK_LDA + row] = v.z;
-        as[(k4 + 3) * TK_LDA + row] = v.w;
+        const int tap = (int)(((float)kk + 0.5f) * rC);  // exact for kk < 128
+        const int c = kk - tap * C;
+        const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;  // tap / 3 for tap < 9
+        const int hw = H * W;
+        const int n = pix / hw, r = pix - n * hw;
+        const int h = r / W, w = r - h * W;
+        const int hh = h - p.csign * (kh - 1), ww = w - p.csign * (kw - 1);
+        oka[j] = pix < p.M && k4 < kc && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        va[j] = *(const float4*)(p.X + (oka[j] ? (((long)n * H + hh) * W + ww) * C + c : 0L));
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int g = tid + j * 256;
         const int row = g >> 3, k4 = (g & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + row < p.M && k4 < kc) v = *(const float4*)(p.A + (long)(m0 + row) * p.lda + k0 + k4);
+        oka[j] = m0 + row < p.M && k4 < kc;
+        va[j] = *(const float4*)(p.A + (oka[j] ? (long)(m0 + row) * p.lda + k0 + k4 : 0L));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // end of the load phase
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = tid + j * 256;
+      const int k = g >> 5, c4 = (g & 31) * 4;
+      *(float4*)(bs + k * TK_LDB + c4) = okb[j] ? vb[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if constexpr (!FLAT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int g = tid + j * 256;
+        const int row = g >> 3, k4 = (g & 7) * 4;
+        const float4 v = oka[j] ? va[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         as[(k4 + 0) * TK_LDA + row] = v.x;
         as[(k4 + 1) * TK_LDA + row] = v.y;
         as[(k4 + 2) * TK_LDA + row] = v.z;
@@ -347,20 +361,9 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
       }
     }
   };
-  auto scatter = [&]() {         // awaits the gather and writes the tile into LDS [k][row]
-    if constexpr (IM2COL) {
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),
-                     "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]),
-                     "+v"(rv[15])::"memory");
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if ((emeta[j] >> 25) & 1) as[emeta[j] & 0xffff] = rv[j];
-    }
-  };
-
-  // one epilogue pass: rows [8q, 8q+8) of the wave's 32 (accumulator registers 4q .. 4q+3) of tile `tme`
-  auto epilogue_pass = [&](const f32x16 (&src)[4], int q, int tme) {
+  // `tile_bias` != nullptr: bias[n] + bias2[image of the tile][n] already in registers (the im2col form prefetches it with the
+  // next tile's gather: a load here would sit between the tile's stores and make hipcc drain them with vmcnt(0))
+  auto epilogue_pass = [&](const f32x16 (&src)[4], int q, int tme, const float4* tile_bias) {
     const int mw = tme * TK_TM + wave * 32;
     const bool full = (tme + 1) * TK_TM <= p.M && n0 + TK_TN <= p.N;  // block-uniform
 #pragma unroll
@@ -369,7 +372,9 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
       for (int rr = 0; rr < 4; ++rr) stg[(rr + 4 * lhi) * TF_LDS + j * 32 + l31] = src[j][4 * q + rr];
     __builtin_amdgcn_wave_barrier();
     float4 bq = bn;  // bias[n] + bias2[image of these 8 rows][n]: one load per pass (rpg % 8 == 0, host-checked)
-    if (p.bias2 && nok && mw + 8 * q < p.M) {  // (rows of a ragged last tile past M have no image: M % 8 == 0 here)
+    if (tile_bias) {
+      bq = *tile_bias;
+    } else if (p.bias2 && nok && mw + 8 * q < p.M) {  // (rows of a ragged last tile past M have no image: M % 8 == 0 here)
       const int img = (mw + 8 * q) / p.rpg;
       const float4 b = *(const float4*)(p.bias2 + (long)img * p.N + n);
       bq.x += b.x; bq.y += b.y; bq.z += b.z; bq.w += b.w;
@@ -403,25 +408,8 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
     __builtin_amdgcn_wave_barrier();
   };
 
-  if constexpr (IM2COL) {
-    if (tm < tiles_m) {
-      gather(tm);
-      scatter();
-    }
-  }
-  for (; tm < tiles_m; tm += mstep) {
-    __syncthreads();  // this tile's A (written at the end of the previous iteration) is visible
-    const int tnext = tm + mstep;
-    const bool next_full = (tnext + 1) * TK_TM <= p.M;  // block-uniform
-    if constexpr (IM2COL) {
-      if (next_full) gather(tnext);
-    } else if (next_full) {
-      const float* src = p.A + (long)tnext * TK_TM * K;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ra[j] = *(const f32x4*)(src + goff[j]);   // plain loads: hipcc owns their wait (see `ra`)
-    }
-
-    f32x16 acc[4];
+  const int npairs_ = npairs;
+  auto mfma_tile = [&](f32x16 (&acc)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -430,8 +418,8 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
     float a0 = rb16<BF16>(af[lhi * TK_LDA]), b0[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) b0[j] = rb16<BF16>(bf[lhi * TK_LDB + j * 32]);
-    for (int kk = 0; kk < npairs; ++kk) {
-      const int k = 2 * min(kk + 1, npairs - 1) + lhi;
+    for (int kk = 0; kk < npairs_; ++kk) {
+      const int k = 2 * min(kk + 1, npairs_ - 1) + lhi;
       const float a1 = rb16<BF16>(af[k * TK_LDA]);
       float b1[4];
 #pragma unroll
@@ -442,18 +430,83 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
 #pragma unroll
       for (int j = 0; j < 4; ++j) b0[j] = b1[j];
     }
+  };
 
-    __syncthreads();  // every wave is done with this tile's A fragments
-    if constexpr (IM2COL) {
-      if (next_full) scatter();
-    } else if (next_full) {
-      sstore_a(ra, tile_elems);
-    } else if (tnext < tiles_m) {
-      sstore_a(rs, load_tile_sync(tnext));
-    }
-    // stores last: nothing waits for them until the next tile's MFMAs are done
+  if constexpr (IM2COL) {
+    // Round 5: the stores of a tile are never waited for inside the iteration that issues them.  vmcnt retires in order, so
+    // the OLD loop (gather(i+1) -> MFMAs(i) -> wait for the gather -> stores(i)) drained the stores of tile i-1 at every wait
+    // for a gather and then left the write path idle while it scattered the tile and staged the next epilogue: 9 us per
+    // round of 512 tiles against 5.3 us of HBM write time.  Here the prefetch group of tile i+2 (its 16 gathers + the
+    // per-image bias row) is issued BEFORE the 16 stores of tile i, and the wait in front of scatter(i+2) is the counted
+    // `vmcnt(16)`: it retires the prefetch group and everything older -- the stores of tile i-1 -- and leaves the 16 stores
+    // of tile i in flight for one whole iteration more.  (A whole tile lies inside one image -- H W % 128 == 0, host-checked --
+    // so its bias2 row is ONE 16-byte load per lane; all tiles are full: M % 128 == 0, N % 128 == 0 checked by the launcher
+    // for the counted form, anything else waits with vmcnt(0).)
+    // ONE static site per asynchronous load and per register hand-over (software-pipelined loop whose first two rounds only
+    // prefetch): with a gather in a prologue AND in the loop the two definitions of `rv` merge at the loop header and hipcc
+    // copies the destination registers there -- while the loads are in flight (tools/asm_async_scan.py, round 4's bug class).
+    float4 bq_cur = bn, bq_next = bn;
+    f32x4 bq_nxt;
+    const bool exact = (p.M % TK_TM) == 0 && (p.N % TK_TN) == 0 && !p.R;   // 16 unconditional stores per wave and tile
+    bool counted = false;   // the first wait has no stores behind its prefetch group
+    // round r: compute + store tile t0 + r mstep (r >= 0), scatter tile t0 + (r + 1) mstep, request tile t0 + (r + 2) mstep
+    for (int r = -2;; ++r) {
+      const int tc = tm + r * mstep, tsc = tc + mstep, tg = tc + 2 * mstep;
+      if (r >= 0 && tc >= tiles_m) break;
+      f32x16 acc[4];
+      if (r >= 0) {
+        __syncthreads();  // this tile's A (written in the previous round) is visible
+        mfma_tile(acc);
+        __syncthreads();  // every wave is done with this tile's A fragments
+      }
+      if (r >= -1 && tsc < tiles_m) {
+        if (counted && exact) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile(""
+                     : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),
+                       "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]),
+                       "+v"(rv[15]), "+v"(bq_nxt)::"memory");
 #pragma unroll
-    for (int q = 0; q < 4; ++q) epilogue_pass(acc, q, tm);
+        for (int j = 0; j < 16; ++j)
+          if ((emeta[j] >> 25) & 1) as[emeta[j] & 0xffff] = rv[j];
+        bq_next = make_float4(bn.x + bq_nxt[0], bn.y + bq_nxt[1], bn.z + bq_nxt[2], bn.w + bq_nxt[3]);
+      }
+      if (tg < tiles_m) {
+        gather(tg);
+        const float* src = thin_zero_word;   // the tile's bias2 row: asynchronous like the gathers, awaited by the same s_waitcnt
+        if (p.bias2 && nok) src = p.bias2 + (long)((tg * TK_TM) / p.rpg) * p.N + n;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq_nxt) : "v"(src) : "memory");
+      }
+      if (r >= 0) {
+        // stores last: they stay in flight until the wait of the round after the next
+#pragma unroll
+        for (int q = 0; q < 4; ++q) epilogue_pass(acc, q, tc, &bq_cur);
+        counted = true;
+      }
+      bq_cur = bq_next;
+    }
+  } else {
+    for (; tm < tiles_m; tm += mstep) {
+      __syncthreads();  // this tile's A (written at the end of the previous iteration) is visible
+      const int tnext = tm + mstep;
+      const bool next_full = (tnext + 1) * TK_TM <= p.M;  // block-uniform
+      if (next_full) {
+        const float* src = p.A + (long)tnext * TK_TM * K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = *(const f32x4*)(src + goff[j]);   // plain loads: hipcc owns their wait (see `ra`)
+      }
+      f32x16 acc[4];
+      mfma_tile(acc);
+      __syncthreads();  // every wave is done with this tile's A fragments
+      if (next_full) {
+        sstore_a(ra, tile_elems);
+      } else if (tnext < tiles_m) {
+        sstore_a(rs, load_tile_sync(tnext));
+      }
+      // stores last: nothing waits for them until the next tile's MFMAs are done
+#pragma unroll
+      for (int q = 0; q < 4; ++q) epilogue_pass(acc, q, tm, nullptr);
+    }
   }
 }
 

@@ -1478,6 +1478,18 @@ def _f16_geometry(N, H, W, C, idim):
             and M * 9 * C < (1 << 31))
 
 
+_F16_STATS = {}
+
+
+def f16_stats(reset=False):
+    """{(C, H, W): [blocks run on F16 (bf16-storage) kernels, blocks run on fp32 tensors]} of the block-driver forwards since
+    the last reset -- which scales of a flow the bf16-storage path actually covers (tests assert on it)."""
+    out = {k: list(v) for k, v in _F16_STATS.items()}
+    if reset:
+        _F16_STATS.clear()
+    return out
+
+
 def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, training, W2=None):
     """One iResBlock forward + log-det estimate through indm_iresblock_fwd_logdet.
     -> None if the geometry is not covered, else (y, logdet, saved) with saved = the tensors the backward needs
@@ -1490,6 +1502,7 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     dev = x.device
     M = N * H * W
     f16 = storage_dtype() == "bf16" and W2 is not None and _f16_geometry(N, H, W, C, idim)
+    _F16_STATS.setdefault((C, H, W), [0, 0])[0 if f16 else 1] += 1
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
     a = _IResFwdArgs()
     a.N, a.H, a.W, a.C, a.idim, a.preact, a.training = N, H, W, C, idim, int(preact), int(training)
