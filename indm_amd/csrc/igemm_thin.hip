@@ -397,7 +397,10 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
       }
     }
     float* crow = p.C + (long)(mw + 8 * q + lhi) * p.ldc + n;
-    if (full) {
+    if (full && ((p.tune >> 8) & 1)) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) __builtin_nontemporal_store(*(const f32x4*)&v[it], (f32x4*)(crow + (long)(2 * it) * p.ldc));
+    } else if (full) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) *(float4*)(crow + (long)(2 * it) * p.ldc) = v[it];
     } else {
@@ -447,8 +450,10 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
     // copies the destination registers there -- while the loads are in flight (tools/asm_async_scan.py, round 4's bug class).
     float4 bq_cur = bn, bq_next = bn;
     f32x4 bq_nxt;
-    const bool exact = (p.M % TK_TM) == 0 && (p.N % TK_TN) == 0 && !p.R;   // 16 unconditional stores per wave and tile
+    const bool exact = (p.M % TK_TM) == 0 && (p.N % TK_TN) == 0 && !p.R && !((p.tune >> 9) & 1);   // 16 unconditional stores per wave and tile
     bool counted = false;   // the first wait has no stores behind its prefetch group
+    if ((p.tune & 255) && ((lb / tiles_n) & 1))
+      for (int i = 0; i < (p.tune & 255); ++i) __builtin_amdgcn_s_sleep(16);
     // round r: compute + store tile t0 + r mstep (r >= 0), scatter tile t0 + (r + 1) mstep, request tile t0 + (r + 2) mstep
     for (int r = -2;; ++r) {
       const int tc = tm + r * mstep, tsc = tc + mstep, tg = tc + 2 * mstep;
@@ -508,6 +513,186 @@ __global__ __launch_bounds__(256, (IM2COL ? 2 : 3)) void igemm_thin_kflat_kernel
       for (int q = 0; q < 4; ++q) epilogue_pass(acc, q, tm, nullptr);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: 3x3 convolution of a <= 3-channel NHWC image (K = 9 C <= 27, W = 32) without the LDS round trip of its im2col
+// operand and without workgroup barriers.  igemm_thin_kflat_kernel<true, *> above staged the 128 x 27 im2col tile through
+// LDS (16 gathers + 16 ds_write_b32 per thread, two workgroup barriers per tile) and its accumulators through LDS again (64
+// ds_write_b32 + 16 ds_read_b128 per wave and tile): 72 us per launch at M = 131072 against 24 us of MFMA time and a 40 us HBM
+// write floor, and tools/kflat_probe.py showed that nothing the memory system offers moves it (non-temporal stores, stores left
+// in flight across the next tile with a counted vmcnt, de-phased workgroups: all within +-4 us; one workgroup per CU instead
+// of two: 96 us) -- the launch is bound by the length of ONE wave's dependent chain per tile at two waves per SIMD.
+// Here (the design of the bf16-storage thin convolution, flow_f16.hip):
+//   * a wave owns 32 consecutive pixels (one image row) x 128 output columns; lane (l31, lhi) gathers exactly the 14 im2col
+//     values it multiplies, k = 2 kk + lhi of pixel l31 (unconditional loads from clamped offsets + select: no branch, all
+//     14 in flight), one tile ahead of the MFMAs;
+//   * the MFMA operands are swapped, D[n][m]: the lane ends up with 16 x 4 CONSECUTIVE output columns of ITS pixel and stores
+//     them as float4 straight from the accumulators (a 128-byte row segment is completed by four stores of the same wave, as
+//     in the chain kernel's t2 store): no staging, no wave barrier;
+//   * the weight slice [28 x 128] sits in LDS for the whole launch (one barrier per workgroup, before the loop); the waves of
+//     a workgroup then run independently, four per SIMD (<= 128 VGPRs), so one wave's stores overlap another's MFMAs.
+// Same arithmetic as the kernel it replaces (k pairs in the same order on the same fp32 MFMA, (acc + (bias + bias2)) * alpha):
+// bit-identical results.
+constexpr int TR_LDW = TK_TN + 4;   // weight slice rows: [28 VW][128 + 4]
+
+// VW = 1: C = 3 (K = 27 = 27 units of one value); VW = 4: C = 12 (K = 108 = 27 units of four consecutive channels, fetched
+// with one 16-byte load).  Either way a lane gathers 14 units per tile -- unit u = 2 kk + lhi, tap = u / 3 -- and multiplies
+// them in the natural k order (k = VW u + i), so the weight rows are read as they lie in memory.  NWV waves per workgroup
+// share one weight slice ([28 VW][128] floats: 15 KB / 59 KB) and nothing else.
+// UNIT: alpha == 1 (x * 1.0f == x: the multiply is dropped; every call of the flow); JB: 32-column blocks per MFMA group
+template <int VW, int NWV, bool BF16, bool UNIT, int JB>
+__global__ __launch_bounds__(NWV * 64, (VW == 1 ? 4 : 2)) void thin_conv_rows_kernel(ThinGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float wsm[28 * VW * TR_LDW];
+  __shared__ __attribute__((aligned(16))) float bsm[NWV * TK_TN];   // per wave: bias[n] + bias2[image][n] of its current image
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int tiles_n = p.N / TK_TN;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);   // the tiles_n workgroups of one row group sit on one XCD
+  const int tn = lb % tiles_n, grp = lb / tiles_n, ngroups = gridDim.x / tiles_n;
+  const int n0 = tn * TK_TN;
+  const int K = p.K, C = p.cC, H = p.cH, W = p.cW;
+  // weight slice -> LDS (rows >= K are zero: the pad of the last pair)
+  for (int g = tid; g < 28 * VW * 32; g += NWV * 64) {
+    const int k = g >> 5, c4 = (g & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) v = *(const float4*)(p.B + (long)k * p.ldb + n0 + c4);
+    *(float4*)(wsm + k * TR_LDW + c4) = v;
+  }
+  // Instruction count is what bounds this kernel once the barriers are gone: fp32 MFMAs do not co-execute with other waves'
+  // VALU work (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r05_pmc_thin_conv_rows.txt), so every VALU instruction of a tile is
+  // added to its MFMA cycles.  The gathers therefore go through a raw BUFFER resource over the image: a lane whose tap
+  // falls outside the image ORs bit 31 into its byte offset and the load returns 0.0 by itself (out of range) -- no
+  // clamped address, no select behind the load: add + shift + and-or per unit.
+  // per-lane tables of its 14 units: offset relative to its own pixel in units of VW floats (packed 10-bit fields:
+  // |off| <= 3 (W + 1) + 2 = 101 for W = 32), and for every tap row kh the mask of the units whose tap is valid in that row
+  // (W = 32: a tile is one image row; W = 16: two -- lane l31 is column l31 % W of row l31 / W of the tile)
+  const int wl = l31 & (W - 1), dr = l31 / W, rpt = 32 / W;
+  unsigned offp[5] = {0u, 0u, 0u, 0u, 0u};   // three fields per register (offset + 128)
+  unsigned km[3] = {0u, 0u, 0u};             // bit kk of km[kh]: unit kk belongs to tap row kh, exists, column inside the image
+#pragma unroll
+  for (int kk = 0; kk < 14; ++kk) {
+    const int u = 2 * kk + lhi;
+    const int tap = u / 3, cu = u - tap * 3;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    const int dh = -p.csign * (kh - 1), dw = -p.csign * (kw - 1);
+    const bool ok = u < 27 && wl + dw >= 0 && wl + dw < W;
+    offp[kk / 3] |= (unsigned)((ok ? (dh * W + dw) * 3 + cu : 0) + 128) << (10 * (kk % 3));
+    if (ok) km[kh < 3 ? kh : 0] |= 1u << kk;
+  }
+  float* brow = bsm + wave * TK_TN;
+  const int rblocks = p.M >> 5;
+  // a wave walks CONSECUTIVE image rows (its own run of `per` tiles): the image -- and with it the bias row -- changes at most
+  // once or twice per wave (strided over the launch's waves, every tile was another image: a refresh with its drained loads per tile)
+  const int per = (rblocks + ngroups * NWV - 1) / (ngroups * NWV);
+  const int rb_beg = (grp * NWV + wave) * per, rb_end = min(rblocks, rb_beg + per);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.M * C * 4, 0x00020000);
+  float* __restrict__ Cout = p.C;
+  typedef float gvec __attribute__((ext_vector_type(VW)));
+  gvec ga[14];
+  auto gather = [&](int rbg, gvec (&g)[14]) {
+    const int r0 = rbg * rpt;
+    const int h = r0 - (r0 / H) * H + dr;   // this lane's image row
+    // taps of row kh read image row h - csign (kh - 1): kh = 0 needs h + csign inside, kh = 2 needs h - csign inside
+    const unsigned ok = (h + p.csign >= 0 && h + p.csign < H ? km[0] : 0u) | km[1] | (h - p.csign >= 0 && h - p.csign < H ? km[2] : 0u);
+    const unsigned bad = ~ok;
+    const unsigned pix = (unsigned)((rbg * 32 + l31) * 3 - 128) * (4u * VW);   // (the -128 undoes the bias of the packed offsets)
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) {
+      const unsigned o = ((offp[kk / 3] >> (10 * (kk % 3))) & 1023u) * (4u * VW);
+      const unsigned oob = (bad << (31 - kk)) & 0x80000000u;
+      if constexpr (VW == 1) g[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, (pix + o) | oob, 0, 0));
+      else g[kk] = __builtin_bit_cast(gvec, __builtin_amdgcn_raw_buffer_load_b128(xr, (pix + o) | oob, 0, 0));
+    }
+  };
+  __syncthreads();
+  int cur_img = -1;
+  gvec gn[VW == 1 ? 14 : 1];   // VW = 1: the next tile's units, requested one tile ahead (56 more registers for VW = 4: not there)
+  if constexpr (VW == 1) {
+    if (rb_beg < rb_end) gather(rb_beg, gn);
+  }
+  for (int rb = rb_beg; rb < rb_end; ++rb) {
+    if constexpr (VW == 1) {
+#pragma unroll
+      for (int kk = 0; kk < 14; ++kk) ga[kk] = gn[kk];
+      // the NEXT tile's gathers go out first: they are the oldest requests in flight when this tile's stores are issued
+      // (vmcnt retires in order), and this tile's MFMAs cover their latency
+      if (rb + 1 < rb_end) gather(rb + 1, gn);
+    } else {
+      gather(rb, ga);   // the other waves of the SIMD cover the latency
+    }
+    if constexpr (BF16) {
+#pragma unroll
+      for (int kk = 0; kk < 14; ++kk)
+#pragma unroll
+        for (int i = 0; i < VW; ++i) ga[kk][i] = rb16<true>(ga[kk][i]);
+    }
+    const int img = (rb * 32) / p.rpg;
+    if (img != cur_img) {   // wave-uniform: refresh this wave's bias row (two columns per lane; zeros without a bias:
+      cur_img = img;        // the sum below is unconditional, like the `(v + bq) * alpha` of the kernel this one replaces)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int c = lane + 64 * t;
+        float v = p.bias ? *(const float*)((const char*)p.bias + (unsigned)((n0 + c) * 4)) : 0.f;
+        if (p.bias2) v += *(const float*)((const char*)p.bias2 + (unsigned)((img * p.N + n0 + c) * 4));
+        brow[c] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // one 64-bit row pointer per tile; the 16 stores differ by immediates (j * 128 + a * 32 bytes)
+    float* crow = (float*)((char*)Cout + ((unsigned)(rb * 32 + l31) * (unsigned)p.ldc + (unsigned)(n0 + 4 * lhi)) * 4u);
+    const float* bl = brow + 4 * lhi;
+    // JB 32-column blocks at a time: their MFMAs (JB independent accumulator chains), then their 4 JB stores -- the stores
+    // of a tile are spread over its arithmetic instead of following it (the first store of a launch leaves after a
+    // fraction of a tile) and only 16 JB accumulator registers are live
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += JB) {
+      __builtin_amdgcn_sched_barrier(0);   // one group at a time: hipcc otherwise hoists every group's LDS reads to the top and spills
+      f32x16 acc[JB];
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 14; ++kk) {
+        if constexpr (VW == 4) {
+          if ((kk & 1) == 0) __builtin_amdgcn_sched_barrier(0);   // (at most eight weight reads ahead: 56 hoisted ones spill)
+        }
+#pragma unroll
+        for (int i = 0; i < VW; ++i)
+#pragma unroll
+          for (int j = 0; j < JB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(rb16<BF16>(wsm[(VW * (2 * kk + lhi) + i) * TR_LDW + l31 + (j0 + j) * 32]),
+                                                          ga[kk][i], acc[j], 0, 0, 0);   // D[n][m]
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // lane (l31, lhi) holds C[m = 32 rb + l31][n0 + 32 j + 8 a + 4 lhi + (0..3)] in acc[j][4a .. 4a+3]
+#pragma unroll
+      for (int j = 0; j < JB; ++j)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float4 bq = *(const float4*)(bl + (j0 + j) * 32 + 8 * a);
+          float4 v = make_float4(acc[j][4 * a] + bq.x, acc[j][4 * a + 1] + bq.y, acc[j][4 * a + 2] + bq.z, acc[j][4 * a + 3] + bq.w);
+          if constexpr (!UNIT) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
+          *(float4*)(crow + (j0 + j) * 32 + 8 * a) = v;
+        }
+    }
+  }
+}
+
+template <int VW, int NWV>
+int launch_thin_conv_rows(const ThinGemmArgs& a, int groups, int tiles_n, hipStream_t st) {
+  const dim3 grid(groups * tiles_n), blk(NWV * 64);
+  const bool unit = a.alpha == 1.0f;
+  const int jb = ((a.tune >> 13) & 3);   // probe: 0 -> 1 block per group (default: measured best), 1 -> 2
+  if (a.bf16) {
+    if (unit) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, true, 1>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, false, 1>), grid, blk, 0, st, a);
+  } else if (!unit) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, false, 1>), grid, blk, 0, st, a);
+  else if (jb == 1) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 2>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 1>), grid, blk, 0, st, a);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
 int launch_thin_k(const ThinGemmArgs& a, hipStream_t st) {
@@ -866,15 +1051,38 @@ int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, f
 
 }  // namespace
 
-int indm_thin_conv3x3(const ThinGemmArgs& a, hipStream_t st) {
+int indm_thin_conv3x3(const ThinGemmArgs& a_in, hipStream_t st) {
+  ThinGemmArgs a = a_in;
+  {
+    static const int tune = [] {   // experiment knobs, read once per process (tools/kflat_probe.py starts one process per value)
+      const char* e = getenv("INDM_THIN_TUNE");
+      return e ? (int)strtol(e, nullptr, 0) : 0;
+    }();
+    a.tune = tune;
+  }
   const int C = a.cC, H = a.cH, W = a.cW;
   if (!a.X || C < 1 || a.K != 9 * C || a.batch != 1 || a.G || a.M < 1024 || a.N < 128 || (a.N & 3) || (a.ldb & 3) ||
       (a.ldc & 3) || (a.R && (a.ldr & 3)) || !al16(a.X) || !al16(a.B) || !al16(a.C) || !al16(a.bias) || !al16(a.bias2) ||
       !al16(a.R) || (long)a.M * 9 * C >= (1L << 31))
     return THIN_NA;
   const int tiles_n = cdiv(a.N, TK_TN), tiles_m = cdiv(a.M, TK_TM);
+  // bit 12 of INDM_THIN_TUNE: the round-4 staged kernels (A/B, tools/kflat_probe.py)
+  if ((C == 3 || C == 12) && (W == 32 || W == 16) && !(H % (32 / W)) && !(a.N % TK_TN) && !a.R && !(a.M % 32) && (!a.bias2 || !(a.rpg % 32)) && !((a.tune >> 12) & 1) &&
+      (long)a.M * a.ldc * 4 < (1L << 32) && (!a.bias2 || ((long)a.M / a.rpg + 1) * a.N * 4 < (1L << 32)) && (long)a.M * C * 4 < (1L << 31)) {
+    int per_cu = (a.tune >> 10) & 3;
+    const int nwv = 4;
+    // C = 3: 88 VGPRs, 17 KB of LDS -> four workgroups per CU; C = 12: the 14 float4 units of a lane are 56 registers (~160 in
+    // all; forced under 128 hipcc spills 13 - 90 of them depending on the loop shape) and the weight slice is 59 KB -> two
+    if (!per_cu) per_cu = C == 3 ? 4 : 2;
+    int groups = 256 * per_cu / tiles_n;    // each workgroup walks its share of the image rows
+    const int rgroups = cdiv(a.M / 32, nwv);
+    if (groups > rgroups) groups = rgroups;
+    if (groups < 1) groups = 1;
+    return C == 3 ? launch_thin_conv_rows<1, 4>(a, groups, tiles_n, st) : launch_thin_conv_rows<4, 4>(a, groups, tiles_n, st);
+  }
   if (C <= 3 && W <= 128 && (128 % W) == 0 && ((H * W) % 128) == 0 && (a.M % 128) == 0 && (!a.bias2 || !(a.rpg & 7))) {
     int groups = 512 / tiles_n;  // two blocks per CU (the element tables cost registers)
+    if ((a.tune >> 10) & 3) groups = 256 * ((a.tune >> 10) & 3) / tiles_n;
     if (groups > tiles_m) groups = tiles_m;
     if (groups < 1) groups = 1;
     if (a.bf16) hipLaunchKernelGGL((igemm_thin_kflat_kernel<true, true>), dim3(groups * tiles_n), dim3(256), 0, st, a);
