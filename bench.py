@@ -27,6 +27,15 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak of the same guide
+# what "bf16" means in this build: which tensors live in HBM as bf16, which only enter the MFMAs as bf16
+BF16_TENSORS = {
+    "stored_bf16": "the flow's [pixels, 512] tensors a1, d1, a2, d2, t3, t2 and the temporaries of its backward, at the scales the "
+                   "F16 kernels cover (C <= 12 channels, >= 1024 pixels: both CIFAR scales, CelebA's first)",
+    "stored_fp32_rounded_to_bf16_at_the_mfma": "everything else that enters a contraction: the score network's activations, weights (fp32 "
+                                               "masters), the flow's 3- / 12-channel side, CelebA's 48-channel scale",
+    "fp32_always": "accumulators, GroupNorm / BatchNorm statistics, reductions, log-dets, losses, optimiser state, gradients",
+    "step_roofline_peak": "2.5 PFLOP/s dense bf16 for the WHOLE step, although part of it is fp32-stored: read `frac` with this list",
+}
 
 
 def step_gflop_per_image(n_bar):
@@ -221,7 +230,9 @@ def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
     out["images_per_s"] = 3 * 32 / (time.time() - t0)
     out["gflop_per_image"] = flops_call / 32 / 1e9
     out["achieved_tflops"] = out["gflop_per_image"] * out["images_per_s"] / 1e3
-    out["frac"] = out["achieved_tflops"] / PEAK_F32_MFMA_TFLOPS
+    bf16 = hip.compute_dtype() == "bf16"
+    out["peak_tflops"] = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS   # (--dtype bf16: the leg runs in that mode too)
+    out["frac"] = out["achieved_tflops"] / out["peak_tflops"]
     out["note"] = "random-init weights after the timed steps; eval-mode flow log-det (n+20 power-series terms)"
     score.train(); flow.train()
     return out
@@ -285,7 +296,9 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
             "nfe_per_image": 1000,
             "gflop_per_image_per_step": flops_step / batch / 1e9,
             "achieved_tflops": flops_step / (g["gpu_ms_per_step"] * 1e-3) / 1e12,
-            "frac": flops_step / (g["gpu_ms_per_step"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+            "peak_tflops": PEAK_BF16_MFMA_TFLOPS if hip.compute_dtype() == "bf16" else PEAK_F32_MFMA_TFLOPS,
+            "frac": flops_step / (g["gpu_ms_per_step"] * 1e-3) / 1e12
+                    / (PEAK_BF16_MFMA_TFLOPS if hip.compute_dtype() == "bf16" else PEAK_F32_MFMA_TFLOPS)}
 
 
 def pmc_traffic(kernel_key):
@@ -309,6 +322,16 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def per_rank_batch(batch, global_batch, world):
+    """-> (images per rank, strong?): `--batch B` keeps B images per GPU (weak scaling); `--global-batch G` shards a fixed
+    global batch evenly over the ranks (strong scaling: the partitioning of BASELINE configs #3 - #5) and overrides it."""
+    if global_batch > 0:
+        if global_batch % world:
+            raise SystemExit(f"--global-batch {global_batch} does not divide over {world} ranks")
+        return global_batch // world, True
+    return batch, False
 
 
 def launch_ranks(n, argv):
@@ -430,21 +453,34 @@ def run_training(args, cfg_name, batch, dtype, steps, warmup, rank, world, dev, 
             nb = 4.0 * 3 * M * 512 + 4.0 * 512 * 512 + 4.0 * M * J + (4.0 * M * 512 if "t2out" in variant else 0)
         prof[dominant] = dict(launches=p0["launches"] + r["launches"], flops=p0["flops"] + r["flops"],
                               bytes=p0["bytes"] + nb * r["launches"], ms=p0["ms"] + r["ms"])
-    exposed_ms = None
+    exposed_ms, exposed_info = None, None
     if exposed and dist_on and world > 1:
-        # the same step WITHOUT the collective (replicas drift apart from here on: last thing this function does): what
-        # the all-reduce costs on the critical path = step time with it - step time without it
+        # the same steps WITHOUT the collective (replicas drift apart from here on: last thing this function does): what the
+        # all-reduce costs on the critical path = step time with it - step time without it.  The flow's cost follows the
+        # Poisson series lengths (n + 8 passes per block), so the replay draws them from a FRESH stream with the timed run's
+        # seeds and walks the same warm-up + timed batches: every replayed step unrolls exactly the series its timed twin did
+        # (a continued stream on other batches made the difference noise of a few ms at 264 ms per step).
         nocoll = losses.get_step_fn(cfg, sde, train=True, world_size=world, allreduce=None)
-        k = max(2, min(steps, 6))
-        nocoll(state, flow_state, batches[0], rng=rng)
+        rng2 = DeviceRng(dev, seed=1234 + rank, poisson_seed=4321)
+        for i in range(warmup):
+            nocoll(state, flow_state, batches[i], rng=rng2)
         barrier()
+        m2 = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t1 = time.time()
-        for i in range(k):
-            nocoll(state, flow_state, batches[i % len(batches)], rng=rng)
+        m2[0].record()
+        for i in range(steps):
+            nocoll(state, flow_state, batches[warmup + i], rng=rng2)
+            m2[i + 1].record()
         barrier()
-        t_nc = torch.tensor([(time.time() - t1) / k], device=dev)
+        t_nc = torch.tensor([(time.time() - t1) / steps], device=dev)
         torch.distributed.all_reduce(t_nc, op=torch.distributed.ReduceOp.MAX)
         exposed_ms = 1e3 * float(t_nc)
+        # per-step differences on this rank (GPU-side step boundaries): their spread says how far to trust the mean
+        d = [marks[i].elapsed_time(marks[i + 1]) - m2[i].elapsed_time(m2[i + 1]) for i in range(steps)]
+        mean_d = sum(d) / len(d)
+        exposed_info = {"per_step_difference_ms_rank0": {"mean": mean_d, "min": min(d), "max": max(d),
+                                                         "std": (sum((v - mean_d) ** 2 for v in d) / len(d)) ** 0.5},
+                        "replayed_steps": steps, "same_poisson_stream": True}
     if dist_on:
         t = torch.tensor([elapsed], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -473,7 +509,9 @@ def run_training(args, cfg_name, batch, dtype, steps, warmup, rank, world, dev, 
     return dict(cfg=cfg, sde=sde, score=score, flow=flow, elapsed=elapsed, images_per_s=imgs_per_s,
                 ms_per_step=1e3 * elapsed / steps, median_ms=median_ms, roofline=roof, n_bar=n_bar,
                 last_loss_mean=float(last[0].mean()) if last is not None else None,
-                allreduce_exposed_ms=(1e3 * elapsed / steps - exposed_ms) if exposed_ms is not None else None,
+                allreduce_exposed_ms=max(0.0, 1e3 * elapsed / steps - exposed_ms) if exposed_ms is not None else None,
+                allreduce_exposed_raw_ms=(1e3 * elapsed / steps - exposed_ms) if exposed_ms is not None else None,
+                allreduce_exposed_detail=exposed_info,
                 ms_per_step_without_collective=exposed_ms,
                 collectives_per_step=list(reducer.calls) if reducer is not None else None)
 
@@ -534,11 +572,7 @@ def main():
         local = 0
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks")
-    strong = args.global_batch > 0
-    if strong:
-        if args.global_batch % world:
-            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
-        args.batch = args.global_batch // world
+    args.batch, strong = per_rank_batch(args.batch, args.global_batch, world)
     # host-side work per step is a few [B]-vector ops: keep every rank's intra-op pool small so N ranks on one host do
     # not oversubscribe its cores
     torch.set_num_threads(max(1, min(8, _usable_cores() // max(world, 1))))
@@ -582,7 +616,9 @@ def main():
         out["devices"] = idents
         out["backend"] = torch.distributed.get_backend() if dist_on else None
         if world > 1:
-            out["allreduce_exposed_ms"] = r["allreduce_exposed_ms"]
+            out["allreduce_exposed_ms"] = r["allreduce_exposed_ms"]          # clamped at 0; the raw difference and its spread:
+            out["allreduce_exposed_raw_ms"] = r["allreduce_exposed_raw_ms"]
+            out["allreduce_exposed_detail"] = r["allreduce_exposed_detail"]
             out["ms_per_step_without_collective"] = r["ms_per_step_without_collective"]
             out["collective_elements_per_step"] = r["collectives_per_step"]
         if world == 1 and not args.no_cpu_baseline:
@@ -608,7 +644,8 @@ def main():
                     out["bf16"] = {"value": b["images_per_s"], "unit": "images/s", "ms_per_step": b["ms_per_step"],
                                    "ms_per_step_median": b["median_ms"], "steps": min(args.steps, 8), "warmup": 2,
                                    "roofline": b["roofline"], "last_loss_mean": b["last_loss_mean"], "n_bar": b["n_bar"],
-                                   "dtype": "bf16 MFMA inputs, fp32 accumulate, bf16 storage of the flow's 512-wide tensors"}
+                                   "dtype": "bf16 MFMA inputs, fp32 accumulate, bf16 storage of the flow's 512-wide tensors",
+                                   "bf16_tensors": BF16_TENSORS}
                     del b
                     torch.cuda.empty_cache()
                 out["train_per_rank_shard_of_8"] = shard_legs(args, dev)

@@ -250,13 +250,7 @@ int launch_attn(const AttnArgs& p, int B, hipStream_t st) {
   constexpr int BUF1 = NARR * (T + OWN) * BK;
   constexpr int main_f = (2 * BUF1 > 2 * 64 * 128 ? 2 * BUF1 : 2 * 64 * 128);
   constexpr size_t bytes = (size_t)(main_f + (MODE == DKV ? 2 * T : 0)) * sizeof(float);
-  static bool ready = false;
-  if (!ready) {
-    if (hipFuncSetAttribute((const void*)attn_kernel<MODE, NB, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
-        hipSuccess)
-      return INDM_E_LAUNCH;
-    ready = true;
-  }
+  if (indm_lds_optin<attn_kernel<MODE, NB, WV>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
   hipLaunchKernelGGL((attn_kernel<MODE, NB, WV>), dim3(T / OWN, B), dim3(WV * 64), bytes, st, p);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }

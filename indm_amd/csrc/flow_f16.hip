@@ -333,13 +333,7 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_rows_kernel(RowsArgs p) {
 template <int MODE, int JB, bool T2OUT, int TMV>
 int launch_rows_tm(const RowsArgs& a, hipStream_t st) {
   constexpr int bytes = TMV * R_N * 2;
-  static bool ready = false;
-  if (!ready) {
-    if (hipFuncSetAttribute((const void*)f16_rows_kernel<MODE, JB, T2OUT, TMV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            bytes) != hipSuccess)
-      return INDM_E_LAUNCH;
-    ready = true;
-  }
+  if (indm_lds_optin<f16_rows_kernel<MODE, JB, T2OUT, TMV>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
   hipLaunchKernelGGL((f16_rows_kernel<MODE, JB, T2OUT, TMV>), dim3(a.M / TMV), dim3(R_NW * 64), bytes, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
@@ -976,12 +970,7 @@ INDM_API int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(((S + 7) / 8) * 8 * 16);
   constexpr int lds2 = 4 * 128 * (32 * 2 + 8) * 2, lds1 = 4 * 128 * (32 + 8) * 2;
-  static bool ready = false;
-  if (!ready) {
-    if (hipFuncSetAttribute((const void*)f16_wgrad_gemm_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess)
-      return INDM_E_LAUNCH;
-    ready = true;
-  }
+  if (!gateX && indm_lds_optin<f16_wgrad_gemm_kernel<false, 2>>(lds2) != INDM_OK) return INDM_E_LAUNCH;   // 72 KB (the gated form: 40 KB)
   if (gateX) hipLaunchKernelGGL((f16_wgrad_gemm_kernel<true, 1>), grid, dim3(256), lds1, st, p);
   else hipLaunchKernelGGL((f16_wgrad_gemm_kernel<false, 2>), grid, dim3(256), lds2, st, p);
   INDM_CHECK_LAUNCH();

@@ -860,15 +860,31 @@ __global__ void thin_wgrad_reduce(const float* __restrict__ ws, float* __restric
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int t = i / N, c = i - t * N;
+  // Round 5: SIXTEEN slab values requested before the first is added (the loop used to fetch four, wait, add: S / 4 memory
+  // latencies one after the other -- 15 us for S = 192 slabs of 55 KB, two thirds of what the weight-grad kernel itself takes).
+  // The sums keep their association (s_j collects the slabs s = j mod 4 in order): bit-identical results.
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float* w = ws + i;
   int s = 0;
-  for (; s + 3 < S; s += 4) {
-    s0 += ws[(long)s * total + i];
-    s1 += ws[(long)(s + 1) * total + i];
-    s2 += ws[(long)(s + 2) * total + i];
-    s3 += ws[(long)(s + 3) * total + i];
+  for (; s + 15 < S; s += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = w[(long)(s + j) * total];
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+      s0 += v[j];
+      s1 += v[j + 1];
+      s2 += v[j + 2];
+      s3 += v[j + 3];
+    }
   }
-  for (; s < S; ++s) s0 += ws[(long)s * total + i];
+  for (; s + 3 < S; s += 4) {
+    s0 += w[(long)s * total];
+    s1 += w[(long)(s + 1) * total];
+    s2 += w[(long)(s + 2) * total];
+    s3 += w[(long)(s + 3) * total];
+  }
+  for (; s < S; ++s) s0 += w[(long)s * total];
   const float v = alpha * ((s0 + s1) + (s2 + s3));
   if (transpose) out[(long)c * ldo + t] = v;
   else out[(long)t * ldo + c] = v;
@@ -993,13 +1009,8 @@ int launch_thin_wgrad_dma(const float* thin, const float* wide, const float* gat
                           int P, dim3 grid, hipStream_t st) {
   const int thin_floats = ((TD_BK * T + TP + 3) & ~3);
   const size_t bytes = 2 * (size_t)(TD_BK * 128 * (HAS_G ? 2 : 1) + thin_floats) * sizeof(float);
-  static size_t ready = 0;  // > 64 KB of LDS needs the opt-in (per instantiation; T changes the size)
-  if (bytes > ready) {
-    if (hipFuncSetAttribute((const void*)thin_wgrad_dma_kernel<TP, HAS_G, BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess)
-      return INDM_E_LAUNCH;
-    ready = bytes;
-  }
+  // > 64 KB of LDS needs the opt-in (per instantiation and device; T changes the size)
+  if (indm_lds_optin<thin_wgrad_dma_kernel<TP, HAS_G, BF16>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
   hipLaunchKernelGGL((thin_wgrad_dma_kernel<TP, HAS_G, BF16>), grid, dim3(256), bytes, st, thin, wide, gate, ws, T, N, ldw, chunk, P);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }

@@ -23,6 +23,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Opt-in for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize), once per kernel AND per device:
+// the attribute belongs to the function on the CURRENT device, so a process-wide flag would skip the opt-in on a second
+// GPU of the same process.  The size only grows; racing threads repeat an idempotent call.
+template <auto Kernel>
+static inline int indm_lds_optin(size_t bytes) {
+  static size_t ready[32] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return INDM_E_LAUNCH;
+  const bool tracked = dev >= 0 && dev < 32;
+  if (tracked && __atomic_load_n(&ready[dev], __ATOMIC_RELAXED) >= bytes) return INDM_OK;
+  if (hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return INDM_E_LAUNCH;
+  if (tracked) __atomic_store_n(&ready[dev], bytes, __ATOMIC_RELAXED);
+  return INDM_OK;
+}
+
 // Grid size for grid-stride HBM-bound kernels: enough workgroups to fill
 // 256 CUs x 8 blocks, no more (cdna guide, Guideline 11).
 static inline int ew_grid(long n_items, int block) {

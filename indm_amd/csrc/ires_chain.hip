@@ -418,13 +418,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_pw_kernel(ChainArgsPW q
 template <int JB, bool T2OUT>
 int launch_chain_pw_t(const ChainArgsPW& q, hipStream_t st) {
   constexpr size_t bytes = PW_NBUF * PW_BUF * sizeof(float);  // 72 KB (the 64 KB stage-2 reduction buffer overlays it)
-  static bool ready = false;
-  if (!ready) {
-    if (hipFuncSetAttribute((const void*)ires_chain_pw_kernel<JB, T2OUT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess)
-      return INDM_E_LAUNCH;
-    ready = true;
-  }
+  if (indm_lds_optin<ires_chain_pw_kernel<JB, T2OUT>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
   hipLaunchKernelGGL((ires_chain_pw_kernel<JB, T2OUT>), dim3(q.c.M / TM), dim3(NW * 64), bytes, st, q);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
@@ -432,13 +426,7 @@ int launch_chain_pw_t(const ChainArgsPW& q, hipStream_t st) {
 template <int JB, bool BF16, bool T2OUT, int TMV>
 int launch_chain_tm(const ChainArgs& p, hipStream_t st) {
   constexpr size_t bytes = 2 * BUF * sizeof(float);
-  static bool ready = false;
-  if (!ready) {
-    if (hipFuncSetAttribute((const void*)ires_chain_kernel<JB, BF16, T2OUT, TMV>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)bytes) != hipSuccess)
-      return INDM_E_LAUNCH;
-    ready = true;
-  }
+  if (indm_lds_optin<ires_chain_kernel<JB, BF16, T2OUT, TMV>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
   hipLaunchKernelGGL((ires_chain_kernel<JB, BF16, T2OUT, TMV>), dim3(p.M / TMV), dim3(NW * 64), bytes, st, p);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }

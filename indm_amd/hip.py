@@ -353,7 +353,12 @@ F16_STORAGE = {"on": os.environ.get("INDM_F16_STORAGE", "1") != "0"}   # tools /
 
 def storage_dtype():
     """'bf16' when the flow's 512-wide tensors live in HBM as bf16 (bf16 compute mode on the block drivers: F16 fragment
-    order, csrc/flow_f16.hip), else 'f32'"""
+    order, csrc/flow_f16.hip), else 'f32'.
+    THREE switches decide it: set_compute_dtype('bf16'), f16_storage(True) (default) and block_drivers(True) (default) -- the
+    op-level composition has no F16 form, so block_drivers(False) silently falls back to bf16 MFMA inputs on fp32 tensors
+    (bench.py's profiled warm-up step and tools/ rely on that).  It applies to the training AND the eval forward (the
+    NELBO's power-series log-det); the fixed-point inverse always runs on fp32 tensors (bf16 MFMA inputs in bf16 mode):
+    tests/test_block_drivers_gpu.py::test_bf16_storage_eval_logdet_and_inverse_round_trip states the resulting tolerances."""
     return "bf16" if (_MFMA["dtype"] == "bf16" and F16_STORAGE["on"] and BLOCK_DRIVERS["on"]) else "f32"
 
 

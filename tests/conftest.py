@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # skip REASONS in the short summary of every run (`-rs`), also under the driver's plain `-x -q`: a self-skipping test
+    # (the 2-GPU RCCL step on a one-GPU box) must say why in the log nobody watches
+    if "s" not in (config.option.reportchars or ""):
+        config.option.reportchars = (config.option.reportchars or "") + "s"
 
 
 @pytest.fixture

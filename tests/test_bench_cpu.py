@@ -70,3 +70,45 @@ def test_synthetic_batch_is_the_dequantised_uniform_image_of_the_reference_pipel
     assert float(x.min()) >= -1.0 and float(x.max()) < 1.0          # (255 u + U[0,1)) / 256 * 2 - 1
     assert torch.equal(x, bench.synthetic_batch(4, 32, 0, torch.device("cpu")))      # seeded: the same batch again
     assert not torch.equal(x, bench.synthetic_batch(4, 32, 1, torch.device("cpu")))
+
+
+def test_per_rank_batch_of_weak_and_strong_scaling():
+    assert bench.per_rank_batch(128, 0, 8) == (128, False)          # --batch: per-GPU batch fixed
+    assert bench.per_rank_batch(128, 128, 8) == (16, True)          # --global-batch: configs #2 / #3 / #4-#5 on 8 ranks
+    assert bench.per_rank_batch(128, 512, 8) == (64, True) and bench.per_rank_batch(7, 256, 8) == (32, True)
+    with pytest.raises(SystemExit):
+        bench.per_rank_batch(128, 100, 8)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra,scaling,per_rank", [(["--batch", "2"], "weak", 2), (["--global-batch", "4"], "strong", 2)])
+def test_multi_rank_path_dry_run_on_cpu(extra, scaling, per_rank):
+    """What an unattended `bench.py --gpus N` run depends on besides the kernels, with two gloo ranks on CPU (kernel layer
+    emulated, mini configuration, tests/bench_dry_run.py): rank bookkeeping, weak / strong batch partitioning, the gradient
+    reducer's two collectives per step, barrier-bracketed timing, and the no-collective replay behind `allreduce_exposed_ms`
+    (same Poisson stream and step count as the timed run, clamped at 0, spread reported)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    port = 29700 + (os.getpid() + len(extra[0])) % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "bench_dry_run.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1"] + extra
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["per_rank_batch"] == per_rank and d["global_batch"] == 2 * per_rank
+    assert d["value"] > 0 and abs(d["value"] - d["global_batch"] * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-6
+    assert d["backend"] == "gloo" and len(d["collective_elements_per_step"]) == 2 and min(d["collective_elements_per_step"]) > 0
+    assert d["allreduce_exposed_ms"] >= 0.0 and d["allreduce_exposed_ms"] == max(0.0, d["allreduce_exposed_raw_ms"])
+    det = d["allreduce_exposed_detail"]
+    assert det["same_poisson_stream"] and det["replayed_steps"] == 2
+    s = det["per_step_difference_ms_rank0"]
+    assert s["min"] <= s["mean"] <= s["max"] and s["std"] >= 0
+    assert d["ms_per_step_without_collective"] > 0

@@ -49,6 +49,9 @@ def test_two_rank_bench_weak_and_strong():
     assert weak["ranks_seen"] == 2 and weak["distinct_devices"] == 1 and weak["backend"] == "gloo"
     assert len(weak["devices"]) == 2 and all("name" in d for d in weak["devices"])
     assert isinstance(weak["allreduce_exposed_ms"], float) and weak["ms_per_step_without_collective"] > 0
+    # clamped at 0; the raw difference and the per-step spread of the replay (same Poisson stream, same step count) are there
+    assert weak["allreduce_exposed_ms"] == max(0.0, weak["allreduce_exposed_raw_ms"])
+    assert weak["allreduce_exposed_detail"]["same_poisson_stream"] and weak["allreduce_exposed_detail"]["replayed_steps"] == 2
     assert weak["collective_elements_per_step"] and len(weak["collective_elements_per_step"]) == 2
     assert weak["cpu_baseline"] is None            # rank 0 at N = 1 only
     strong = _run(["--global-batch", "16"], port + 1)

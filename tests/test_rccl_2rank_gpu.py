@@ -41,7 +41,8 @@ def _rank_main(rank, world, port, out_path, fx, backend="nccl"):
 @pytest.mark.parametrize("fx", ["mini_vp_nll", "mini_vp_fid"])
 def test_two_rank_rccl_step(fx, tmp_path):
     if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs (RCCL over xGMI); single-GPU box")
+        pytest.skip(f"RCCL with two ranks needs 2 GPUs: this box exposes {torch.cuda.device_count()} "
+                    "(the same step over gloo on one GPU runs below; on an 8-GPU node this test runs)")
     port = 29500 + os.getpid() % 1000
     path = str(tmp_path / "r{rank}.pt")
     mp.spawn(_rank_main, args=(2, port, path, fx), nprocs=2, join=True)
