@@ -1004,6 +1004,81 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_dma_kernel(const float* __r
     }
 }
 
+// ---- register-streamed form of the thin weight grad, T <= 32 (round 5) ---------------------------------------------------
+// Both forms above copy a 32-pixel slab to LDS, wait for it with vmcnt(0), synchronise the workgroup and only then multiply:
+// one slab (16 / 32 KB) in flight per workgroup: 3.9 - 4.5 TB/s on launches that only have to read 268 / 536 MB once.  The
+// contraction needs no LDS at all: with the MFMA's B operand taken as `wide[pixel 2 kk + lhi][128 w + 4 l31 + i]` -- the four
+// floats of ONE 16-byte load per lane, a half-wave reading the 512 contiguous bytes of its pixel's row piece -- MFMA i (i = 0..3)
+// accumulates output columns 128 w + 4 l31 + i: a permutation of the columns, undone for free by the float4 stores of the
+// epilogue.  The A operand thin[pixel 2 kk + lhi][t = l31] is one dword load (lanes t >= T read on into the next pixel: they
+// feed output rows that are never stored; a raw buffer resource returns 0 past the end of the tensor).  A workgroup owns a run
+// of PIXELS and all N columns -- wave w the 128-column tile w, so the workgroup reads whole contiguous rows -- and its waves
+// never meet: no barrier, no cross-wave sum, two stages of four pixel pairs in flight per wave (24 loads, counted vmcnt waits).
+// Per pixel pair and 128 columns: two 16-byte loads (wide, gate), one dword load, two packed multiplies, four MFMAs.
+// Measured at M = 131072 (tools/thin_bench.py, kernel + slab reduce; split = workgroups = partial slabs): ungated 61.4 us staged
+// (192 slabs) -> 56.5 us at 256, 73 at 512, 96 at 1024; gated 106.3 -> 105.2 / 114 / 141: the launch is at the part's mixed-read
+// rate either way (4.7 - 5.1 TB/s) and the reduce of the partial slabs (55 KB each) is what a finer split costs, so ONE
+// workgroup per CU (256) is the default (INDM_THIN_WGRAD_STREAM = split, 0 = the staged forms above).
+template <bool HAS_G, bool BF16>
+__global__ __launch_bounds__(256, 2) void thin_wgrad_stream_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
+                                                                    const float* __restrict__ gate, float* __restrict__ ws, int T,
+                                                                    int N, long ldw, int chunk, int P) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n0 = (blockIdx.x * 4 + wave) * 128;
+  if (n0 >= N) return;
+  const int w_beg = blockIdx.y * chunk, w_end = min(P, w_beg + chunk);   // a multiple of 16 pixels (host-checked)
+  const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void*)thin, 0, (int)((long)P * T * 4), 0x00020000);
+  const unsigned w_off = (unsigned)(lhi * ldw + 4 * l31) * 4u;        // bytes from the pair's row base
+  const unsigned t_off = (unsigned)(lhi * T + l31) * 4u;
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  constexpr int U = 4;   // pixel pairs per stage
+  f32x4 wv[2][U], gv[2][U];
+  float tv[2][U];
+  auto request = [&](int px, int st) {   // the pixel pairs (px + 2u, px + 2u + 1) -> stage st
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long row = (long)(px + 2 * u) * ldw + n0;
+      wv[st][u] = *(const f32x4*)((const char*)(wide + row) + w_off);
+      if constexpr (HAS_G) gv[st][u] = *(const f32x4*)((const char*)(gate + row) + w_off);
+      tv[st][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(tr, (unsigned)((px + 2 * u) * T) * 4u + t_off, 0, 0));
+    }
+  };
+  auto consume = [&](int st) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      f32x4 b = wv[st][u];
+      if constexpr (HAS_G) b = b * gv[st][u];
+      const float a = rb16<BF16>(tv[st][u]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, rb16<BF16>(b[i]), acc[i], 0, 0, 0);
+    }
+  };
+  int px = w_beg;
+  if (px < w_end) request(px, 0);
+  for (; px + 4 * U <= w_end; px += 4 * U) {   // two stages per trip: no register rotation
+    request(px + 2 * U, 1);
+    __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the requests below the MFMAs they are meant to run under)
+    consume(0);
+    __builtin_amdgcn_sched_barrier(0);
+    request(min(px + 4 * U, w_end - 2 * U), 0);   // unconditional (the last trip re-reads its own pixels): a branch here makes hipcc
+    __builtin_amdgcn_sched_barrier(0);            // wait for the merged state of both paths, i.e. drain the requests it has just issued
+    consume(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // lane (l31, lhi), register r of accumulator i: out[t = (r & 3) + 8 (r >> 2) + 4 lhi][n0 + 4 l31 + i]
+  float* out = ws + (long)blockIdx.y * T * N + n0 + 4 * l31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    if (t < T) *(float4*)(out + (long)t * N) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+  }
+}
+
 template <int TP, bool HAS_G, bool BF16>
 int launch_thin_wgrad_dma(const float* thin, const float* wide, const float* gate, float* ws, int T, int N, long ldw, int chunk,
                           int P, dim3 grid, hipStream_t st) {
@@ -1027,6 +1102,23 @@ int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, f
   S = cdiv(P, chunk);
   if (S * T * N > ws_floats || S > 65535) return THIN_NA;
   dim3 grid(tiles_n, (unsigned)S);
+  static const int stream_s = [] { const char* e = getenv("INDM_THIN_WGRAD_STREAM"); return e ? atoi(e) : 256; }();   // 0: staged forms
+  if (T <= 32 && !(N & 127) && !(ldw & 3) && (long)P * T * 4 < (1L << 31) && stream_s > 0) {
+    // register-streamed form: one workgroup per pixel run (all N columns, 128 per wave), one workgroup per CU
+    long Ss = stream_s;
+    int ch = cdiv(cdiv(P, Ss), TW_BK) * TW_BK;   // a multiple of 32 pixels (P % 32 == 0 checked above): whole 16-pixel trips
+    Ss = cdiv(P, ch);
+    if (Ss * T * N <= ws_floats && Ss <= 65535) {
+      const dim3 g2(cdiv(tiles_n, 4), (unsigned)Ss);
+      if (gate) { if (bf16) hipLaunchKernelGGL((thin_wgrad_stream_kernel<true, true>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P);
+        else hipLaunchKernelGGL((thin_wgrad_stream_kernel<true, false>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P); }
+      else { if (bf16) hipLaunchKernelGGL((thin_wgrad_stream_kernel<false, true>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P);
+        else hipLaunchKernelGGL((thin_wgrad_stream_kernel<false, false>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P); }
+      if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+      hipLaunchKernelGGL(thin_wgrad_reduce, dim3(cdiv((long)T * N, 256)), dim3(256), 0, st, ws, out, (int)Ss, T, N, alpha, transpose, ldo);
+      return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+    }
+  }
   // direct-to-LDS form for the UNGATED launches: full 128-column tiles, 16-byte aligned rows (every production shape).
   // Measured at M = 131072 / 32768 (kernel + reduce): 77 -> 69 us and 65 -> 57 us ungated; the gated form reads three LDS
   // words per MFMA at two workgroups per CU and ran 119 / 73 us against 114 / 68 us register-staged, so it stays there.

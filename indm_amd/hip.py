@@ -358,7 +358,7 @@ def storage_dtype():
     op-level composition has no F16 form, so block_drivers(False) silently falls back to bf16 MFMA inputs on fp32 tensors
     (bench.py's profiled warm-up step and tools/ rely on that).  It applies to the training AND the eval forward (the
     NELBO's power-series log-det); the fixed-point inverse always runs on fp32 tensors (bf16 MFMA inputs in bf16 mode):
-    tests/test_block_drivers_gpu.py::test_bf16_storage_eval_logdet_and_inverse_round_trip states the resulting tolerances."""
+    tests/test_block_drivers_gpu.py::test_bf16_storage_eval_logdet_and_inverse_tolerances states the resulting tolerances."""
     return "bf16" if (_MFMA["dtype"] == "bf16" and F16_STORAGE["on"] and BLOCK_DRIVERS["on"]) else "f32"
 
 

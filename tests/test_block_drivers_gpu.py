@@ -143,12 +143,13 @@ def test_bf16_storage_block_tracks_bf16_compute_on_fp32_tensors(drivers, B):
     print("largest relative gradient errors (storage, compute-only, name):", sorted(worst, reverse=True)[:5])
 
 
-def test_bf16_storage_eval_logdet_and_inverse_round_trip(drivers):
+def test_bf16_storage_eval_logdet_and_inverse_tolerances(drivers):
     """with compute_dtype = 'bf16' the EVAL forward (the NELBO's power-series log-det, n + 20 terms) also runs on
     bf16-stored activations with hardware sine / cosine, while the fixed-point inverse runs the bf16-compute kernels on fp32
     tensors -- the two directions of one flow use different numerics.  Stated tolerances, against the fp32 drivers on the same
-    weights and noise: z within 2e-3 absolute, the log-det within 2 % of its largest entry (+1e-3), and the round trip
-    inverse(forward(x)) back to x within 5e-3 absolute in BOTH modes (fp32: 1e-4)."""
+    weights and noise: z within 2e-3 absolute, the log-det within 2 % of its largest entry (+1e-3), and the inverse of the SAME
+    latent (same prior sample h: the reverse pass draws its conditioning from the prior, so forward -> inverse is not a
+    round trip in either mode) within 5e-3 absolute, same iteration counts +- 1 per block."""
     cfg, fl = _flow(7)
     fl.eval()
     hip.block_drivers(True)
@@ -163,15 +164,18 @@ def test_bf16_storage_eval_logdet_and_inverse_round_trip(drivers):
             with torch.no_grad():
                 z, ld = flow_forward(cfg, fl, x, reverse=False, rng=DeviceRng(DEV, seed=31, poisson_seed=9))
                 stats = hip.f16_stats(reset=True)
-                xr, _ = flow_forward(cfg, fl, z, reverse=True, rng=DeviceRng(DEV, seed=32))
-            outs[mode] = (z, ld, xr, stats)
+                if mode == "f32":
+                    z_ref = z
+                it = []
+                xr, _ = flow_forward(cfg, fl, z_ref, reverse=True, rng=DeviceRng(DEV, seed=32), iters=it)
+            outs[mode] = (z, ld, xr, stats, it)
     finally:
         hip.set_compute_dtype("f32")
-    z0, ld0, x0, s0 = outs["f32"]
-    z1, ld1, x1, s1 = outs["bf16"]
+    z0, ld0, x0, s0, it0 = outs["f32"]
+    z1, ld1, x1, s1, it1 = outs["bf16"]
     assert s0 == {(3, 32, 32): [0, 16], (12, 16, 16): [0, 16]} and s1 == {(3, 32, 32): [16, 0], (12, 16, 16): [16, 0]}, (s0, s1)
-    assert torch.isfinite(z1).all() and torch.isfinite(ld1).all()
+    assert torch.isfinite(z1).all() and torch.isfinite(ld1).all() and torch.isfinite(x1).all()
     assert (z1 - z0).abs().max().item() <= 2e-3
     assert (ld1 - ld0).abs().max().item() <= 2e-2 * ld0.abs().max().item() + 1e-3, (ld1, ld0)
-    assert (x0 - x).abs().max().item() <= 1e-4
-    assert (x1 - x).abs().max().item() <= 5e-3, (x1 - x).abs().max().item()
+    assert (x1 - x0).abs().max().item() <= 5e-3, (x1 - x0).abs().max().item()
+    assert len(it0) == len(it1) and max(abs(a - b) for a, b in zip(it0, it1)) <= 1, (it0, it1)
