@@ -111,3 +111,43 @@ def test_f16_kernels_keep_their_loads_in_flight(tmp_path):
     for name, k in load_pipeline_scan.scan(str(s), "f16_rows_kernel").items():
         if "Li64E" in name and "ILi3E" not in name:                 # every 64-row mode with a main loop (the chain modes'
             assert min(k["mfma_waits"][:40]) >= 4, (name, k)         # moves between the two MFMA stages are their epilogue)
+
+
+def test_lds_fold_scanner_on_planted_code(tmp_path):
+    """tools/lds_fold_scan.py: 'all threads write partials to LDS, one barrier, a few threads fold many of them' -- a straight-line
+    fold, a fold LOOP (round 3's GroupNorm), and two negatives (a uniform fold; a register butterfly without a barrier)"""
+    import lds_fold_scan
+    head = "_Zk:\n\tds_write_b32 v1, v2\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n"
+    fold = "\tv_cmp_gt_u32_e32 vcc, 4, v0\n\ts_and_saveexec_b64 s[4:5], vcc\n" + "\tds_read_b32 v3, v4\n" * 6 + "\ts_or_b64 exec, exec, s[4:5]\n\ts_endpgm\n"
+    loop = ("\tv_cmp_gt_u32_e32 vcc, 4, v0\n\ts_and_saveexec_b64 s[4:5], vcc\n.LBB0_2:\n\tds_read_b32 v3, v4\n\tv_add_f32 v5, v5, v3\n"
+            "\ts_add_i32 s6, s6, 1\n\ts_cmp_lt_i32 s6, s7\n\ts_cbranch_scc1 .LBB0_2\n\ts_or_b64 exec, exec, s[4:5]\n\ts_endpgm\n")
+    uniform = "\tds_read_b32 v3, v4\n" * 6 + "\ts_endpgm\n"
+    butterfly = "_Zk:\n" + "\tds_swizzle_b32 v1, v1 offset:swizzle(SWAP,16)\n\tv_add_f32 v1, v1, v2\n" * 5 + "\ts_endpgm\n"
+    for name, text, want in (("fold", head + fold, [6]), ("loop", head + loop, [-1]), ("uniform", head + uniform, []), ("butterfly", butterfly, [])):
+        f = tmp_path / (name + ".s")
+        f.write_text(text)
+        assert [h[2] for h in lds_fold_scan.scan(str(f))] == want, name
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_lds_fold_matches_are_the_audited_kernels(tmp_path):
+    """Every kernel of norm_act.hip / ires_chain.hip / elementwise.hip with the fold shape is one that DESIGN section 6's audit
+    table lists (and tools/flake_audit.sh stressed, or that is off the default path): a NEW match has to be looked at, stressed
+    and listed here.  The round-3 reproducer must still match (the scanner's positive control on real code)."""
+    import lds_fold_scan
+    audited = {"norm_act.hip": {"gn_stats_kernel", "gn_bwd_stats_kernel", "colreduce_part_kernel", "colreduce_final_kernel",
+                                "gn_fused_fwd_kernel", "gn_fused_bwd_kernel", "gn_fused_fwd_serial_kernel"},
+               "ires_chain.hip": {"ires_chain_kernel", "ires_chain_pw_kernel"},
+               "elementwise.hip": {"lop_colnorm_kernel", "lop_coldot_kernel"}}
+    for f, names in audited.items():
+        out = tmp_path / (f + ".s")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                        "-ffp-contract=off", "--cuda-device-only", "-S", os.path.join(CSRC, f), "-o", str(out)],
+                       check=True, capture_output=True, timeout=900)
+        found = set()
+        for k, _, _ in lds_fold_scan.scan(str(out)):
+            m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)(I[LN]|E[PNv])", k)
+            found.add(m.group(1) if m else k)
+        assert found <= names, (f, sorted(found - names))
+        if f == "norm_act.hip":
+            assert "gn_fused_fwd_serial_kernel" in found

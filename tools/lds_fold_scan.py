@@ -6,7 +6,8 @@ race-free as written), so the defence is not to have the shape -- or to know whe
 
 For every kernel of a gfx950 assembly file (hipcc -S --cuda-device-only) the scanner reports each
     ds_write ... s_barrier ... <exec narrowed> ... N >= MIN_READS ds_read ... <exec restored>
-occurrence: (kernel, line of the barrier, LDS reads inside the divergent region).  Uniform folds (all lanes read), butterflies
+occurrence: (kernel, line of the barrier, LDS reads inside the divergent region; -1 = the reads sit in a loop, i.e. a serial
+fold of unknown length: round 3's GroupNorm).  Uniform folds (all lanes read), butterflies
 (ds_swizzle / DPP / ds_bpermute, no barrier) and wave-level folds do not match.
 usage: python tools/lds_fold_scan.py file.s [...]      (exit code 0; one line per hit)"""
 import re
@@ -38,17 +39,29 @@ def scan(path):
                 wrote, barrier_line = False, None
             elif barrier_line is not None and NARROW.match(ln):
                 # divergent region: count LDS reads until exec is restored (or 400 lines / the next barrier)
-                reads, j = 0, i + 1
+                reads, j, labels, read_at, looped = 0, i + 1, {}, [], False
+                sv = re.match(r"^\s*s_and_saveexec_b64\s+(s\[\d+:\d+\])", ln)
+                saved = sv.group(1) if sv else None      # the region ends where THIS saved mask is restored
                 while j < len(lines) and j < i + 400:
                     t = lines[j].strip()
-                    if RESTORE.match(lines[j]) or t.startswith("s_barrier") or t.startswith("s_endpgm"):
+                    if t.startswith("s_barrier") or t.startswith("s_endpgm"):
                         break
+                    if RESTORE.match(lines[j]) and (saved is None or t.replace(" ", "").endswith("," + saved)):
+                        break
+                    lab = re.match(r"^(\.LBB\w+):", t)
+                    if lab:
+                        labels[lab.group(1)] = j
                     if t.startswith("ds_read") or t.startswith("ds_load"):
                         # ds_read2 / b64 / b128 read several words
                         reads += 2 if "read2" in t else 1
+                        read_at.append(j)
+                    br = re.match(r"^s_cbranch_\w+\s+(\.LBB\w+)", t)
+                    if br and br.group(1) in labels and any(labels[br.group(1)] < r < j for r in read_at):
+                        looped = True   # a backward branch over LDS reads: a serial fold loop (round 3's GroupNorm: 128 - 256 trips)
+                        break
                     j += 1
-                if reads >= MIN_READS:
-                    hits.append((kernel, barrier_line, reads))
+                if looped or reads >= MIN_READS:
+                    hits.append((kernel, barrier_line, -1 if looped else reads))
                     barrier_line = None   # one report per barrier
         i += 1
     return hits
@@ -59,5 +72,5 @@ if __name__ == "__main__":
     for p in sys.argv[1:]:
         for k, ln, n in scan(p):
             total += 1
-            print(f"{p}: {k}: barrier at line {ln}, divergent fold with {n} LDS reads")
+            print(f"{p}: {k}: barrier at line {ln}, divergent fold " + ("in a LOOP of LDS reads" if n < 0 else f"with {n} LDS reads"))
     print(f"total {total}")
