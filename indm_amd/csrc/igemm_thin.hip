@@ -1019,18 +1019,22 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_dma_kernel(const float* __r
 // (192 slabs) -> 56.5 us at 256, 73 at 512, 96 at 1024; gated 106.3 -> 105.2 / 114 / 141: the launch is at the part's mixed-read
 // rate either way (4.7 - 5.1 TB/s) and the reduce of the partial slabs (55 KB each) is what a finer split costs, so ONE
 // workgroup per CU (256) is the default (INDM_THIN_WGRAD_STREAM = split, 0 = the staged forms above).
-template <bool HAS_G, bool BF16>
+// TT = 1 (T <= 32): wave w of a workgroup owns the 128-column tile 4 blockIdx.x + w.  TT = 4 (T <= 128: the 12-channel scale,
+// T = 108): the workgroup owns ONE 128-column tile and wave w the 32 thin rows [32 w, 32 w + 32) -- the four waves request the
+// same wide / gate rows (one HBM fetch, four L1 / L2 reads) and 4 x the MFMAs run on them: MFMA-bound there.
+template <bool HAS_G, bool BF16, int TT>
 __global__ __launch_bounds__(256, 2) void thin_wgrad_stream_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
                                                                     const float* __restrict__ gate, float* __restrict__ ws, int T,
                                                                     int N, long ldw, int chunk, int P) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int n0 = (blockIdx.x * 4 + wave) * 128;
-  if (n0 >= N) return;
+  const int n0 = TT == 1 ? (blockIdx.x * 4 + wave) * 128 : blockIdx.x * 128;
+  const int t0 = TT == 1 ? 0 : wave * 32;   // first thin row of this wave
+  if (n0 >= N || t0 >= T) return;
   const int w_beg = blockIdx.y * chunk, w_end = min(P, w_beg + chunk);   // a multiple of 16 pixels (host-checked)
   const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void*)thin, 0, (int)((long)P * T * 4), 0x00020000);
   const unsigned w_off = (unsigned)(lhi * ldw + 4 * l31) * 4u;        // bytes from the pair's row base
-  const unsigned t_off = (unsigned)(lhi * T + l31) * 4u;
+  const unsigned t_off = (unsigned)(lhi * T + t0 + l31) * 4u;
   f32x16 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1070,11 +1074,11 @@ __global__ __launch_bounds__(256, 2) void thin_wgrad_stream_kernel(const float* 
     consume(1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // lane (l31, lhi), register r of accumulator i: out[t = (r & 3) + 8 (r >> 2) + 4 lhi][n0 + 4 l31 + i]
+  // lane (l31, lhi), register r of accumulator i: out[t = t0 + (r & 3) + 8 (r >> 2) + 4 lhi][n0 + 4 l31 + i]
   float* out = ws + (long)blockIdx.y * T * N + n0 + 4 * l31;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int t = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
     if (t < T) *(float4*)(out + (long)t * N) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
   }
 }
@@ -1103,17 +1107,27 @@ int launch_thin_wgrad(const float* thin, const float* wide, const float* gate, f
   if (S * T * N > ws_floats || S > 65535) return THIN_NA;
   dim3 grid(tiles_n, (unsigned)S);
   static const int stream_s = [] { const char* e = getenv("INDM_THIN_WGRAD_STREAM"); return e ? atoi(e) : 256; }();   // 0: staged forms
-  if (T <= 32 && !(N & 127) && !(ldw & 3) && (long)P * T * 4 < (1L << 31) && stream_s > 0) {
-    // register-streamed form: one workgroup per pixel run (all N columns, 128 per wave), one workgroup per CU
-    long Ss = stream_s;
+  static const int stream_wide = [] { const char* e = getenv("INDM_THIN_WGRAD_STREAM_T128"); return e ? atoi(e) : 1; }();
+  // (T > 32 only for the GATED launches -- measured at M = 32768, T = 108, kernel + reduce: gated 61.3 -> 52.7 us, ungated
+  // 50.8 -> 56.8 us: the direct-to-LDS form keeps those)
+  if ((T <= 32 || (T <= 128 && stream_wide && gate)) && !(N & 127) && !(ldw & 3) && (long)P * T * 4 < (1L << 31) && stream_s > 0) {
+    // register-streamed form.  T <= 32: one workgroup per pixel run (all N columns, 128 per wave), one workgroup per CU.
+    // T <= 128: a workgroup per (pixel run, 128-column tile), wave = 32 thin rows; the same number of workgroups per CU.
+    const bool wide_t = T > 32;
+    long Ss = wide_t ? cdiv(stream_s, tiles_n) * 2 : stream_s;
     int ch = cdiv(cdiv(P, Ss), TW_BK) * TW_BK;   // a multiple of 32 pixels (P % 32 == 0 checked above): whole 16-pixel trips
     Ss = cdiv(P, ch);
     if (Ss * T * N <= ws_floats && Ss <= 65535) {
-      const dim3 g2(cdiv(tiles_n, 4), (unsigned)Ss);
-      if (gate) { if (bf16) hipLaunchKernelGGL((thin_wgrad_stream_kernel<true, true>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P);
-        else hipLaunchKernelGGL((thin_wgrad_stream_kernel<true, false>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P); }
-      else { if (bf16) hipLaunchKernelGGL((thin_wgrad_stream_kernel<false, true>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P);
-        else hipLaunchKernelGGL((thin_wgrad_stream_kernel<false, false>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P); }
+      const dim3 g2(wide_t ? tiles_n : cdiv(tiles_n, 4), (unsigned)Ss);
+#define INDM_TWS(G, B, TTV) hipLaunchKernelGGL((thin_wgrad_stream_kernel<G, B, TTV>), g2, dim3(256), 0, st, thin, wide, gate, ws, T, N, ldw, ch, (int)P)
+      if (wide_t) {
+        if (gate) { if (bf16) INDM_TWS(true, true, 4); else INDM_TWS(true, false, 4); }
+        else { if (bf16) INDM_TWS(false, true, 4); else INDM_TWS(false, false, 4); }
+      } else {
+        if (gate) { if (bf16) INDM_TWS(true, true, 1); else INDM_TWS(true, false, 1); }
+        else { if (bf16) INDM_TWS(false, true, 1); else INDM_TWS(false, false, 1); }
+      }
+#undef INDM_TWS
       if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
       hipLaunchKernelGGL(thin_wgrad_reduce, dim3(cdiv((long)T * N, 256)), dim3(256), 0, st, ws, out, (int)Ss, T, N, alpha, transpose, ldo);
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
