@@ -56,7 +56,8 @@ def test_gemm_gated(ta, tb):
 
 
 @pytest.mark.parametrize("N,H,W,C,Co", [(8, 32, 32, 3, 512), (4, 16, 16, 12, 512), (2, 64, 64, 3, 128), (16, 16, 16, 1, 256),
-                                         (3, 32, 32, 3, 260), (2, 32, 32, 8, 128), (1, 64, 16, 2, 128)])
+                                         (3, 32, 32, 3, 260), (2, 32, 32, 8, 128), (1, 64, 16, 2, 128),
+                                         (5, 32, 32, 12, 512), (3, 16, 16, 3, 128), (33, 32, 32, 3, 256), (7, 16, 16, 12, 384)])
 @pytest.mark.parametrize("sign", [-1, 1])
 def test_conv3x3_thin(N, H, W, C, Co, sign):
     """skinny-input 3x3 conv with the tap gather inside the thin-K GEMM loader (flat C <= 3 form and C % 4 == 0 form)"""
@@ -69,6 +70,12 @@ def test_conv3x3_thin(N, H, W, C, Co, sign):
     out = hip.conv3x3_thin(x.to(DEV), w.to(DEV), sign, 0.5, bias.to(DEV), bias2.to(DEV), res.to(DEV), -1.5)
     ref = _emu.conv3x3_thin(x.double(), w.double(), sign, 0.5, bias.double(), bias2.double(), res.double(), -1.5)
     close(out, ref, rtol=1e-5, atol=1e-4, name="conv3x3_thin + epilogue")
+    # the epilogue WITHOUT a residual (the row-fragment kernel of round 5 when the geometry is its own: C = 3 | 12, W = 16 | 32,
+    # Co % 128 == 0; a residual sends the call to the staged kernel): bias + per-image bias, alpha != 1 and alpha == 1 forms
+    for alpha in (0.5, 1.0):
+        out = hip.conv3x3_thin(x.to(DEV), w.to(DEV), sign, alpha, bias.to(DEV), bias2.to(DEV))
+        ref = _emu.conv3x3_thin(x.double(), w.double(), sign, alpha, bias.double(), bias2.double())
+        close(out, ref, rtol=1e-5, atol=1e-4, name=f"conv3x3_thin + bias + bias2, alpha {alpha}")
 
 
 def test_conv_dgrad_gated():
