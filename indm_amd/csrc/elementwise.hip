@@ -127,18 +127,26 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict
     const int w = (int)(pix - row * (unsigned)W);
     const int n = (int)(row / (unsigned)H);
     const int h = (int)(row - (unsigned)n * (unsigned)H);
-    float acc = bias ? bias[c] : 0.f;
+    // all nine taps requested before the first is added (round 5: with `if (outside) continue` around each load hipcc
+    // waited for every tap with vmcnt(0) before it requested the next -- nine memory latencies in sequence per element,
+    // 8 us per launch, 220 launches per step); an outside tap reads the pixel's own panel entry and adds 0.0f instead:
+    // the same sum in the same order
+    float t[9];
+    bool ok[9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hh = h + s * (kh - 1);
-      if (hh < 0 || hh >= H) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int ww = w + s * (kw - 1);
-        if (ww < 0 || ww >= W) continue;
-        acc += P[(((long)n * H + hh) * W + ww) * C9 + (kh * 3 + kw) * C + c];
+        const int tp = kh * 3 + kw;
+        ok[tp] = hh >= 0 && hh < H && ww >= 0 && ww < W;
+        t[tp] = P[(((long)n * H + (ok[tp] ? hh : h)) * W + (ok[tp] ? ww : w)) * C9 + tp * C + c];
       }
     }
+    float acc = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) acc += ok[tp] ? t[tp] : 0.f;
     float v = alpha * acc;
     if (mulp) v *= mulp[i];
     y[i] = v;

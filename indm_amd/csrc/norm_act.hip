@@ -311,18 +311,27 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
   const int total = HW * CS4;
   const long img4 = (long)n * HW * C4;           // float4 index of the image
   const int c4_0 = gb * CS4;
+  // Round 5: ALL of the thread's chunks are requested before the first is used (clamped addresses, out-of-range chunks
+  // zeroed afterwards).  Written as `if (f < total) { v = load; s += v }` every load sat behind a branch with
+  // `s_waitcnt vmcnt(0)` -- sixteen memory latencies in sequence per workgroup -- and the stores below were FLAT stores
+  // (the argument pin hides the pointer's address space) waited for one by one with `vmcnt(0) lgkmcnt(0)`: 3.8 TB/s on
+  // a kernel that only streams its tensor once in and once out.  Same sums in the same order.
+  typedef __attribute__((address_space(1))) float gfloat;
+  typedef __attribute__((address_space(1))) f32x4 gfloat4;   // (the ext-vector type: HIP's float4 class has no address-space-1 copy)
+  gfloat* yg = (gfloat*)y;
   float4 v[NF4];
+#pragma unroll
+  for (int k = 0; k < NF4; ++k) {
+    const int pix = min(tid + k * bs, total - 1) / CS4;
+    v[k] = *(const float4*)(x + (img4 + (long)pix * C4 + c4_0 + q) * 4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < NF4; ++k) {
-    const int f = tid + k * bs;
-    v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < total) {
-      const int pix = f / CS4;
-      v[k] = *(const float4*)(x + (img4 + (long)pix * C4 + c4_0 + q) * 4);
-      s1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-      s2 += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
-    }
+    if (tid + k * bs >= total) v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    s2 += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
   }
   // statistics of the slab's groups: per-wave butterfly sums (fixed order) -> one LDS word per (wave, group) -> every thread
   // adds the waves' partials of its own group in wave order.  (Round 3 folded 256 per-thread partials serially on GS threads
@@ -362,29 +371,30 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
     const float mm = a * inv_cnt;
     float var = b * inv_cnt - mm * mm;
     var = fmaxf(var, 0.f);
-    mean[n * G + gb * GS + tid] = mm;
-    rstd[n * G + gb * GS + tid] = rsqrtf(var + eps);
+    ((gfloat*)mean)[n * G + gb * GS + tid] = mm;
+    ((gfloat*)rstd)[n * G + gb * GS + tid] = rsqrtf(var + eps);
   }
-  const float4 gm = *(const float4*)(gamma + (c4_0 + q) * 4);
-  const float4 bt = *(const float4*)(beta + (c4_0 + q) * 4);
-  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+  const f32x4 gm = *(const gfloat4*)((const gfloat*)gamma + (c4_0 + q) * 4);
+  const f32x4 bt = *(const gfloat4*)((const gfloat*)beta + (c4_0 + q) * 4);
+  const float gmv[4] = {gm[0], gm[1], gm[2], gm[3]}, btv[4] = {bt[0], bt[1], bt[2], bt[3]};
+  // (a workgroup-uniform flag instead of a per-chunk branch for the whole slab: with a branch per chunk hipcc waits for the
+  // previous chunk's store -- `vmcnt(0)` at every merge -- before it computes the next)
+  const bool whole = total == NF4 * bs;
 #pragma unroll
   for (int k = 0; k < NF4; ++k) {
     const int f = tid + k * bs;
-    if (f < total) {
-      const int pix = f / CS4;
-      const long i4 = img4 + (long)pix * C4 + c4_0 + q;
-      const float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-      float out[4];
+    const int pix = min(f, total - 1) / CS4;
+    const long i4 = img4 + (long)pix * C4 + c4_0 + q;
+    const float in[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    float out[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float u = (in[j] - m) * r * gmv[j] + btv[j];
-        if (act == 1) u = silu_f(u);
-        if (drop_p > 0.f) u *= dropout_keep(seed, (uint64_t)i4, j, drop_p);
-        out[j] = u;
-      }
-      *(float4*)(y + i4 * 4) = make_float4(out[0], out[1], out[2], out[3]);
+    for (int j = 0; j < 4; ++j) {
+      float u = (in[j] - m) * r * gmv[j] + btv[j];
+      if (act == 1) u = silu_f(u);
+      if (drop_p > 0.f) u *= dropout_keep(seed, (uint64_t)i4, j, drop_p);
+      out[j] = u;
     }
+    if (whole || f < total) *(gfloat4*)(yg + i4 * 4) = f32x4{out[0], out[1], out[2], out[3]};
   }
 }
 

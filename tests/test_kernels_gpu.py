@@ -57,7 +57,7 @@ def test_gemm_gated(ta, tb):
 
 @pytest.mark.parametrize("N,H,W,C,Co", [(8, 32, 32, 3, 512), (4, 16, 16, 12, 512), (2, 64, 64, 3, 128), (16, 16, 16, 1, 256),
                                          (3, 32, 32, 3, 260), (2, 32, 32, 8, 128), (1, 64, 16, 2, 128),
-                                         (5, 32, 32, 12, 512), (3, 16, 16, 3, 128), (33, 32, 32, 3, 256), (7, 16, 16, 12, 384)])
+                                         (5, 32, 32, 12, 512), (5, 16, 16, 3, 128), (33, 32, 32, 3, 256), (7, 16, 16, 12, 384)])
 @pytest.mark.parametrize("sign", [-1, 1])
 def test_conv3x3_thin(N, H, W, C, Co, sign):
     """skinny-input 3x3 conv with the tap gather inside the thin-K GEMM loader (flat C <= 3 form and C % 4 == 0 form)"""
