@@ -631,6 +631,8 @@ static GnFused gn_fused_geom(int HW, int C, int G) {
   // small maps (8 x 8, 4 x 4): wider group blocks -- up to 32 channels = one 128-byte line per pixel -- so that a workgroup
   // has at least ~1024 chunks of work and the grid is not thousands of near-empty workgroups
   while ((long)HW * (gs * cpg / 4) < 1024 && 2 * gs * cpg <= 32 && 2 * gs <= GNF_MAXG && (G % (2 * gs)) == 0) gs *= 2;
+  // (round 5 probe: 32-channel slabs = whole 128-byte lines per pixel wherever 16 chunks per thread still hold the slab measured
+  // the same -- 16 x 16 x 256: 19.9 -> 21.6 us forward, 25.3 -> 24.7 us backward -- so the 16-channel blocks stay)
   const int cs4 = gs * cpg / 4;
   if (gs > GNF_MAXG || gs * cpg > 32 || (cs4 != 1 && cs4 != 2 && cs4 != 3 && cs4 != 4 && cs4 != 6 && cs4 != 8)) return f;
   const long total = (long)HW * cs4;
