@@ -541,10 +541,13 @@ constexpr int TR_LDW = TK_TN + 4;   // weight slice rows: [28 VW][128 + 4]
 // them in the natural k order (k = VW u + i), so the weight rows are read as they lie in memory.  NWV waves per workgroup
 // share one weight slice ([28 VW][128] floats: 15 KB / 59 KB) and nothing else.
 // UNIT: alpha == 1 (x * 1.0f == x: the multiply is dropped; every call of the flow); JB: 32-column blocks per MFMA group
-template <int VW, int NWV, bool BF16, bool UNIT, int JB>
+template <int VW, int NWV, bool BF16, bool UNIT, int JB, bool COAL = false>
 __global__ __launch_bounds__(NWV * 64, (VW == 1 ? 4 : 2)) void thin_conv_rows_kernel(ThinGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float wsm[28 * VW * TR_LDW];
   __shared__ __attribute__((aligned(16))) float bsm[NWV * TK_TN];   // per wave: bias[n] + bias2[image][n] of its current image
+  // COAL: a 32 x 32 block leaves through a per-wave LDS transpose (four ds_write_b128 + four ds_read_b128, no workgroup
+  // barrier) so that every store instruction writes eight whole 128-byte row segments instead of 32-byte pieces of 32 rows
+  __shared__ __attribute__((aligned(16))) float tsm[COAL ? NWV * 32 * 36 : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int tiles_n = p.N / TK_TN;
@@ -675,8 +678,21 @@ __global__ __launch_bounds__(NWV * 64, (VW == 1 ? 4 : 2)) void thin_conv_rows_ke
           const float4 bq = *(const float4*)(bl + (j0 + j) * 32 + 8 * a);
           float4 v = make_float4(acc[j][4 * a] + bq.x, acc[j][4 * a + 1] + bq.y, acc[j][4 * a + 2] + bq.z, acc[j][4 * a + 3] + bq.w);
           if constexpr (!UNIT) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
-          *(float4*)(crow + (j0 + j) * 32 + 8 * a) = v;
+          if constexpr (COAL) *(float4*)(tsm + (wave * 32 + l31) * 36 + 8 * a + 4 * lhi) = v;
+          else *(float4*)(crow + (j0 + j) * 32 + 8 * a) = v;
         }
+      if constexpr (COAL) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < JB; ++j)   // (JB = 1 only)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int row = (lane >> 3) + 8 * t;
+            const float4 v = *(const float4*)(tsm + (wave * 32 + row) * 36 + 4 * (lane & 7));
+            *(float4*)((char*)Cout + ((unsigned)(rb * 32 + row) * (unsigned)p.ldc + (unsigned)(n0 + (j0 + j) * 32 + 4 * (lane & 7))) * 4u) = v;
+          }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 }
@@ -686,12 +702,18 @@ int launch_thin_conv_rows(const ThinGemmArgs& a, int groups, int tiles_n, hipStr
   const dim3 grid(groups * tiles_n), blk(NWV * 64);
   const bool unit = a.alpha == 1.0f;
   const int jb = ((a.tune >> 13) & 3);   // probe: 0 -> 1 block per group (default: measured best), 1 -> 2
+  // stores through the per-wave LDS transpose (whole 128-byte row segments per store instruction) for the 3-channel form:
+  // 59.4 -> 49.3 us at M = 131072 (5.45 TB/s); the 12-channel form is MFMA-bound and measured the same either way (42.6 / 43.2 us
+  // at 16 x 16, 153 / 150 us at 32 x 32): it keeps the direct stores.  INDM_THIN_TUNE bit 15 flips the choice (tools/kflat_probe.py).
+  constexpr bool CO = VW == 1;
+  const bool flip = (a.tune >> 15) & 1;
   if (a.bf16) {
-    if (unit) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, true, 1>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, false, 1>), grid, blk, 0, st, a);
-  } else if (!unit) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, false, 1>), grid, blk, 0, st, a);
-  else if (jb == 1) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 2>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 1>), grid, blk, 0, st, a);
+    if (unit) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, true, 1, CO>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, false, 1, CO>), grid, blk, 0, st, a);
+  } else if (!unit) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, false, 1, CO>), grid, blk, 0, st, a);
+  else if (flip) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 1, !CO>), grid, blk, 0, st, a);
+  else if (jb == 1) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 2, false>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 1, CO>), grid, blk, 0, st, a);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 

@@ -44,6 +44,6 @@ if len(sys.argv) > 3 and sys.argv[2] == "--tune":   # one value per process: the
 import subprocess
 for geom in ["3,32", "12,16", "12,32"]:
     print("geometry (channels, height = width):", geom, flush=True)
-    for tune in [4096, 0, 8192, 1024, 4096, 0]:
+    for tune in [4096, 0, 32768, 0, 32768]:
         subprocess.run([sys.executable, __file__, str(B), "--tune", str(tune)],
                        env=dict(os.environ, INDM_THIN_TUNE=str(tune), KFLAT_GEOM=geom), check=True)
