@@ -61,10 +61,7 @@ __device__ __forceinline__ void dma_x4(unsigned lds_byte_addr, unsigned voff, co
 }
 
 __device__ __forceinline__ u32x4 pack8(const float* v) {   // 8 floats -> 8 bf16 (RNE), element e at bits 16 (e & 1) of word e >> 1
-  bf16x8 h;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
-  return __builtin_bit_cast(u32x4, h);
+  return __builtin_bit_cast(u32x4, indm_pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]));
 }
 __device__ __forceinline__ void unpack8(const u32x4& w, float* v) {
 #pragma unroll

@@ -502,12 +502,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4 ? 3
       bf16x8 fa[RM], fb[RN];
 #pragma unroll
       for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) fa[i][t] = (__bf16)as[(8 * lhi + t) * LDA_S + i * 32];
+        {
+          const float* q = as + 8 * lhi * LDA_S + i * 32;
+          fa[i] = indm_pack_bf16x8(q[0], q[LDA_S], q[2 * LDA_S], q[3 * LDA_S], q[4 * LDA_S], q[5 * LDA_S], q[6 * LDA_S], q[7 * LDA_S]);
+        }
 #pragma unroll
       for (int j = 0; j < RN; ++j)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) fb[j][t] = (__bf16)bs[(8 * lhi + t) * LDB_S + j * 32];
+        {
+          const float* q = bs + 8 * lhi * LDB_S + j * 32;
+          fb[j] = indm_pack_bf16x8(q[0], q[LDB_S], q[2 * LDB_S], q[3 * LDB_S], q[4 * LDB_S], q[5 * LDB_S], q[6 * LDB_S], q[7 * LDB_S]);
+        }
       mid();
 #pragma unroll
       for (int i = 0; i < RM; ++i)
@@ -869,10 +873,7 @@ __global__ __launch_bounds__(256, (TN == 256 ? 1 : 2)) void igemm_big_kernel(Ige
 
   if constexpr (BF16) {
     auto pack = [](const float4& lo, const float4& hi) {
-      bf16x8 v;
-      v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
-      v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
-      return v;
+      return indm_pack_bf16x8(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
     };
     auto slab16 = [&](auto PAR, int s) {
       using OTH = std::integral_constant<int, 1 - decltype(PAR)::value>;
@@ -1047,6 +1048,14 @@ __device__ __attribute__((aligned(16))) float indm_zero16[4] = {0.f, 0.f, 0.f, 0
 // (v_cvt_pk_bf16_f32, RNE; gated operands round the fp32 product) and packed into ONE v_mfma_f32_32x32x16_bf16 per
 // 32 x 32 block and slab -- 8x fewer matrix cycles, so the kernel turns from MFMA-bound into an HBM streamer.  (Any
 // bijection (lane-half, position) -> k is valid for an MFMA as long as both operands use the same one.)
+// LDS slab buffers (see the BF16 loop).  Three where it measured faster (bf16, ungated: implicit-GEMM convolution forward
+// + 5 .. 28 %, data-grad + 3 .. 9 %, NT GEMM + 5 %, TN split-K + 10 %), two where it did not (the A_WGRAD weight-grad
+// image - 4 .. 8 %, NN GEMM - 1 .. 5 %) and for the gated forms (3 x 40 KB would leave one workgroup per CU).
+template <int AM, int BMODE, bool HAS_G, bool BF16>
+constexpr int GLDS_NBUF = (BF16 && !HAS_G && (AM == A_CONV || AM == A_COL || (AM == A_ROW && BMODE == B_COL))) ? 3 : 2;
+template <int C>
+__device__ __forceinline__ void glds_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C) : "memory"); }
+
 template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
   static_assert(AM == A_ROW || AM == A_CONV || AM == A_COL || AM == A_WGRAD,
@@ -1086,8 +1095,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto dma = [&](const float* src, float* dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+    if constexpr (BF16) {
+      // opaque to the compiler like dma_saddr: hipcc puts an s_waitcnt vmcnt(0) in front of every LDS read that follows a
+      // BUILTIN copy (its LDS-DMA alias tracking), which would serialise the three-buffer loop even when this path never runs
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                   :: "s"(lds_byte_addr(dst_wave_base)), "v"(src) : "memory", "m0");
+    } else {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+    }
   };
   // implicit-GEMM A operand: the output pixel of each of this lane's LDS rows (fixed over the K loop)
   PixDec pix[16 / NW];
@@ -1343,17 +1359,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   float4 fa0[RM], fb0[RN], fa1[RM], fb1[RN];
   if constexpr (BF16) {
     auto pack = [](const float4& lo, const float4& hi) {
-      bf16x8 v;
-      v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
-      v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
-      return v;
+      return indm_pack_bf16x8(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
     };
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // GLDS_NBUF = 3: two slabs in flight per workgroup (round 5).  A 16-deep slab holds 4 bf16 MFMAs per wave --
+    // ~0.05 us of arithmetic between a copy wait and a workgroup barrier -- so with one slab in flight the kernel ran at the
+    // copies' latency (885 MB staged in 102 us by the 3 x 3 convolution at batch 128: 1.4 us per slab and workgroup).  The
+    // loop waits with a counted vmcnt for the OLDER slab only and synchronises with a bare s_barrier (__syncthreads()
+    // would drain the copies), as ires_chain_pw_kernel does.  Conv forward 16 x 16, 512 -> 256 at batch 128: 280 -> 201 us.
+    constexpr int D = GLDS_NBUF<AM, BMODE, HAS_G, true> - 1;
+    constexpr int NDMA = (16 / NW) * (HAS_G ? 2 : 1) + 8 / NW;   // copy instructions per stage() and wave
+    {
+      const int pre = nk < D ? nk : D;
+      for (int d = 0; d < pre; ++d) stage(d, d);
+      if (nk >= D) glds_wait_vm<NDMA * (D - 1)>();   // slab 0 has landed, the rest of the prologue is on its way
+      else glds_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    int buf = 0, sbuf = D % (D + 1);   // buffer of slab s / of slab s + D
     for (int s = 0; s < nk; ++s) {
-      const int buf = s & 1;
-      if (s + 1 < nk) stage(buf ^ 1, s + 1);
+      if (s + D < nk) stage(sbuf, s + D);   // that buffer's previous contents (slab s - 1) were read before the last barrier
       // operand by operand: read the two 4-deep fragments, (gate,) round and pack at once -- short live ranges (the
       // generic frags() + pack kept 2 x (RM + RN) float4 alive and spilled an accumulator in the gated A_COL variant)
       bf16x8 ha[RM], hb[RN];
@@ -1409,8 +1433,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       // keep the MFMAs on this side of the barrier: hipcc otherwise sinks three of the four below it and then
       // rotates the 64 accumulator registers with v_mov every iteration (and spills in the gated A_COL variant)
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      // slab s + 1 must have landed; the younger one (if any) stays in flight
+      if constexpr (D == 1) {   // two buffers: the round-2 loop tail (the weight-grad image measured 3 % slower on the bare barrier)
+        glds_wait_vm<0>();
+        __syncthreads();
+        buf ^= 1;
+        sbuf ^= 1;
+      } else {
+        if (s + 2 < nk) glds_wait_vm<NDMA>();
+        else glds_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        buf = buf == D ? 0 : buf + 1;
+        sbuf = sbuf == D ? 0 : sbuf + 1;
+      }
     }
   } else {
   stage(0, 0);
@@ -1468,7 +1503,7 @@ __global__ void igemm_splitk_reduce(IgemmParams p);
 template <int AM, int BMODE, bool HAS_G, int NW, bool BF16>
 int launch_glds_t(const IgemmParams& p, hipStream_t st) {
   constexpr int BUF = 256 * BK + (HAS_G ? 256 * BK : 0) + 128 * BK;
-  constexpr size_t bytes = 2 * BUF * sizeof(float);
+  constexpr size_t bytes = GLDS_NBUF<AM, BMODE, HAS_G, BF16> * BUF * sizeof(float);
   // > 64 KB of LDS needs the opt-in once per kernel and device
   if (indm_lds_optin<igemm_glds_kernel<AM, BMODE, HAS_G, NW, BF16>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
   dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch * p.splitk);

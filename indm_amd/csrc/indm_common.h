@@ -20,6 +20,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 indm_bf16x8 __attribute__((ext_vector_type(8)));
+// 8 floats -> 8 bf16 (RNE) as ONE vector conversion: four v_cvt_pk_bf16_f32.  Element-by-element casts into a bf16x8
+// make hipcc pair (x), (y, z), (w) and repair the lanes with v_perm_b32 / v_alignbit_b32: nine instructions per eight
+// values, in loops whose VALU work is what the MFMAs wait for (round 5).  Same rounding, same bits.
+__device__ __forceinline__ indm_bf16x8 indm_pack_bf16x8(float a, float b, float c, float d, float e, float f, float g, float h) {
+  const f32x8 v = {a, b, c, d, e, f, g, h};
+  return __builtin_convertvector(v, indm_bf16x8);
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

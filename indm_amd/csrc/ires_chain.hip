@@ -255,10 +255,7 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_kernel(ChainArgs p) {
   float4 fm0[MB], fn0[2], fm1[MB], fn1[2];
   if constexpr (BF16) {
     auto pack = [](const float4& lo, const float4& hi) {
-      bf16x8 v;
-      v[0] = (__bf16)lo.x; v[1] = (__bf16)lo.y; v[2] = (__bf16)lo.z; v[3] = (__bf16)lo.w;
-      v[4] = (__bf16)hi.x; v[5] = (__bf16)hi.y; v[6] = (__bf16)hi.z; v[7] = (__bf16)hi.w;
-      return v;
+      return indm_pack_bf16x8(lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w);
     };
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -387,13 +384,10 @@ __global__ __launch_bounds__(NW * 64, 4) void ires_chain_pw_kernel(ChainArgsPW q
     for (int i = 0; i < 2; ++i) hn[i] = *(const bf16x8*)(as + b_dst + i * 256 + lane * 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg) {
-        const int o = (j * 32 + l31) * BK + (((sg * 2 + lhi) ^ swz) << 2);
-        const f32x4 u = *(const f32x4*)(as + o) * *(const f32x4*)(as + A_SZ + o);
-        hm[j][4 * sg + 0] = (__bf16)u.x; hm[j][4 * sg + 1] = (__bf16)u.y;
-        hm[j][4 * sg + 2] = (__bf16)u.z; hm[j][4 * sg + 3] = (__bf16)u.w;
-      }
+      const int o0 = (j * 32 + l31) * BK + ((lhi ^ swz) << 2), o1 = (j * 32 + l31) * BK + (((2 + lhi) ^ swz) << 2);
+      const f32x4 u = *(const f32x4*)(as + o0) * *(const f32x4*)(as + A_SZ + o0);
+      const f32x4 w = *(const f32x4*)(as + o1) * *(const f32x4*)(as + A_SZ + o1);
+      hm[j] = indm_pack_bf16x8(u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -5,6 +5,8 @@ import torch
 from indm_amd import hip
 
 dev = "cuda"
+if os.environ.get("INDM_DENSE_BENCH_DTYPE"):   # "bf16": the same shapes with bf16 MFMA inputs / fp32 accumulate
+    hip.set_compute_dtype(os.environ["INDM_DENSE_BENCH_DTYPE"])
 def timeit(fn, flops, name, iters=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
