@@ -1055,6 +1055,15 @@ template <int AM, int BMODE, bool HAS_G, bool BF16>
 constexpr int GLDS_NBUF = (BF16 && !HAS_G && (AM == A_CONV || AM == A_COL || (AM == A_ROW && BMODE == B_COL))) ? 3 : 2;
 template <int C>
 __device__ __forceinline__ void glds_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C) : "memory"); }
+// Workgroup barrier that orders LDS accesses for the COMPILER too (workgroup-scope release / acquire fences around
+// s_barrier: what __syncthreads() is made of) without waiting for the asm-issued copies, which hipcc does not count: a bare
+// s_barrier intrinsic is IntrNoMem -- nothing but the scheduler's habits keeps the LDS reads of the next slab below it.
+// (ISA check: no extra vmcnt wait appears in the loop, the counted waits stay vmcnt(NDMA) / vmcnt(0).)
+__device__ __forceinline__ void glds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
@@ -1373,7 +1382,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       for (int d = 0; d < pre; ++d) stage(d, d);
       if (nk >= D) glds_wait_vm<NDMA * (D - 1)>();   // slab 0 has landed, the rest of the prologue is on its way
       else glds_wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
+      glds_barrier();
     }
     int buf = 0, sbuf = D % (D + 1);   // buffer of slab s / of slab s + D
     for (int s = 0; s < nk; ++s) {
@@ -1442,7 +1451,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
       } else {
         if (s + 2 < nk) glds_wait_vm<NDMA>();
         else glds_wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
+        glds_barrier();
         buf = buf == D ? 0 : buf + 1;
         sbuf = sbuf == D ? 0 : sbuf + 1;
       }

@@ -831,6 +831,40 @@ def test_bf16_glds_gemm(bf16_mode, M, N, K, tb):
           name="bf16 glds gated")
 
 
+@pytest.mark.parametrize("K", [16, 32, 48, 64])
+@pytest.mark.parametrize("tb", [False, True])
+def test_bf16_glds_short_k(bf16_mode, K, tb):
+    """the three-buffer loop of the bf16 direct-to-LDS kernel at 1 .. 4 slabs (prologue shorter than / equal to / longer than
+    its depth; NT plain = three buffers, gated = two), with a ragged last row tile; the NN arm lands on the thin-K kernel"""
+    M, N = 57344 + 40, 128
+    a, g = rnd(M, K), rnd(M, K, seed=5)
+    b = rnd(N, K, seed=1) if tb else rnd(K, N, seed=1)
+    out = hip.gemm(a.to(DEV), b.to(DEV), trans_b=tb)
+    v = hip.lib().indm_igemm_last_variant().decode()
+    assert ("glds" in v and "bf16" in v) if tb else "thin_k" in v, v   # (NN with K <= 128 is the thin-K kernel's, also in bf16 mode)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)])
+    close(out[rows], _emu.gemm(_r16(a[rows]).double(), _r16(b).double(), trans_b=tb), rtol=1e-5, atol=1e-5 * math.sqrt(K),
+          name="bf16 glds short K")
+    out = hip.gemm(a.to(DEV), b.to(DEV), trans_b=tb, gate=g.to(DEV))
+    close(out[rows], _emu.gemm(_r16(a[rows] * g[rows]).double(), _r16(b).double(), trans_b=tb), rtol=1e-5,
+          atol=1e-5 * math.sqrt(K), name="bf16 glds short K gated")
+
+
+def test_bf16_glds_conv_short_k(bf16_mode):
+    """16-channel convolutions on the same loop: 1 x 1 (one slab), 3 x 3 (nine slabs, one tap each), forward and data-grad"""
+    for k in (1, 3):
+        x, w = rnd(64, 32, 32, 16), rnd(k, k, 16, 128, seed=1, scale=0.2)
+        out = hip.conv2d(x.to(DEV), w.to(DEV), pad=k // 2)
+        imgs = [0, 63]
+        close(out[imgs], _emu.conv2d(_r16(x[imgs]).double(), _r16(w).double(), pad=k // 2), rtol=1e-5, atol=1e-4,
+              name=f"bf16 glds conv {k}x{k} 16 ch")
+        wd = rnd(k, k, 128, 16, seed=2, scale=0.2)
+        dy = rnd(64, 32, 32, 16, seed=4)
+        out = hip.conv2d_dgrad(dy.to(DEV), wd.to(DEV), (32, 32), pad=k // 2)
+        close(out[imgs], _emu.conv2d_dgrad(_r16(dy[imgs]).double(), _r16(wd).double(), (32, 32), pad=k // 2), rtol=1e-5,
+              atol=1e-4, name=f"bf16 glds dgrad {k}x{k} 16 ch")
+
+
 def test_bf16_glds_conv(bf16_mode):
     x, w = rnd(64, 32, 32, 128), rnd(3, 3, 128, 128, seed=1, scale=0.1)
     out = hip.conv2d(x.to(DEV), w.to(DEV))
