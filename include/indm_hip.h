@@ -84,6 +84,16 @@ int indm_conv3x3_thin_f32(const float* x, const float* w, float* y, int Nimg, in
 int indm_conv3x3_thin_bf16(const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout, int sign,
                           float alpha, const float* bias, const float* bias2, const float* R, float beta, void* stream);
 
+/* The same convolution with the flow's Sin activation (the g-net's first level, LopConv2d -> Sin: lipschitz.py:321-369,
+ * layers/base/activations.py:7-12) as its epilogue:
+ * a = sin(2 pi v) / (2 pi), d = cos(2 pi v), v = conv_sign(x, w) + bias[co] + bias2[n][co] (not written).  Bit-identical to
+ * indm_conv3x3_thin_* followed by indm_sincos_act_fwd_f32.  Returns 1 (not an error) when the geometry is not covered
+ * (needs C = 3 or 12, W = 16 or 32, Cout % 128 == 0, pixels % 32 == 0): the caller then runs the two steps. */
+int indm_conv3x3_thin_act_f32(const float* x, const float* w, float* a, float* d, int Nimg, int H, int W, int C, int Cout,
+                              int sign, const float* bias, const float* bias2, void* stream);
+int indm_conv3x3_thin_act_bf16(const float* x, const float* w, float* a, float* d, int Nimg, int H, int W, int C, int Cout,
+                               int sign, const float* bias, const float* bias2, void* stream);
+
 /* Name of the kernel variant this thread's last dense launch (gemm / conv2d_*) was dispatched to, e.g.
  * "glds256x128,gated", "big256x256", "thin128x128", "128x32": bench.py labels its live per-kernel timings with it. */
 const char* indm_igemm_last_variant(void);

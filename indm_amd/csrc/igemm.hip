@@ -1901,11 +1901,12 @@ INDM_API const char* indm_igemm_last_variant(void) { return last_variant; }
 // Returns 1 when the geometry is not covered (the caller then takes the tap_spread + GEMM route).
 static int conv3x3_thin_impl(int bf16, const float* x, const float* w, float* y, int Nimg, int H, int W, int C, int Cout,
                              int sign, float alpha, const float* bias, const float* bias2, const float* R,
-                             float beta, void* stream) {
+                             float beta, void* stream, float* act_d = nullptr) {
   if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return INDM_E_SHAPE;
   if (Nimg == 0) return INDM_OK;
   ThinGemmArgs t = {};
   t.bf16 = bf16;
+  t.act_d = act_d;
   t.B = w; t.C = y; t.M = Nimg * H * W; t.N = Cout; t.K = 9 * C;
   t.ldb = Cout; t.ldc = Cout; t.batch = 1; t.alpha = alpha; t.beta = beta; t.bias = bias; t.bias2 = bias2; t.rpg = H * W;
   t.R = R; t.ldr = Cout; t.X = x; t.cH = H; t.cW = W; t.cC = C; t.csign = sign;
@@ -1924,6 +1925,21 @@ INDM_API int indm_conv3x3_thin_bf16(const float* x, const float* w, float* y, in
                                     int sign, float alpha, const float* bias, const float* bias2, const float* R,
                                     float beta, void* stream) {
   return conv3x3_thin_impl(1, x, w, y, Nimg, H, W, C, Cout, sign, alpha, bias, bias2, R, beta, stream);
+}
+
+// the same convolution with the flow's Sin activation as its epilogue (iresblock.py's g-net: conv1 -> Sin): a = sin(2 pi v) / (2 pi),
+// d = cos(2 pi v), v = conv_sign(x, w) + bias[co] + bias2[n][co] -- v itself is not written.  Bit-identical to
+// indm_conv3x3_thin_* followed by indm_sincos_act_fwd_f32.  Returns 1 (not an error) when the geometry is not covered by the
+// row-fragment kernel (C = 3 / 12, W = 16 / 32, Cout % 128 == 0, pixels % 32 == 0): the caller then runs the two steps.
+INDM_API int indm_conv3x3_thin_act_f32(const float* x, const float* w, float* a, float* d, int Nimg, int H, int W, int C, int Cout,
+                                       int sign, const float* bias, const float* bias2, void* stream) {
+  if (!a || !d) return INDM_E_ARG;
+  return conv3x3_thin_impl(0, x, w, a, Nimg, H, W, C, Cout, sign, 1.0f, bias, bias2, nullptr, 0.0f, stream, d);
+}
+INDM_API int indm_conv3x3_thin_act_bf16(const float* x, const float* w, float* a, float* d, int Nimg, int H, int W, int C, int Cout,
+                                        int sign, const float* bias, const float* bias2, void* stream) {
+  if (!a || !d) return INDM_E_ARG;
+  return conv3x3_thin_impl(1, x, w, a, Nimg, H, W, C, Cout, sign, 1.0f, bias, bias2, nullptr, 0.0f, stream, d);
 }
 
 // C[b] = alpha * (opA(A[b] .* gateA[b]) * opB(B[b]) + bias[n] + bias2[m/rpg][n]) + beta * R[b]   (gateA optional)

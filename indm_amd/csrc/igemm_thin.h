@@ -29,6 +29,9 @@ struct ThinGemmArgs {
   // multiplied on the exact fp32 MFMA -- products of bf16 values are exact in fp32, so the result equals a bf16 MFMA's.
   // (These kernels are HBM-bound either way.)
   int bf16;
+  // im2col convolution only: non-NULL -> the Sin activation as the epilogue: C receives a = sin(2 pi v) / (2 pi), act_d receives
+  // d = cos(2 pi v) (both [M, ldc]), v = the convolution + biases, which is not written (alpha must be 1, no residual)
+  float* act_d;
   // experiment knobs of the im2col kernel (INDM_THIN_TUNE, tools/kflat_probe.py): bits 0-7 start delay of every second
   // workgroup in units of 64 cycles x 16, bit 8 non-temporal stores, bit 9 uncounted waits, bits 10-11 workgroups per CU - 1
   int tune;

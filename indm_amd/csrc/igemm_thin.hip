@@ -9,6 +9,10 @@
 #pragma clang diagnostic ignored "-Winline-asm"   // M0 clobber declared on the copy helper (see igemm.hip)
 
 namespace {
+// (the literals of elementwise.hip: the fused Sin epilogue must round like indm_sincos_act_fwd_f32)
+constexpr float TWO_PI = 6.283185307179586f;
+constexpr float INV_TWO_PI = 0.15915494309189535f;
+
 template <bool ON>
 __device__ __forceinline__ float rb16(float x) {
   if constexpr (ON) return (float)(__bf16)x;
@@ -541,8 +545,12 @@ constexpr int TR_LDW = TK_TN + 4;   // weight slice rows: [28 VW][128 + 4]
 // them in the natural k order (k = VW u + i), so the weight rows are read as they lie in memory.  NWV waves per workgroup
 // share one weight slice ([28 VW][128] floats: 15 KB / 59 KB) and nothing else.
 // UNIT: alpha == 1 (x * 1.0f == x: the multiply is dropped; every call of the flow); JB: 32-column blocks per MFMA group
-template <int VW, int NWV, bool BF16, bool UNIT, int JB, bool COAL = false>
-__global__ __launch_bounds__(NWV * 64, (VW == 1 ? 4 : 2)) void thin_conv_rows_kernel(ThinGemmArgs p) {
+// ACT (round 5): the Sin activation of the flow's g-net as this kernel's epilogue -- C receives a = sin(2 pi v) / (2 pi),
+// p.act_d receives d = cos(2 pi v), v = the convolution + bias (never written): the same `sincosf(TWO_PI * v)` /
+// `s * INV_TWO_PI` expressions as indm_sincos_act_fwd_f32 (bit-identical), one 268 MB write and one 268 MB read less per
+// g-pass at batch 128.  The conversion work (~60 VALU per element) runs next to the stores of a write-bound kernel.
+template <int VW, int NWV, bool BF16, bool UNIT, int JB, bool COAL = false, bool ACT = false>
+__global__ __launch_bounds__(NWV * 64, (VW == 1 ? (ACT ? 3 : 4) : 2)) void thin_conv_rows_kernel(ThinGemmArgs p) {   // (ACT: sincosf spills 14 registers under 128)
   __shared__ __attribute__((aligned(16))) float wsm[28 * VW * TR_LDW];
   __shared__ __attribute__((aligned(16))) float bsm[NWV * TK_TN];   // per wave: bias[n] + bias2[image][n] of its current image
   // COAL: a 32 x 32 block leaves through a per-wave LDS transpose (four ds_write_b128 + four ds_read_b128, no workgroup
@@ -678,6 +686,13 @@ __global__ __launch_bounds__(NWV * 64, (VW == 1 ? 4 : 2)) void thin_conv_rows_ke
           const float4 bq = *(const float4*)(bl + (j0 + j) * 32 + 8 * a);
           float4 v = make_float4(acc[j][4 * a] + bq.x, acc[j][4 * a + 1] + bq.y, acc[j][4 * a + 2] + bq.z, acc[j][4 * a + 3] + bq.w);
           if constexpr (!UNIT) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
+          if constexpr (ACT) {   // (a, d) = Sin(v); the cosines wait in the accumulator registers for their turn to leave
+            float sn, cs;
+            sincosf(TWO_PI * v.x, &sn, &cs); v.x = sn * INV_TWO_PI; acc[j][4 * a] = cs;
+            sincosf(TWO_PI * v.y, &sn, &cs); v.y = sn * INV_TWO_PI; acc[j][4 * a + 1] = cs;
+            sincosf(TWO_PI * v.z, &sn, &cs); v.z = sn * INV_TWO_PI; acc[j][4 * a + 2] = cs;
+            sincosf(TWO_PI * v.w, &sn, &cs); v.w = sn * INV_TWO_PI; acc[j][4 * a + 3] = cs;
+          }
           if constexpr (COAL) *(float4*)(tsm + (wave * 32 + l31) * 36 + 8 * a + 4 * lhi) = v;
           else *(float4*)(crow + (j0 + j) * 32 + 8 * a) = v;
         }
@@ -693,6 +708,29 @@ __global__ __launch_bounds__(NWV * 64, (VW == 1 ? 4 : 2)) void thin_conv_rows_ke
           }
         __builtin_amdgcn_wave_barrier();
       }
+      if constexpr (ACT) {   // the cosine block, the same way
+        float* __restrict__ Dout = p.act_d;
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const float4 v = make_float4(acc[j][4 * a], acc[j][4 * a + 1], acc[j][4 * a + 2], acc[j][4 * a + 3]);
+            if constexpr (COAL) *(float4*)(tsm + (wave * 32 + l31) * 36 + 8 * a + 4 * lhi) = v;
+            else *(float4*)((char*)Dout + ((char*)crow - (char*)Cout) + ((j0 + j) * 32 + 8 * a) * 4) = v;
+          }
+        if constexpr (COAL) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int row = (lane >> 3) + 8 * t;
+              const float4 v = *(const float4*)(tsm + (wave * 32 + row) * 36 + 4 * (lane & 7));
+              *(float4*)((char*)Dout + ((unsigned)(rb * 32 + row) * (unsigned)p.ldc + (unsigned)(n0 + (j0 + j) * 32 + 4 * (lane & 7))) * 4u) = v;
+            }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
     }
   }
 }
@@ -707,6 +745,11 @@ int launch_thin_conv_rows(const ThinGemmArgs& a, int groups, int tiles_n, hipStr
   // at 16 x 16, 153 / 150 us at 32 x 32): it keeps the direct stores.  INDM_THIN_TUNE bit 15 flips the choice (tools/kflat_probe.py).
   constexpr bool CO = VW == 1;
   const bool flip = (a.tune >> 15) & 1;
+  if (a.act_d) {   // (unit alpha: checked by the caller)
+    if (a.bf16) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, true, 1, CO, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, false, true, 1, CO, true>), grid, blk, 0, st, a);
+    return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+  }
   if (a.bf16) {
     if (unit) hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, true, 1, CO>), grid, blk, 0, st, a);
     else hipLaunchKernelGGL((thin_conv_rows_kernel<VW, NWV, true, false, 1, CO>), grid, blk, 0, st, a);
@@ -1212,13 +1255,15 @@ int indm_thin_conv3x3(const ThinGemmArgs& a_in, hipStream_t st) {
     const int nwv = 4;
     // C = 3: 88 VGPRs, 17 KB of LDS -> four workgroups per CU; C = 12: the 14 float4 units of a lane are 56 registers (~160 in
     // all; forced under 128 hipcc spills 13 - 90 of them depending on the loop shape) and the weight slice is 59 KB -> two
-    if (!per_cu) per_cu = C == 3 ? 4 : 2;
+    if (!per_cu) per_cu = C == 3 ? (a.act_d ? 3 : 4) : 2;   // (the Sin epilogue: 144 VGPRs)
     int groups = 256 * per_cu / tiles_n;    // each workgroup walks its share of the image rows
     const int rgroups = cdiv(a.M / 32, nwv);
     if (groups > rgroups) groups = rgroups;
     if (groups < 1) groups = 1;
+    if (a.act_d && (a.alpha != 1.0f || !al16(a.act_d))) return THIN_NA;
     return C == 3 ? launch_thin_conv_rows<1, 4>(a, groups, tiles_n, st) : launch_thin_conv_rows<4, 4>(a, groups, tiles_n, st);
   }
+  if (a.act_d) return THIN_NA;   // only the row-fragment kernel has the activation epilogue
   if (C <= 3 && W <= 128 && (128 % W) == 0 && ((H * W) % 128) == 0 && (a.M % 128) == 0 && (!a.bias2 || !(a.rpg & 7))) {
     int groups = 512 / tiles_n;  // two blocks per CU (the element tables cost registers)
     if ((a.tune >> 10) & 3) groups = 256 * ((a.tune >> 10) & 3) / tiles_n;

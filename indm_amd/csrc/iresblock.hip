@@ -7,6 +7,7 @@
 //
 // Reference: flows/resflow/layers/iresblock.py:14-174 (forward :60-76, _logdetgrad :90-174, estimators :253-273,
 // _inverse_fixed_point :78-88).
+#include <cstdlib>
 #include "indm_common.h"
 
 #pragma GCC visibility push(default)
@@ -71,6 +72,13 @@ struct Ctx {
     auto f = bf16 ? indm_conv3x3_thin_bf16 : indm_conv3x3_thin_f32;
     return f(x, w2d, y, N, H, W, C, Cw, sign, 1.0f, bias, nullptr, nullptr, 1.0f, st);
   }
+  // conv + Sin in one launch; 1 = geometry not covered (or no gate output wanted)
+  int thin_act(const float* x, const float* w2d, float* a, float* d, const float* bias) const {
+    static const bool on = !getenv("INDM_GPASS_FUSED") || atoi(getenv("INDM_GPASS_FUSED")) != 0;   // 0: the two-step form (A/B)
+    if (!d || !on) return 1;
+    auto f = bf16 ? indm_conv3x3_thin_act_bf16 : indm_conv3x3_thin_act_f32;
+    return f(x, w2d, a, d, N, H, W, C, Cw, -1, bias, nullptr, st);
+  }
   int chain(const float* t3, const float* d2, const float* W2T, const void* W2Tp, const float* d1, const float* panel,
             float* P, float* t2) const {
     const int J = 9 * C;
@@ -106,8 +114,14 @@ static int g_pass(const Ctx& c, int preact, const float* x, const float* cb, con
     TRY(indm_sincos_act_fwd_f32(x, a0, d0, nC, c.st));
     in = a0;
   }
-  TRY(c.thin(in, W1, p, -1, b1));                                                   // p1 = conv(a0, W1) + b1
-  TRY(indm_sincos_act_fwd_f32(p, a1, d1, nW, c.st));
+  // (a1, d1) = Sin(conv(a0, W1) + b1): one kernel where the row-fragment thin convolution covers the geometry (p1 never
+  // written), else the convolution and the activation pass; same values either way
+  const int fused = c.thin_act(in, W1, a1, d1, b1);
+  if (fused < 0) return fused;
+  if (fused == 1) {
+    TRY(c.thin(in, W1, p, -1, b1));                                                 // p1 = conv(a0, W1) + b1
+    TRY(indm_sincos_act_fwd_f32(p, a1, d1, nW, c.st));
+  }
   TRY(c.gemm(a1, nullptr, W2T, p, (int)c.M, c.Cw, c.Cw, 0, 1, c.Cw, c.Cw, b2, cb, c.H * c.W));   // p2 = a1 W2 + b2 + cb[n]
   TRY(indm_sincos_act_fwd_f32(p, a2, d2, nW, c.st));
   TRY(c.gemm(a2, nullptr, W3ct, Pn, (int)c.M, 9 * c.C, c.Cw, 0, 0, c.Cw, 9 * c.C, nullptr, nullptr, 1));   // skinny-output conv: GEMM + 9-tap gather

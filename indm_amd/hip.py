@@ -56,6 +56,8 @@ _SIGS = {
     "indm_igemm_last_variant": [],
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_conv3x3_thin_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
+    "indm_conv3x3_thin_act_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "indm_conv3x3_thin_act_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
     "indm_sincos_act_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "indm_attn_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
@@ -455,6 +457,23 @@ def prepack_weights(ws):
 
 def _skinny(kh, kw, stride, pad, c_small, c_wide):
     return kh == 3 and kw == 3 and stride == 1 and pad == 1 and c_small <= 16 and c_wide >= 64
+
+
+def conv3x3_thin_act(x, w2d, sign=-1, bias=None, bias2=None):
+    """(a, d) = Sin(conv3x3_thin(x, w2d, sign) + bias + bias2) in ONE launch (the pre-activation is never written): the first
+    level of the flow's g-net.  Bit-identical to conv3x3_thin followed by sincos_fwd.  None when the row-fragment kernel does
+    not cover the geometry: the caller runs the two steps."""
+    N, H, W, C = x.shape
+    Co = w2d.shape[1]
+    a = torch.empty((N, H, W, Co), dtype=torch.float32, device=x.device)
+    d = torch.empty_like(a)
+    with _timed("A_CONV3", "B_ROW", N * H * W, Co, 9 * C, nbytes=4 * (x.numel() + w2d.numel() + 2 * a.numel())):
+        st = _dense("conv3x3_thin_act")(_ptr(x), _ptr(w2d), _ptr(a), _ptr(d), N, H, W, C, Co, sign, _ptr(bias), _ptr(bias2),
+                                        _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_conv3x3_thin_act_f32")
+    return a, d
 
 
 def tap_gather(P, bias, sign, alpha=1.0):

@@ -59,6 +59,10 @@ def conv3x3_thin(x, w2d, sign, alpha=1.0, bias=None, bias2=None, res=None, beta=
     return gemm(xcol, w2d, alpha=alpha, bias=bias, bias2=bias2, rows_per_group=H * W, res=r, beta=beta).view(N, H, W, -1)
 
 
+def conv3x3_thin_act(x, w2d, sign=-1, bias=None, bias2=None):
+    return sincos_fwd(conv3x3_thin(x, w2d, sign, 1.0, bias, bias2))
+
+
 def tap_spread(y, sign, alpha=1.0):
     N, H, W, C = y.shape
     yp = F.pad(y, (0, 0, 1, 1, 1, 1))

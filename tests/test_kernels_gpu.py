@@ -194,6 +194,36 @@ def test_wgrad_gemm_big_tile_splitk(M, N, K):
     close(out, ref, rtol=1e-5, atol=3e-3, name="big wgrad gated")
 
 
+@pytest.mark.parametrize("N,H,W,C,Co", [(5, 32, 32, 3, 512), (4, 16, 16, 12, 512), (33, 32, 32, 3, 256), (7, 16, 16, 12, 384),
+                                        (2, 32, 32, 12, 128)])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_conv3x3_thin_act_equals_the_two_steps(N, H, W, C, Co, mode):
+    """conv + Sin in one launch (the g-net's first level inside the block drivers): the pre-activation is never written and
+    (a, d) are BIT-identical to conv3x3_thin followed by sincos_fwd, with a bias, a per-image bias, both, neither; fp32 and
+    bf16-rounded operands; against the fp64 reference within the convolution's tolerance"""
+    hip.set_compute_dtype(mode)
+    try:
+        x, w = rnd(N, H, W, C, seed=3), rnd(9 * C, Co, seed=4, scale=0.3)
+        bias, bias2 = rnd(Co, seed=5), rnd(N, Co, seed=6)
+        for b, b2 in ((None, None), (bias, None), (bias, bias2), (None, bias2)):
+            bd = b.to(DEV) if b is not None else None
+            b2d = b2.to(DEV) if b2 is not None else None
+            out = hip.conv3x3_thin_act(x.to(DEV), w.to(DEV), -1, bd, b2d)
+            assert out is not None, "geometry should be covered"
+            p = hip.conv3x3_thin(x.to(DEV), w.to(DEV), -1, 1.0, bd, b2d)
+            a, d = hip.sincos_fwd(p)
+            assert torch.equal(out[0], a) and torch.equal(out[1], d)
+        if mode == "f32":
+            ra, rd = _emu.conv3x3_thin_act(x.double(), w.double(), -1, bias.double(), bias2.double())
+            fa, fd = hip.conv3x3_thin_act(x.to(DEV), w.to(DEV), -1, bias.to(DEV), bias2.to(DEV))
+            close(fa, ra, rtol=1e-5, atol=1e-4, name="conv + Sin: a")
+            close(fd, rd, rtol=1e-5, atol=2e-3, name="conv + Sin: d")   # (d/dv cos(2 pi v) = 2 pi: the conv's 1e-4 x 2 pi, rounded up)
+    finally:
+        hip.set_compute_dtype("f32")
+    # not covered: 64-pixel-wide images, a residual-free call with 48 channels -> None, the caller runs the two steps
+    assert hip.conv3x3_thin_act(rnd(2, 64, 64, 3).to(DEV), rnd(27, 512).to(DEV)) is None
+
+
 # ---- "bf16 compute / fp32 accumulate" mode (BASELINE configs #3-#5) -----------------------------------------------
 def _r16(t):
     return t.bfloat16().float()
