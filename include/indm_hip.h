@@ -69,6 +69,14 @@ int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, 
                           int KH, int KW, int pad_t, int in_dil, int OH, int OW, float alpha, const float* R,
                           float beta, float* ws, long ws_floats, void* stream);
 
+/* (a, d) = Sin(A B^T + bias[n] + bias2[m / rows_per_group][n]) in one launch: the second level of the residual flow's g-net
+ * (1x1 LopConv2d / LopLinear -> Sin: lipschitz.py:321-369, layers/base/activations.py:7-12), the pre-activation never written.
+ * A [M, K] row-major (lda), B stored [N, K] (ldb), a and d [M, N] (ldc).  Bit-identical to indm_gemm_f32 (transB = 1) followed by
+ * indm_sincos_act_fwd_f32.  Returns 1 (not an error) when the problem is not the direct-to-LDS kernel's (M >= 1024, N >= 64,
+ * K % 16 == 0, at least 224 tiles of 256 x 128, 16-byte aligned operands): the caller then runs the two steps. */
+int indm_gemm_sin_f32(const float* A, const float* B, float* a, float* d, int M, int N, int K, long lda, long ldb, long ldc,
+                      const float* bias, const float* bias2, int rows_per_group, void* stream);
+
 /* dw[kh,kw,ci,co] = alpha * sum_pixels x * dy (+ beta*R): weight gradient of the convolution (autograd of
  * F.conv2d); the pixel reduction is split-K into ws. */
 int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout,

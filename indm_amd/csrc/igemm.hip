@@ -63,7 +63,11 @@ struct IgemmParams {
   int ow_sh, ohw_sh;                 // log2(OW), log2(OH*OW) when both are powers of two, else -1
   int a_buf;                         // A_CONV on the direct-to-LDS kernel: buffer-addressed copies (dma_buffer)
   int bf16;                          // MFMA inputs rounded to bf16 (RNE), fp32 accumulate (BASELINE configs #3-#5)
+  float* act_d;                      // Sin epilogue (indm_gemm_sin_f32): C receives sin(2 pi v) / (2 pi), act_d cos(2 pi v) ([M, ldc])
 };
+// (the literals of elementwise.hip: the fused Sin epilogue must round like indm_sincos_act_fwd_f32)
+constexpr float SIN_TWO_PI = 6.283185307179586f;
+constexpr float SIN_INV_TWO_PI = 0.15915494309189535f;
 
 // name of the kernel variant the last launch of this thread went to (bench.py labels its live timings with it)
 thread_local const char* last_variant = "";
@@ -281,7 +285,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // Written as `if (m < M) { v += bias2[..]; v += beta * R[..]; store }` per element, every one of those loads became a branch
 // with `s_waitcnt vmcnt(0)` behind it (profiles/r04_isa_serial_load_census.txt): 32 memory latencies per block, one after the
 // other.  Same operations in the same order per element (R may alias C: a lane reads exactly the elements it then writes).
-template <class Acc>
+template <class Acc, bool ACT = false>
 __device__ __forceinline__ void epilogue_block(const IgemmParams& p, const Acc& acc, float* C, long ldc, const float* R,
                                                bool partial, int mbase, int n, int lhi) {
   __builtin_amdgcn_sched_barrier(0);   // one block at a time: hipcc otherwise hoists every block's loads to the top and spills
@@ -320,6 +324,19 @@ __device__ __forceinline__ void epilogue_block(const IgemmParams& p, const Acc& 
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] += p.beta * t[r];
     }
+  }
+  if constexpr (ACT) {   // (a, d) = Sin(v): v is what the plain epilogue would have written, so both outputs equal the two-step form's
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      float sn, cs;
+      sincosf(SIN_TWO_PI * v[r], &sn, &cs);
+      if ((ok >> r) & 1) {
+        C[(long)m * ldc + n] = sn * SIN_INV_TWO_PI;
+        p.act_d[(long)m * ldc + n] = cs;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -1065,7 +1082,9 @@ __device__ __forceinline__ void glds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false>
+// ACT (round 5): the flow's Sin activation as the epilogue (second level of the g-net, indm_gemm_sin_f32): every tile takes the
+// general epilogue, which ends in sincosf instead of the store of v.
+template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false, bool ACT = false>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
   static_assert(AM == A_ROW || AM == A_CONV || AM == A_COL || AM == A_WGRAD,
                 "A_ROW / A_CONV: k-contiguous; A_COL / A_WGRAD: row-contiguous ([16 k][256 m] image)");
@@ -1483,7 +1502,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   float* C = partial ? p.ws + ((long)z * p.M) * p.N : p.C + (long)bz * p.sC;
   const long ldc = partial ? p.N : p.ldc;
   const float* R = (!partial && p.R) ? p.R + (long)bz * p.sR : nullptr;
-  if (m0 + TM <= p.M && n0 + TN <= p.N && !R && (partial || !p.bias2)) {
+  if (!ACT && m0 + TM <= p.M && n0 + TN <= p.N && !R && (partial || !p.bias2)) {
     // full tile, no per-element reads: no bounds tests, one running row pointer per 32 x 32 block (the epilogue's
     // integer work is ~40 % of the kernel's non-MFMA VALU instructions, none of which overlap with the MFMAs)
     const float alpha = partial ? 1.f : p.alpha;
@@ -1497,6 +1516,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) cp[(long)((r & 3) + 8 * (r >> 2)) * ldc] = (acc[i][j][r] + bn) * alpha;
       }
+    }
+    return;
+  }
+  if constexpr (ACT) {
+    // ONE copy of the 16 inlined sincosf per kernel: the four 32 x 32 blocks go through a ROLLED loop, each selected into a
+    // fixed register block with uniform conditions.  (Left to `#pragma unroll`, hipcc rolled the j loop on its own, indexed
+    // acc[i][j] dynamically and moved all 64 accumulators to scratch -- written back every slab of the main loop.)
+    static_assert(RM == 2 && RN == 2, "written for the 8-wave tile");
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {
+      f32x16 v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = b == 0 ? acc[0][0][r] : b == 1 ? acc[0][1][r] : b == 2 ? acc[1][0][r] : acc[1][1][r];
+      epilogue_block<f32x16, true>(p, v, C, ldc, R, partial, m0 + mw + (b >> 1) * 32, n0 + nw + (b & 1) * 32 + l31, lhi);
     }
     return;
   }
@@ -1533,6 +1566,16 @@ int launch_glds_t(const IgemmParams& p, hipStream_t st) {
 
 template <int AM, int BMODE, bool HAS_G, int NW>
 int launch_glds(const IgemmParams& p, hipStream_t st) {
+  if constexpr (AM == A_ROW && BMODE == B_COL && !HAS_G && NW == 8) {
+    if (p.act_d) {   // (fp32, no split-K: checked by the caller)
+      constexpr size_t bytes = 2 * (256 * BK + 128 * BK) * sizeof(float);
+      if (indm_lds_optin<igemm_glds_kernel<A_ROW, B_COL, false, 8, false, true>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+      last_variant = "glds256x128,sin";
+      hipLaunchKernelGGL((igemm_glds_kernel<A_ROW, B_COL, false, 8, false, true>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch),
+                         dim3(512), bytes, st, p);
+      return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+    }
+  }
   return p.bf16 ? launch_glds_t<AM, BMODE, HAS_G, NW, true>(p, st) : launch_glds_t<AM, BMODE, HAS_G, NW, false>(p, st);
 }
 
@@ -1616,10 +1659,12 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     const bool big256 = !p.G && p.K >= 1024 && big_tile_n(p) == 256;
     if ((!big256 || p.bf16) && p.splitk == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.M >= 1024 &&
         p.N >= 64 && (BMODE == B_COL || !(p.N & 3)) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224) {
+      if (p.act_d && (p.G || BMODE != B_COL)) return 1;
       if (p.G) return launch_glds<A_ROW, BMODE, true, 8>(p, st);
       return launch_glds<A_ROW, BMODE, false, 8>(p, st);
     }
   }
+  if (p.act_d) return 1;   // the Sin epilogue exists on the NT direct-to-LDS kernel only: the caller runs the two steps
   if constexpr (AM == A_CONV && (BMODE == B_ROW || BMODE == B_DGRAD)) {
     // long convolutions (forward and data-grad): the same direct-to-LDS kernel on the implicit-GEMM A operand.
     // (Round 2 kept the data-grads that fill 256 x 256 tiles on the big-tile kernel, 118-123 TF; with the buffer-addressed
@@ -1727,7 +1772,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if ((p.R && (long)p.M * p.ldr >= (1L << 32)) || (p.bias2 && ((long)p.M / (p.rpg > 0 ? p.rpg : 1) + 1) * p.N >= (1L << 32)))
     return INDM_E_SHAPE;
   p.ws = ws;
-  if ((am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
+  if (!p.act_d && (am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
     // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip (bf16 mode: operands
     // rounded at the fragment read, exact fp32 MFMA)
     ThinGemmArgs t = {p.A, p.G, p.B, p.C, p.M, p.N, p.K, am == A_COL, bm == B_COL, p.lda, p.ldb, p.ldc, p.batch,
@@ -1969,6 +2014,24 @@ INDM_API int indm_gemm_f32(const float* A, const float* gateA, const float* B, f
                            const float* bias2, int rows_per_group, const float* R, long ldr,
                            long strideR, float beta, float* ws, long ws_floats, void* stream) {
   return gemm_f32_impl(0, A, gateA, B, C, M, N, K, transA, transB, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, bias, bias2, rows_per_group, R, ldr, strideR, beta, ws, ws_floats, stream);
+}
+// (a, d) = Sin(A B^T + bias[n] + bias2[m / rpg][n]): the g-net's second level (iresblock.py: Linear/1x1 LopConv -> Sin) in ONE
+// launch -- the pre-activation is never written.  A [M, K] row-major (lda), B stored [N, K] (ldb), a / d [M, N] (ldc).
+// Bit-identical to indm_gemm_f32 (transB = 1) followed by indm_sincos_act_fwd_f32.  Returns 1 (not an error) when the problem
+// is not the direct-to-LDS kernel's (M >= 1024, N >= 64, K % 16 == 0, >= 224 tiles of 256 x 128, 16-byte aligned operands).
+INDM_API int indm_gemm_sin_f32(const float* A, const float* B, float* a, float* d, int M, int N, int K, long lda, long ldb, long ldc,
+                               const float* bias, const float* bias2, int rows_per_group, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return INDM_E_SHAPE;
+  if (!a || !d) return INDM_E_ARG;
+  if ((long)M * ldc >= (1L << 32)) return 1;
+  IgemmParams p = {};
+  p.A = A; p.B = B; p.C = a; p.act_d = d; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.batch = 1;
+  p.alpha = 1.0f; p.beta = 0.0f; p.bias = bias; p.bias2 = bias2;
+  p.rpg = rows_per_group > 0 ? rows_per_group : 1;
+  p.a_vec = al16(A) && (lda % 4 == 0);
+  p.b_vec = al16(B) && (ldb % 4 == 0);
+  return run(p, A_ROW, B_COL, nullptr, 0, (hipStream_t)stream);
 }
 // same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
 INDM_API int indm_gemm_bf16(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,

@@ -53,6 +53,12 @@ static bool covered(int N, int H, int W, int C, int idim) {
     if (st_ != 0) return st_ < 0 ? st_ : INDM_E_SHAPE; /* a sub-launch that declines a covered geometry is a bug */ \
   } while (0)
 
+// INDM_GPASS_FUSED (A/B switch, read once): bit 0 conv + Sin, bit 1 GEMM + Sin in one launch each; default 3, 0 = the two-step forms
+static int gpass_fused() {
+  static const int v = getenv("INDM_GPASS_FUSED") ? atoi(getenv("INDM_GPASS_FUSED")) : 3;
+  return v;
+}
+
 struct Ctx {
   int N, H, W, C, Cw, bf16;
   long M;
@@ -74,8 +80,7 @@ struct Ctx {
   }
   // conv + Sin in one launch; 1 = geometry not covered (or no gate output wanted)
   int thin_act(const float* x, const float* w2d, float* a, float* d, const float* bias) const {
-    static const bool on = !getenv("INDM_GPASS_FUSED") || atoi(getenv("INDM_GPASS_FUSED")) != 0;   // 0: the two-step form (A/B)
-    if (!d || !on || (C > 3 && M < 8192)) return 1;   // (12 channels at 16 images: 21.7 us fused against 13.5 + 6.2)
+    if (!d || !(gpass_fused() & 1) || (C > 3 && M < 8192)) return 1;   // (12 channels at 16 images: 21.7 us fused against 13.5 + 6.2)
     auto f = bf16 ? indm_conv3x3_thin_act_bf16 : indm_conv3x3_thin_act_f32;
     return f(x, w2d, a, d, N, H, W, C, Cw, -1, bias, nullptr, st);
   }
@@ -122,8 +127,15 @@ static int g_pass(const Ctx& c, int preact, const float* x, const float* cb, con
     TRY(c.thin(in, W1, p, -1, b1));                                                 // p1 = conv(a0, W1) + b1
     TRY(indm_sincos_act_fwd_f32(p, a1, d1, nW, c.st));
   }
-  TRY(c.gemm(a1, nullptr, W2T, p, (int)c.M, c.Cw, c.Cw, 0, 1, c.Cw, c.Cw, b2, cb, c.H * c.W));   // p2 = a1 W2 + b2 + cb[n]
-  TRY(indm_sincos_act_fwd_f32(p, a2, d2, nW, c.st));
+  // (a2, d2) = Sin(a1 W2 + b2 + cb[n]): the GEMM's epilogue where the direct-to-LDS kernel takes the problem (fp32, gates wanted)
+  int fused2 = 1;
+  if (d2 && !c.bf16 && (gpass_fused() & 2))
+    fused2 = indm_gemm_sin_f32(a1, W2T, a2, d2, (int)c.M, c.Cw, c.Cw, c.Cw, c.Cw, c.Cw, b2, cb, c.H * c.W, c.st);
+  if (fused2 < 0) return fused2;
+  if (fused2 == 1) {
+    TRY(c.gemm(a1, nullptr, W2T, p, (int)c.M, c.Cw, c.Cw, 0, 1, c.Cw, c.Cw, b2, cb, c.H * c.W));   // p2 = a1 W2 + b2 + cb[n]
+    TRY(indm_sincos_act_fwd_f32(p, a2, d2, nW, c.st));
+  }
   TRY(c.gemm(a2, nullptr, W3ct, Pn, (int)c.M, 9 * c.C, c.Cw, 0, 0, c.Cw, 9 * c.C, nullptr, nullptr, 1));   // skinny-output conv: GEMM + 9-tap gather
   if (y_res)   // the block's output y = x + g in the gather's own pass (x + 1.0f * g: the same sum axpby would form)
     TRY(indm_tap_gather_acc_f32(Pn, b3, nullptr, g, x, y_res, 1.0f, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));

@@ -56,6 +56,7 @@ _SIGS = {
     "indm_igemm_last_variant": [],
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_conv3x3_thin_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
+    "indm_gemm_sin_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p, c_i, c_p],
     "indm_conv3x3_thin_act_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "indm_conv3x3_thin_act_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "indm_sincos_act_fwd_f32": [c_p, c_p, c_p, c_l, c_p],
@@ -457,6 +458,22 @@ def prepack_weights(ws):
 
 def _skinny(kh, kw, stride, pad, c_small, c_wide):
     return kh == 3 and kw == 3 and stride == 1 and pad == 1 and c_small <= 16 and c_wide >= 64
+
+
+def gemm_sin(a, b_nk, bias=None, bias2=None, rows_per_group=1):
+    """(s, c) = Sin(a @ b_nk^T + bias + bias2[row // rows_per_group]) in ONE launch (fp32; the pre-activation is never written):
+    the second level of the flow's g-net.  a [M, K], b_nk [N, K].  Bit-identical to gemm(trans_b=True) followed by sincos_fwd.
+    None when the direct-to-LDS kernel does not cover the problem: the caller runs the two steps."""
+    M, K = a.shape
+    N = b_nk.shape[0]
+    s = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    c = torch.empty_like(s)
+    st = lib().indm_gemm_sin_f32(_ptr(a), _ptr(b_nk), _ptr(s), _ptr(c), M, N, K, a.stride(0), b_nk.stride(0), N, _ptr(bias),
+                                 _ptr(bias2), rows_per_group, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_gemm_sin_f32")
+    return s, c
 
 
 def conv3x3_thin_act(x, w2d, sign=-1, bias=None, bias2=None):

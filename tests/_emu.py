@@ -59,6 +59,10 @@ def conv3x3_thin(x, w2d, sign, alpha=1.0, bias=None, bias2=None, res=None, beta=
     return gemm(xcol, w2d, alpha=alpha, bias=bias, bias2=bias2, rows_per_group=H * W, res=r, beta=beta).view(N, H, W, -1)
 
 
+def gemm_sin(a, b_nk, bias=None, bias2=None, rows_per_group=1):
+    return sincos_fwd(gemm(a, b_nk, trans_b=True, bias=bias, bias2=bias2, rows_per_group=rows_per_group))
+
+
 def conv3x3_thin_act(x, w2d, sign=-1, bias=None, bias2=None):
     return sincos_fwd(conv3x3_thin(x, w2d, sign, 1.0, bias, bias2))
 

@@ -224,6 +224,32 @@ def test_conv3x3_thin_act_equals_the_two_steps(N, H, W, C, Co, mode):
     assert hip.conv3x3_thin_act(rnd(2, 64, 64, 3).to(DEV), rnd(27, 512).to(DEV)) is None
 
 
+@pytest.mark.parametrize("M,N,K,rpg", [(57344, 512, 512, 1024), (57344 + 72, 128, 64, 8), (65536, 256, 48, 256)])
+def test_gemm_sin_equals_the_two_steps(M, N, K, rpg):
+    """GEMM + Sin in one launch (the g-net's second level inside the block drivers): (a, d) BIT-identical to gemm(trans_b) followed
+    by sincos_fwd -- bias, per-image bias, both, neither; a ragged last tile; a short K -- and within the GEMM's tolerance of the
+    fp64 reference; problems the direct-to-LDS kernel does not take return None"""
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+    bias, bias2 = rnd(N, seed=3), rnd((M + rpg - 1) // rpg, N, seed=4)
+    for bb, b2 in ((None, None), (bias, None), (bias, bias2), (None, bias2)):
+        bd = bb.to(DEV) if bb is not None else None
+        b2d = b2.to(DEV) if b2 is not None else None
+        out = hip.gemm_sin(a.to(DEV), b.to(DEV), bd, b2d, rpg)
+        assert out is not None, "problem should be covered"
+        assert hip.lib().indm_igemm_last_variant().decode() == "glds256x128,sin"
+        p = hip.gemm(a.to(DEV), b.to(DEV), trans_b=True, bias=bd, bias2=b2d, rows_per_group=rpg)
+        s, c = hip.sincos_fwd(p)
+        assert torch.equal(out[0], s) and torch.equal(out[1], c)
+    rows = torch.cat([torch.arange(0, 200), torch.arange(M - 200, M)])
+    rs, rc = _emu.sincos_fwd(_emu.gemm(a.double(), b.double(), trans_b=True, bias=bias.double(), bias2=bias2.double(),
+                                       rows_per_group=rpg))
+    fs, fc = hip.gemm_sin(a.to(DEV), b.to(DEV), bias.to(DEV), bias2.to(DEV), rpg)
+    close(fs[rows], rs[rows], rtol=1e-5, atol=1e-5 * math.sqrt(K), name="gemm + Sin: a")
+    close(fc[rows], rc[rows], rtol=1e-5, atol=1e-4 * math.sqrt(K), name="gemm + Sin: d")
+    assert hip.gemm_sin(rnd(512, 64).to(DEV), rnd(128, 64).to(DEV)) is None          # too few tiles
+    assert hip.gemm_sin(rnd(57344, 24).to(DEV), rnd(128, 24).to(DEV)) is None        # K % 16
+
+
 # ---- "bf16 compute / fp32 accumulate" mode (BASELINE configs #3-#5) -----------------------------------------------
 def _r16(t):
     return t.bfloat16().float()
