@@ -77,6 +77,17 @@ int indm_conv2d_dgrad_f32(const float* dy, const float* w, float* dx, int Nimg, 
 int indm_gemm_sin_f32(const float* A, const float* B, float* a, float* d, int M, int N, int K, long lda, long ldb, long ldc,
                       const float* bias, const float* bias2, int rows_per_group, void* stream);
 
+/* One Sin level of the hand-written iResBlock backward (the reverse of lipschitz.py:321-369 -> layers/base/activations.py:7-12
+ * inside iresblock.py:60-76) together with the GEMM that produces its incoming gradient: da = A B^T is NOT written,
+ *   dp = da*d - 4 pi^2 * a * (du*t),  dt = du*d (dt may be NULL),  seg[s][n] = sum of dp over the rows of segment s (seg may be
+ * NULL; else rows_per_seg % 64 == 0, M % rows_per_seg == 0 and ws >= indm_ires_bwd_act_ws_floats(M, N) floats).
+ * A [M, K] (lda), B stored [N, K] (ldb), du, d, a, t, dp, dt [M, N] contiguous.  Bit-identical to indm_gemm_f32 (transB = 1)
+ * followed by indm_ires_bwd_act_f32, segment sums included.  Returns 1 (not an error) when the direct-to-LDS kernel does not
+ * take the problem (see indm_gemm_sin_f32; also M % 64 == 0): the caller then runs the two steps. */
+int indm_gemm_ires_bwd_act_f32(const float* A, const float* B, const float* du, const float* d, const float* a, const float* t,
+                               float* dp, float* dt, float* seg, int M, int N, int K, long lda, long ldb, long rows_per_seg,
+                               float* ws, void* stream);
+
 /* dw[kh,kw,ci,co] = alpha * sum_pixels x * dy (+ beta*R): weight gradient of the convolution (autograd of
  * F.conv2d); the pixel reduction is split-K into ws. */
 int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout,

@@ -253,6 +253,13 @@ __global__ __launch_bounds__(256) void ires_seg_fold_kernel(const float* __restr
 
 INDM_API long indm_ires_bwd_act_ws_floats(long R, int C) { return ((R + IRES_CH - 1) / IRES_CH) * (long)C; }
 
+// the fold of the 64-row partial sums, for the GEMM that carries the pass as its epilogue (igemm.hip, not exported)
+int indm_ires_seg_fold(const float* part, float* seg, long nseg, int cps, int C, hipStream_t st) {
+  hipLaunchKernelGGL(ires_seg_fold_kernel, dim3(ew_grid(nseg * C, 256)), dim3(256), 0, st, part, seg, nseg, cps, C);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
 // da, du, d, a, t, dp (and dt_out if non-null): [R, C]; seg_out (if non-null): [R / rows_per_seg, C], which needs
 // rows_per_seg % 64 == 0 and ws of indm_ires_bwd_act_ws_floats(R, C) floats.
 INDM_API int indm_ires_bwd_act_f32(const float* da, const float* du, const float* d, const float* a, const float* t,

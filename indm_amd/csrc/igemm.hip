@@ -64,6 +64,11 @@ struct IgemmParams {
   int a_buf;                         // A_CONV on the direct-to-LDS kernel: buffer-addressed copies (dma_buffer)
   int bf16;                          // MFMA inputs rounded to bf16 (RNE), fp32 accumulate (BASELINE configs #3-#5)
   float* act_d;                      // Sin epilogue (indm_gemm_sin_f32): C receives sin(2 pi v) / (2 pi), act_d cos(2 pi v) ([M, ldc])
+  // Sin-level backward as the epilogue (indm_gemm_ires_bwd_act_f32; all [M, ldc]): with da = this GEMM's result (never written)
+  //   C = dp = da * d - 4 pi^2 * a * (du * t),   e_dt = du * d (optional),
+  //   e_part[(m / 64) * N + n] = sum of dp over the 64-row chunk in row order (optional; indm_ires_bwd_act_f32's partial sums)
+  const float *e_du, *e_d, *e_a, *e_t;
+  float *e_dt, *e_part;
 };
 // (the literals of elementwise.hip: the fused Sin epilogue must round like indm_sincos_act_fwd_f32)
 constexpr float SIN_TWO_PI = 6.283185307179586f;
@@ -342,6 +347,52 @@ __device__ __forceinline__ void epilogue_block(const IgemmParams& p, const Acc& 
   for (int r = 0; r < 16; ++r) {
     const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
     if ((ok >> r) & 1) C[(long)m * ldc + n] = v[r];
+  }
+}
+
+// One 32 x 32 block of indm_gemm_ires_bwd_act_f32's epilogue: `da` = the block's GEMM result (lane: column n, rows
+// mbase + 8 q + 4 lhi + e), the four operand tensors read at the same elements (16 loads in flight per quarter), dp / dt
+// written, and `run` = the column's running sum of dp over the rows so far IN ROW ORDER -- rows 8 q .. 8 q + 3 live in lane
+// half 0, 8 q + 4 .. 8 q + 7 in half 1, so the sum crosses the halves twice per quarter (ds_bpermute): the same additions
+// in the same order as ires_bwd_act_kernel's `s += g` over its 64-row chunk (bit-identical partial sums).
+__device__ __forceinline__ void epilogue_bwd_act_block(const IgemmParams& p, const f32x16& da, int mbase, int n, int lane,
+                                                       float& run) {
+  const float K = SIN_TWO_PI * SIN_TWO_PI;
+  const int lhi = lane >> 5;
+  const bool nok = n < p.N;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    __builtin_amdgcn_sched_barrier(0);   // one quarter's 16 loads at a time
+    float uu[4], dd[4], aa[4], tt[4], g[4];
+    bool ok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = mbase + 8 * q + 4 * lhi + e;
+      ok[e] = nok && m < p.M;
+      const unsigned o = ok[e] ? (unsigned)m * (unsigned)p.ldc + (unsigned)n : 0u;
+      uu[e] = p.e_du[o]; dd[e] = p.e_d[o]; aa[e] = p.e_a[o]; tt[e] = p.e_t[o];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = mbase + 8 * q + 4 * lhi + e;
+      g[e] = da[4 * q + e] * dd[e] - K * aa[e] * (uu[e] * tt[e]);
+      if (ok[e]) {
+        const unsigned o = (unsigned)m * (unsigned)p.ldc + (unsigned)n;
+        p.C[o] = g[e];
+        if (p.e_dt) p.e_dt[o] = uu[e] * dd[e];
+      }
+    }
+    if (p.e_part) {
+      float sa = run;                                    // meaningful in half 0: rows 8 q .. 8 q + 3
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sa = ok[e] ? sa + g[e] : sa;
+      const float from0 = __shfl_xor(sa, 32, 64);
+      float sb = lhi ? from0 : 0.f;                      // half 1 continues from half 0's sum: rows 8 q + 4 .. 8 q + 7
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sb = ok[e] ? sb + g[e] : sb;
+      const float from1 = __shfl_xor(sb, 32, 64);
+      run = lhi ? sb : from1;                            // both halves now hold the sum over rows .. 8 q + 7
+    }
   }
 }
 
@@ -1084,7 +1135,9 @@ __device__ __forceinline__ void glds_barrier() {
 
 // ACT (round 5): the flow's Sin activation as the epilogue (second level of the g-net, indm_gemm_sin_f32): every tile takes the
 // general epilogue, which ends in sincosf instead of the store of v.
-template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false, bool ACT = false>
+// ACT = 2: the Sin-level BACKWARD of the flow as the epilogue (indm_gemm_ires_bwd_act_f32, epilogue_bwd_act_block above): the
+// HBM-bound pass (four tensors read, two written per element) runs while the CU's other workgroup multiplies.
+template <int AM, int BMODE, bool HAS_G, int NW, bool BF16 = false, int ACT = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(IgemmParams p) {
   static_assert(AM == A_ROW || AM == A_CONV || AM == A_COL || AM == A_WGRAD,
                 "A_ROW / A_CONV: k-contiguous; A_COL / A_WGRAD: row-contiguous ([16 k][256 m] image)");
@@ -1502,7 +1555,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
   float* C = partial ? p.ws + ((long)z * p.M) * p.N : p.C + (long)bz * p.sC;
   const long ldc = partial ? p.N : p.ldc;
   const float* R = (!partial && p.R) ? p.R + (long)bz * p.sR : nullptr;
-  if (!ACT && m0 + TM <= p.M && n0 + TN <= p.N && !R && (partial || !p.bias2)) {
+  if (ACT == 0 && m0 + TM <= p.M && n0 + TN <= p.N && !R && (partial || !p.bias2)) {
     // full tile, no per-element reads: no bounds tests, one running row pointer per 32 x 32 block (the epilogue's
     // integer work is ~40 % of the kernel's non-MFMA VALU instructions, none of which overlap with the MFMAs)
     const float alpha = partial ? 1.f : p.alpha;
@@ -1519,7 +1572,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     }
     return;
   }
-  if constexpr (ACT) {
+  if constexpr (ACT == 2) {
+    static_assert(RM == 2 && RN == 2, "written for the 8-wave tile: a wave owns one 64-row chunk x 64 columns");
+    float run0 = 0.f, run1 = 0.f;   // running column sums of the two 32-column blocks over the wave's 64 rows
+#pragma unroll 1
+    for (int b = 0; b < 4; ++b) {   // (i = b >> 1, j = b & 1): rows 0..31 of both column blocks, then rows 32..63
+      f32x16 v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = b == 0 ? acc[0][0][r] : b == 1 ? acc[0][1][r] : b == 2 ? acc[1][0][r] : acc[1][1][r];
+      float run = (b & 1) ? run1 : run0;
+      epilogue_bwd_act_block(p, v, m0 + mw + (b >> 1) * 32, n0 + nw + (b & 1) * 32 + l31, lane, run);
+      if (b & 1) run1 = run; else run0 = run;
+    }
+    if (p.e_part && lhi == 0 && m0 + mw < p.M) {
+      const long chunk = (m0 + mw) >> 6;
+      const int n = n0 + nw + l31;
+      if (n < p.N) p.e_part[chunk * p.N + n] = run0;
+      if (n + 32 < p.N) p.e_part[chunk * p.N + n + 32] = run1;
+    }
+    return;
+  }
+  if constexpr (ACT == 1) {
     // ONE copy of the 16 inlined sincosf per kernel: the four 32 x 32 blocks go through a ROLLED loop, each selected into a
     // fixed register block with uniform conditions.  (Left to `#pragma unroll`, hipcc rolled the j loop on its own, indexed
     // acc[i][j] dynamically and moved all 64 accumulators to scratch -- written back every slab of the main loop.)
@@ -1567,11 +1640,19 @@ int launch_glds_t(const IgemmParams& p, hipStream_t st) {
 template <int AM, int BMODE, bool HAS_G, int NW>
 int launch_glds(const IgemmParams& p, hipStream_t st) {
   if constexpr (AM == A_ROW && BMODE == B_COL && !HAS_G && NW == 8) {
+    if (p.e_du) {   // (fp32, no split-K, no bias / residual: checked by the caller)
+      constexpr size_t bytes = 2 * (256 * BK + 128 * BK) * sizeof(float);
+      if (indm_lds_optin<igemm_glds_kernel<A_ROW, B_COL, false, 8, false, 2>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+      last_variant = "glds256x128,ires_bwd_act";
+      hipLaunchKernelGGL((igemm_glds_kernel<A_ROW, B_COL, false, 8, false, 2>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch),
+                         dim3(512), bytes, st, p);
+      return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+    }
     if (p.act_d) {   // (fp32, no split-K: checked by the caller)
       constexpr size_t bytes = 2 * (256 * BK + 128 * BK) * sizeof(float);
-      if (indm_lds_optin<igemm_glds_kernel<A_ROW, B_COL, false, 8, false, true>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+      if (indm_lds_optin<igemm_glds_kernel<A_ROW, B_COL, false, 8, false, 1>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
       last_variant = "glds256x128,sin";
-      hipLaunchKernelGGL((igemm_glds_kernel<A_ROW, B_COL, false, 8, false, true>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch),
+      hipLaunchKernelGGL((igemm_glds_kernel<A_ROW, B_COL, false, 8, false, 1>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch),
                          dim3(512), bytes, st, p);
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
     }
@@ -1659,12 +1740,12 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     const bool big256 = !p.G && p.K >= 1024 && big_tile_n(p) == 256;
     if ((!big256 || p.bf16) && p.splitk == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.M >= 1024 &&
         p.N >= 64 && (BMODE == B_COL || !(p.N & 3)) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224) {
-      if (p.act_d && (p.G || BMODE != B_COL)) return 1;
+      if ((p.act_d || p.e_du) && (p.G || BMODE != B_COL)) return 1;
       if (p.G) return launch_glds<A_ROW, BMODE, true, 8>(p, st);
       return launch_glds<A_ROW, BMODE, false, 8>(p, st);
     }
   }
-  if (p.act_d) return 1;   // the Sin epilogue exists on the NT direct-to-LDS kernel only: the caller runs the two steps
+  if (p.act_d || p.e_du) return 1;   // the fused epilogues exist on the NT direct-to-LDS kernel only: the caller runs the two steps
   if constexpr (AM == A_CONV && (BMODE == B_ROW || BMODE == B_DGRAD)) {
     // long convolutions (forward and data-grad): the same direct-to-LDS kernel on the implicit-GEMM A operand.
     // (Round 2 kept the data-grads that fill 256 x 256 tiles on the big-tile kernel, 118-123 TF; with the buffer-addressed
@@ -1772,7 +1853,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if ((p.R && (long)p.M * p.ldr >= (1L << 32)) || (p.bias2 && ((long)p.M / (p.rpg > 0 ? p.rpg : 1) + 1) * p.N >= (1L << 32)))
     return INDM_E_SHAPE;
   p.ws = ws;
-  if (!p.act_d && (am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
+  if (!p.act_d && !p.e_du && (am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
     // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip (bf16 mode: operands
     // rounded at the fragment read, exact fp32 MFMA)
     ThinGemmArgs t = {p.A, p.G, p.B, p.C, p.M, p.N, p.K, am == A_COL, bm == B_COL, p.lda, p.ldb, p.ldc, p.batch,
@@ -2032,6 +2113,31 @@ INDM_API int indm_gemm_sin_f32(const float* A, const float* B, float* a, float* 
   p.a_vec = al16(A) && (lda % 4 == 0);
   p.b_vec = al16(B) && (ldb % 4 == 0);
   return run(p, A_ROW, B_COL, nullptr, 0, (hipStream_t)stream);
+}
+// One Sin level of the hand-written iResBlock backward with its producing GEMM: da = A B^T is NOT written,
+//   dp = da * d - 4 pi^2 * a * (du * t),  dt = du * d (dt may be NULL),  seg[s][n] = sum of dp over the rows of segment s
+// (seg may be NULL; else rows_per_seg % 64 == 0 and ws >= indm_ires_bwd_act_ws_floats(M, N) floats).  A [M, K] (lda), B stored
+// [N, K] (ldb), every other tensor [M, N] contiguous.  Bit-identical to indm_gemm_f32 (transB = 1) + indm_ires_bwd_act_f32,
+// segment sums included.  Returns 1 (not an error) when the direct-to-LDS kernel does not take the problem.
+int indm_ires_seg_fold(const float* part, float* seg, long nseg, int cps, int C, hipStream_t st);   // elementwise.hip
+INDM_API int indm_gemm_ires_bwd_act_f32(const float* A, const float* B, const float* du, const float* d, const float* a,
+                                        const float* t, float* dp, float* dt, float* seg, int M, int N, int K, long lda, long ldb,
+                                        long rows_per_seg, float* ws, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return INDM_E_SHAPE;
+  if (!du || !d || !a || !t || !dp) return INDM_E_ARG;
+  if (seg && (rows_per_seg <= 0 || rows_per_seg % 64 || M % rows_per_seg || !ws)) return INDM_E_ARG;
+  if ((long)M * N >= (1L << 32) || (M & 63)) return 1;
+  IgemmParams p = {};
+  p.A = A; p.B = B; p.C = dp; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = N; p.batch = 1;
+  p.alpha = 1.0f; p.beta = 0.0f; p.rpg = 1;
+  p.e_du = du; p.e_d = d; p.e_a = a; p.e_t = t; p.e_dt = dt; p.e_part = seg ? ws : nullptr;
+  p.a_vec = al16(A) && (lda % 4 == 0);
+  p.b_vec = al16(B) && (ldb % 4 == 0);
+  const int r = run(p, A_ROW, B_COL, nullptr, 0, (hipStream_t)stream);
+  if (r != INDM_OK) return r;
+  if (seg) return indm_ires_seg_fold(ws, seg, M / rows_per_seg, (int)(rows_per_seg / 64), N, (hipStream_t)stream);
+  return INDM_OK;
 }
 // same contraction with the MFMA inputs rounded to bf16 (fp32 tensors, fp32 accumulate)
 INDM_API int indm_gemm_bf16(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,

@@ -53,9 +53,10 @@ static bool covered(int N, int H, int W, int C, int idim) {
     if (st_ != 0) return st_ < 0 ? st_ : INDM_E_SHAPE; /* a sub-launch that declines a covered geometry is a bug */ \
   } while (0)
 
-// INDM_GPASS_FUSED (A/B switch, read once): bit 0 conv + Sin, bit 1 GEMM + Sin in one launch each; default 3, 0 = the two-step forms
+// INDM_GPASS_FUSED (A/B switch, read once): bit 0 conv + Sin, bit 1 GEMM + Sin (g-pass), bit 2 GEMM + Sin-level backward in one
+// launch each; default 7, 0 = the two-step forms
 static int gpass_fused() {
-  static const int v = getenv("INDM_GPASS_FUSED") ? atoi(getenv("INDM_GPASS_FUSED")) : 3;
+  static const int v = getenv("INDM_GPASS_FUSED") ? atoi(getenv("INDM_GPASS_FUSED")) : 7;
   return v;
 }
 
@@ -525,11 +526,21 @@ INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) 
   TRY(indm_ires_bwd_act_f32(da2, du2, a->d2, a->a2, a->t3, dp2, nullptr, a->dcb, c.M, Cw, rps, act_w, stream));
   TRY(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
   // ---- level 2:  p2 = a1 W2 + b2 + cb[image] ----
-  float* da1 = bufA;                                                                               // da2 is dead
-  TRY(c.gemm(dp2, nullptr, a->W2, da1, Mi, Cw, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));           // da1 = dp2 W2^T
+  // da1 = dp2 W2^T and the Sin level it feeds -- dp1 = da1 d1 - 4 pi^2 a1 (q1 t2), dt2 = q1 d1, per-image sums of dp1 -- as ONE
+  // launch where the direct-to-LDS kernel takes the GEMM (fp32): da1 is never written, and the pass's 1.6 GB of HBM traffic
+  // runs under the other workgroup's MFMAs.  dt2 then lives in da1's slot (dp2 = bufD is still being read by other tiles).
+  float *dp1 = bufC, *dt2 = bufA;                                                                  // du2, da2 are dead
+  int fusedb = 1;
+  if (!c.bf16 && (gpass_fused() & 4))
+    fusedb = indm_gemm_ires_bwd_act_f32(dp2, a->W2, q1, a->d1, a->a1, a->t2, dp1, dt2, seg1, Mi, Cw, Cw, Cw, Cw, rps, act_w, stream);
+  if (fusedb < 0) return fusedb;
+  float* da1 = bufA;
+  if (fusedb == 1) TRY(c.gemm(dp2, nullptr, a->W2, da1, Mi, Cw, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));         // da1 = dp2 W2^T
   TRY(c.gemm(a->a1, nullptr, dp2, a->dW2, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));       // dW2 = a1^T dp2
-  float *dp1 = bufC, *dt2 = bufD;                                                                  // du2, dp2 are dead
-  TRY(indm_ires_bwd_act_f32(da1, q1, a->d1, a->a1, a->t2, dp1, dt2, seg1, c.M, Cw, rps, act_w, stream));
+  if (fusedb == 1) {
+    dt2 = bufD;                                                                                    // dp2 is dead
+    TRY(indm_ires_bwd_act_f32(da1, q1, a->d1, a->a1, a->t2, dp1, dt2, seg1, c.M, Cw, rps, act_w, stream));
+  }
   TRY(c.gemm(a->t3, a->d2, dt2, a->dW2T, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));        // dW2T = (t3 .* d2)^T (q1 .* d1)
   TRY(indm_colreduce_f32(seg1, nullptr, a->db1, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
   // ---- level 1:  p1 = conv(a0, W1) + b1 ----

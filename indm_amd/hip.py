@@ -56,6 +56,7 @@ _SIGS = {
     "indm_igemm_last_variant": [],
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_conv3x3_thin_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
+    "indm_gemm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p],
     "indm_gemm_sin_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p, c_i, c_p],
     "indm_conv3x3_thin_act_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "indm_conv3x3_thin_act_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
@@ -458,6 +459,28 @@ def prepack_weights(ws):
 
 def _skinny(kh, kw, stride, pad, c_small, c_wide):
     return kh == 3 and kw == 3 and stride == 1 and pad == 1 and c_small <= 16 and c_wide >= 64
+
+
+def gemm_ires_bwd_act(x, b_nk, du, d, a, t, want_dt=False, rows_per_seg=None):
+    """ires_bwd_act(gemm(x, b_nk, trans_b=True), du, d, a, t, ...) in ONE launch (fp32): the GEMM result is never written and the
+    elementwise pass runs as the GEMM's epilogue.  Returns (dp, dt, seg) bit-identical to the two calls, or None when the
+    direct-to-LDS kernel does not cover the GEMM: the caller runs the two steps."""
+    M, K = x.shape
+    N = b_nk.shape[0]
+    dp = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    dt = torch.empty_like(dp) if want_dt else None
+    seg = ws = None
+    if rows_per_seg is not None:
+        if rows_per_seg % 64 or M % rows_per_seg:
+            raise RuntimeError("gemm_ires_bwd_act: rows_per_seg must be a multiple of 64 that divides the row count")
+        seg = torch.empty((M // rows_per_seg, N), dtype=torch.float32, device=x.device)
+        ws = _ws(lib().indm_ires_bwd_act_ws_floats(M, N), x.device)
+    st = lib().indm_gemm_ires_bwd_act_f32(_ptr(x), _ptr(b_nk), _ptr(du), _ptr(d), _ptr(a), _ptr(t), _ptr(dp), _ptr(dt), _ptr(seg),
+                                          M, N, K, x.stride(0), b_nk.stride(0), rows_per_seg or 0, _ptr(ws), _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_gemm_ires_bwd_act_f32")
+    return dp, dt, seg
 
 
 def gemm_sin(a, b_nk, bias=None, bias2=None, rows_per_group=1):

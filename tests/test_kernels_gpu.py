@@ -250,6 +250,33 @@ def test_gemm_sin_equals_the_two_steps(M, N, K, rpg):
     assert hip.gemm_sin(rnd(57344, 24).to(DEV), rnd(128, 24).to(DEV)) is None        # K % 16
 
 
+@pytest.mark.parametrize("M,N,K,rps", [(57344, 512, 512, 1024), (65536, 128, 64, 256), (114688, 256, 32, 64)])
+def test_gemm_ires_bwd_act_equals_the_two_steps(M, N, K, rps):
+    """GEMM + Sin-level backward in one launch (the block drivers' da1 = dp2 W2^T -> dp1, dt2, per-image sums): dp, dt and the
+    segment sums BIT-identical to gemm(trans_b) followed by ires_bwd_act (the epilogue adds a chunk's rows in the elementwise
+    kernel's order, across the two lane halves), with and without dt / segment sums; fp64 reference within tolerance"""
+    x, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+    du, d, a, t = (rnd(M, N, seed=10 + i) for i in range(4))
+    xd, bd, dud, dd, ad, td = (z.to(DEV) for z in (x, b, du, d, a, t))
+    da = hip.gemm(xd, bd, trans_b=True)
+    for want_dt, seg in ((True, rps), (False, rps), (True, None), (False, None)):
+        out = hip.gemm_ires_bwd_act(xd, bd, dud, dd, ad, td, want_dt, seg)
+        assert out is not None, "problem should be covered"
+        assert hip.lib().indm_igemm_last_variant().decode() == "glds256x128,ires_bwd_act"
+        ref = hip.ires_bwd_act(da, dud, dd, ad, td, want_dt, seg)
+        for o, r, name in zip(out, ref, ("dp", "dt", "seg")):
+            assert (o is None) == (r is None), name
+            if o is not None:
+                assert torch.equal(o, r), f"{name}: max |diff| {float((o - r).abs().max())}"
+    rows = torch.cat([torch.arange(0, 128), torch.arange(M - 128, M)])
+    rdp, rdt, _ = _emu.ires_bwd_act(_emu.gemm(x[rows].double(), b.double(), trans_b=True), du[rows].double(), d[rows].double(),
+                                    a[rows].double(), t[rows].double(), True)
+    dp, dt, _ = hip.gemm_ires_bwd_act(xd, bd, dud, dd, ad, td, True, None)
+    close(dp[rows], rdp, rtol=1e-5, atol=2e-4 * math.sqrt(K), name="gemm + ires_bwd_act: dp")
+    close(dt[rows], rdt, rtol=1e-6, atol=1e-6, name="gemm + ires_bwd_act: dt")
+    assert hip.gemm_ires_bwd_act(xd[:512], bd, dud[:512], dd[:512], ad[:512], td[:512]) is None   # too few tiles
+
+
 # ---- "bf16 compute / fp32 accumulate" mode (BASELINE configs #3-#5) -----------------------------------------------
 def _r16(t):
     return t.bfloat16().float()
