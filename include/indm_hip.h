@@ -88,6 +88,15 @@ int indm_gemm_ires_bwd_act_f32(const float* A, const float* B, const float* du, 
                                float* dp, float* dt, float* seg, int M, int N, int K, long lda, long ldb, long rows_per_seg,
                                float* ws, void* stream);
 
+/* The same Sin level when the GEMM produces du (the chain's cotangent) instead of da: du = (A .* gateA) B is written, and
+ *   dp = da*d - 4 pi^2 * a * (du*t),  seg[s][n] = per-segment sums of dp (seg may be NULL)
+ * come out of the same launch (iresblock.py:60-76 reversed; activations.py:7-12).  A, gateA [M, K] (lda), B [K, N] row-major (ldb),
+ * the other tensors [M, N] contiguous.  Bit-identical to indm_gemm_f32 with a gate followed by indm_ires_bwd_act_f32.  Returns 1
+ * (not an error) when the gated direct-to-LDS kernel does not take the problem. */
+int indm_gemm_gated_ires_bwd_act_f32(const float* A, const float* gateA, const float* B, const float* da, const float* d,
+                                     const float* a, const float* t, float* du, float* dp, float* seg, int M, int N, int K,
+                                     long lda, long ldb, long rows_per_seg, float* ws, void* stream);
+
 /* dw[kh,kw,ci,co] = alpha * sum_pixels x * dy (+ beta*R): weight gradient of the convolution (autograd of
  * F.conv2d); the pixel reduction is split-K into ws. */
 int indm_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout,

@@ -69,6 +69,10 @@ struct IgemmParams {
   //   e_part[(m / 64) * N + n] = sum of dp over the 64-row chunk in row order (optional; indm_ires_bwd_act_f32's partial sums)
   const float *e_du, *e_d, *e_a, *e_t;
   float *e_dt, *e_part;
+  // the same pass on the GEMM that produces du instead (indm_gemm_gated_ires_bwd_act_f32): C = du = this GEMM's result (written:
+  // other consumers need it), e_da = the incoming da (read), e_dp = dp (written); e_d, e_a, e_t, e_part as above
+  const float* e_da;
+  float* e_dp;
 };
 // (the literals of elementwise.hip: the fused Sin epilogue must round like indm_sincos_act_fwd_f32)
 constexpr float SIN_TWO_PI = 6.283185307179586f;
@@ -355,6 +359,8 @@ __device__ __forceinline__ void epilogue_block(const IgemmParams& p, const Acc& 
 // written, and `run` = the column's running sum of dp over the rows so far IN ROW ORDER -- rows 8 q .. 8 q + 3 live in lane
 // half 0, 8 q + 4 .. 8 q + 7 in half 1, so the sum crosses the halves twice per quarter (ds_bpermute): the same additions
 // in the same order as ires_bwd_act_kernel's `s += g` over its 64-row chunk (bit-identical partial sums).
+// DU_ACC: the block is du (stored to C), da is read from p.e_da and dp goes to p.e_dp -- same expressions.
+template <bool DU_ACC>
 __device__ __forceinline__ void epilogue_bwd_act_block(const IgemmParams& p, const f32x16& da, int mbase, int n, int lane,
                                                        float& run) {
   const float K = SIN_TWO_PI * SIN_TWO_PI;
@@ -370,16 +376,23 @@ __device__ __forceinline__ void epilogue_bwd_act_block(const IgemmParams& p, con
       const int m = mbase + 8 * q + 4 * lhi + e;
       ok[e] = nok && m < p.M;
       const unsigned o = ok[e] ? (unsigned)m * (unsigned)p.ldc + (unsigned)n : 0u;
-      uu[e] = p.e_du[o]; dd[e] = p.e_d[o]; aa[e] = p.e_a[o]; tt[e] = p.e_t[o];
+      uu[e] = DU_ACC ? p.e_da[o] : p.e_du[o];   // (DU_ACC: this slot holds da)
+      dd[e] = p.e_d[o]; aa[e] = p.e_a[o]; tt[e] = p.e_t[o];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int m = mbase + 8 * q + 4 * lhi + e;
-      g[e] = da[4 * q + e] * dd[e] - K * aa[e] * (uu[e] * tt[e]);
+      const float dav = DU_ACC ? uu[e] : da[4 * q + e], duv = DU_ACC ? da[4 * q + e] : uu[e];
+      g[e] = dav * dd[e] - K * aa[e] * (duv * tt[e]);
       if (ok[e]) {
         const unsigned o = (unsigned)m * (unsigned)p.ldc + (unsigned)n;
-        p.C[o] = g[e];
-        if (p.e_dt) p.e_dt[o] = uu[e] * dd[e];
+        if constexpr (DU_ACC) {
+          p.C[o] = duv;
+          p.e_dp[o] = g[e];
+        } else {
+          p.C[o] = g[e];
+          if (p.e_dt) p.e_dt[o] = duv * dd[e];
+        }
       }
     }
     if (p.e_part) {
@@ -1572,7 +1585,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
     }
     return;
   }
-  if constexpr (ACT == 2) {
+  if constexpr (ACT == 2 || ACT == 3) {   // 3: the block is du (gated NN GEMM), see IgemmParams::e_da
     static_assert(RM == 2 && RN == 2, "written for the 8-wave tile: a wave owns one 64-row chunk x 64 columns");
     float run0 = 0.f, run1 = 0.f;   // running column sums of the two 32-column blocks over the wave's 64 rows
 #pragma unroll 1
@@ -1581,7 +1594,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void igemm_glds_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = b == 0 ? acc[0][0][r] : b == 1 ? acc[0][1][r] : b == 2 ? acc[1][0][r] : acc[1][1][r];
       float run = (b & 1) ? run1 : run0;
-      epilogue_bwd_act_block(p, v, m0 + mw + (b >> 1) * 32, n0 + nw + (b & 1) * 32 + l31, lane, run);
+      epilogue_bwd_act_block<ACT == 3>(p, v, m0 + mw + (b >> 1) * 32, n0 + nw + (b & 1) * 32 + l31, lane, run);
       if (b & 1) run1 = run; else run0 = run;
     }
     if (p.e_part && lhi == 0 && m0 + mw < p.M) {
@@ -1653,6 +1666,16 @@ int launch_glds(const IgemmParams& p, hipStream_t st) {
       if (indm_lds_optin<igemm_glds_kernel<A_ROW, B_COL, false, 8, false, 1>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
       last_variant = "glds256x128,sin";
       hipLaunchKernelGGL((igemm_glds_kernel<A_ROW, B_COL, false, 8, false, 1>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch),
+                         dim3(512), bytes, st, p);
+      return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+    }
+  }
+  if constexpr (AM == A_ROW && BMODE == B_ROW && HAS_G && NW == 8) {
+    if (p.e_da) {   // (fp32, no split-K, no bias / residual: checked by the caller)
+      constexpr size_t bytes = 2 * (2 * 256 * BK + 128 * BK) * sizeof(float);
+      if (indm_lds_optin<igemm_glds_kernel<A_ROW, B_ROW, true, 8, false, 3>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+      last_variant = "glds256x128,gated,ires_bwd_act";
+      hipLaunchKernelGGL((igemm_glds_kernel<A_ROW, B_ROW, true, 8, false, 3>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch),
                          dim3(512), bytes, st, p);
       return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
     }
@@ -1741,11 +1764,12 @@ int launch_tiles(const IgemmParams& p, hipStream_t st) {
     if ((!big256 || p.bf16) && p.splitk == 1 && p.a_vec && p.b_vec && !(p.K & 15) && p.M >= 1024 &&
         p.N >= 64 && (BMODE == B_COL || !(p.N & 3)) && (long)cdiv(p.M, 256) * cdiv(p.N, 128) * p.batch >= 224) {
       if ((p.act_d || p.e_du) && (p.G || BMODE != B_COL)) return 1;
+      if (p.e_da && (!p.G || BMODE != B_ROW)) return 1;
       if (p.G) return launch_glds<A_ROW, BMODE, true, 8>(p, st);
       return launch_glds<A_ROW, BMODE, false, 8>(p, st);
     }
   }
-  if (p.act_d || p.e_du) return 1;   // the fused epilogues exist on the NT direct-to-LDS kernel only: the caller runs the two steps
+  if (p.act_d || p.e_du || p.e_da) return 1;   // the fused epilogues exist on the direct-to-LDS kernel only: the caller runs the two steps
   if constexpr (AM == A_CONV && (BMODE == B_ROW || BMODE == B_DGRAD)) {
     // long convolutions (forward and data-grad): the same direct-to-LDS kernel on the implicit-GEMM A operand.
     // (Round 2 kept the data-grads that fill 256 x 256 tiles on the big-tile kernel, 118-123 TF; with the buffer-addressed
@@ -1853,7 +1877,7 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
   if ((p.R && (long)p.M * p.ldr >= (1L << 32)) || (p.bias2 && ((long)p.M / (p.rpg > 0 ? p.rpg : 1) + 1) * p.N >= (1L << 32)))
     return INDM_E_SHAPE;
   p.ws = ws;
-  if (!p.act_d && !p.e_du && (am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
+  if (!p.act_d && !p.e_du && !p.e_da && (am == A_ROW || am == A_COL) && (bm == B_ROW || bm == B_COL)) {
     // thin contractions of the flow's 3-/12-channel edges: HBM-streaming kernels of igemm_thin.hip (bf16 mode: operands
     // rounded at the fragment read, exact fp32 MFMA)
     ThinGemmArgs t = {p.A, p.G, p.B, p.C, p.M, p.N, p.K, am == A_COL, bm == B_COL, p.lda, p.ldb, p.ldc, p.batch,
@@ -2135,6 +2159,29 @@ INDM_API int indm_gemm_ires_bwd_act_f32(const float* A, const float* B, const fl
   p.a_vec = al16(A) && (lda % 4 == 0);
   p.b_vec = al16(B) && (ldb % 4 == 0);
   const int r = run(p, A_ROW, B_COL, nullptr, 0, (hipStream_t)stream);
+  if (r != INDM_OK) return r;
+  if (seg) return indm_ires_seg_fold(ws, seg, M / rows_per_seg, (int)(rows_per_seg / 64), N, (hipStream_t)stream);
+  return INDM_OK;
+}
+// The same level when the GEMM produces du instead: du = (A .* gateA) B is written (its other consumers need it) and
+//   dp = da * d - 4 pi^2 * a * (du * t),  seg[s][n] = per-segment sums of dp (optional)
+// come out of the same launch.  A, gateA [M, K] (lda), B [K, N] row-major (ldb).  Bit-identical to indm_gemm_f32 (gated) followed
+// by indm_ires_bwd_act_f32.  Returns 1 when the gated direct-to-LDS kernel does not take the problem.
+INDM_API int indm_gemm_gated_ires_bwd_act_f32(const float* A, const float* gateA, const float* B, const float* da, const float* d,
+                                              const float* a, const float* t, float* du, float* dp, float* seg, int M, int N,
+                                              int K, long lda, long ldb, long rows_per_seg, float* ws, void* stream) {
+  if (M < 0 || N < 0 || K < 0) return INDM_E_SHAPE;
+  if (!gateA || !da || !d || !a || !t || !du || !dp) return INDM_E_ARG;
+  if (seg && (rows_per_seg <= 0 || rows_per_seg % 64 || M % rows_per_seg || !ws)) return INDM_E_ARG;
+  if ((long)M * N >= (1L << 32) || (M & 63)) return 1;
+  IgemmParams p = {};
+  p.A = A; p.G = gateA; p.B = B; p.C = du; p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = N; p.batch = 1;
+  p.alpha = 1.0f; p.beta = 0.0f; p.rpg = 1;
+  p.e_da = da; p.e_d = d; p.e_a = a; p.e_t = t; p.e_dp = dp; p.e_part = seg ? ws : nullptr;
+  p.a_vec = al16(A) && al16(gateA) && (lda % 4 == 0);
+  p.b_vec = al16(B) && (ldb % 4 == 0);
+  const int r = run(p, A_ROW, B_ROW, nullptr, 0, (hipStream_t)stream);
   if (r != INDM_OK) return r;
   if (seg) return indm_ires_seg_fold(ws, seg, M / rows_per_seg, (int)(rows_per_seg / 64), N, (hipStream_t)stream);
   return INDM_OK;

@@ -53,10 +53,10 @@ static bool covered(int N, int H, int W, int C, int idim) {
     if (st_ != 0) return st_ < 0 ? st_ : INDM_E_SHAPE; /* a sub-launch that declines a covered geometry is a bug */ \
   } while (0)
 
-// INDM_GPASS_FUSED (A/B switch, read once): bit 0 conv + Sin, bit 1 GEMM + Sin (g-pass), bit 2 GEMM + Sin-level backward in one
-// launch each; default 7, 0 = the two-step forms
+// INDM_GPASS_FUSED (A/B switch, read once): bit 0 conv + Sin, bit 1 GEMM + Sin (g-pass), bit 2 GEMM + Sin-level backward (level 1),
+// bit 3 gated GEMM + Sin-level backward (level 2) in one launch each; default 15, 0 = the two-step forms
 static int gpass_fused() {
-  static const int v = getenv("INDM_GPASS_FUSED") ? atoi(getenv("INDM_GPASS_FUSED")) : 7;
+  static const int v = getenv("INDM_GPASS_FUSED") ? atoi(getenv("INDM_GPASS_FUSED")) : 15;
   return v;
 }
 
@@ -517,13 +517,19 @@ INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) 
   TRY(c.thin(q0p, a->W1, q1, -1, nullptr));                                                      // q1 = conv(q0, W1) = dL/d(t2 .* d1)
   TRY(indm_tap_spread_f32(q0p, col, c.N, c.H, c.W, C, -1, 1.0f, stream));                        // dW1 (chain part)^T = (t2 .* d1)^T spread(q0)
   TRY(c.gemm(a->t2, a->d1, col, qb, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
-  float* du2 = bufC;
-  TRY(c.gemm(q1, a->d1, a->W2, du2, Mi, Cw, Cw, 0, 0, Cw, Cw, nullptr, nullptr, 1));              // du2 = (q1 .* d1) W2 = dL/d(t3 .* d2)
+  // du2 = (q1 .* d1) W2 = dL/d(t3 .* d2), and -- where the gated direct-to-LDS kernel takes the GEMM (fp32) -- the Sin level that
+  // du2 feeds as the same launch's epilogue: dp2 = da2 d2 - 4 pi^2 a2 (du2 t3) and its per-image sums dcb
+  float *du2 = bufC, *dp2 = bufD;
+  int fusedc = 1;
+  if (!c.bf16 && (gpass_fused() & 8))
+    fusedc = indm_gemm_gated_ires_bwd_act_f32(q1, a->d1, a->W2, da2, a->d2, a->a2, a->t3, du2, dp2, a->dcb, Mi, Cw, Cw, Cw, Cw, rps,
+                                              act_w, stream);
+  if (fusedc < 0) return fusedc;
+  if (fusedc == 1) TRY(c.gemm(q1, a->d1, a->W2, du2, Mi, Cw, Cw, 0, 0, Cw, Cw, nullptr, nullptr, 1));
   TRY(indm_tap_spread_f32(a->w, col, c.N, c.H, c.W, C, 1, 1.0f, stream));                        // dW3 (chain part) = (du2 .* d2)^T spread(w)
   TRY(c.gemm(du2, a->d2, col, qc, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
   TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream));                                // [Cw, tap, c] -> [tap, Cw, c], both parts summed
-  float* dp2 = bufD;
-  TRY(indm_ires_bwd_act_f32(da2, du2, a->d2, a->a2, a->t3, dp2, nullptr, a->dcb, c.M, Cw, rps, act_w, stream));
+  if (fusedc == 1) TRY(indm_ires_bwd_act_f32(da2, du2, a->d2, a->a2, a->t3, dp2, nullptr, a->dcb, c.M, Cw, rps, act_w, stream));
   TRY(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
   // ---- level 2:  p2 = a1 W2 + b2 + cb[image] ----
   // da1 = dp2 W2^T and the Sin level it feeds -- dp1 = da1 d1 - 4 pi^2 a1 (q1 t2), dt2 = q1 d1, per-image sums of dp1 -- as ONE

@@ -57,6 +57,7 @@ _SIGS = {
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_conv3x3_thin_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_gemm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p],
+    "indm_gemm_gated_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p],
     "indm_gemm_sin_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p, c_i, c_p],
     "indm_conv3x3_thin_act_f32": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "indm_conv3x3_thin_act_bf16": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
@@ -481,6 +482,28 @@ def gemm_ires_bwd_act(x, b_nk, du, d, a, t, want_dt=False, rows_per_seg=None):
         return None
     _chk(st, "indm_gemm_ires_bwd_act_f32")
     return dp, dt, seg
+
+
+def gemm_gated_ires_bwd_act(x, gate, b_kn, da, d, a, t, rows_per_seg=None):
+    """du = gemm(x, b_kn, gate=gate) AND ires_bwd_act(da, du, d, a, t, False, rows_per_seg) in ONE launch (fp32).  Returns
+    (du, dp, seg) bit-identical to the two calls, or None when the gated direct-to-LDS kernel does not cover the GEMM."""
+    M, K = x.shape
+    N = b_kn.shape[1]
+    du = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    dp = torch.empty_like(du)
+    seg = ws = None
+    if rows_per_seg is not None:
+        if rows_per_seg % 64 or M % rows_per_seg:
+            raise RuntimeError("gemm_gated_ires_bwd_act: rows_per_seg must be a multiple of 64 that divides the row count")
+        seg = torch.empty((M // rows_per_seg, N), dtype=torch.float32, device=x.device)
+        ws = _ws(lib().indm_ires_bwd_act_ws_floats(M, N), x.device)
+    st = lib().indm_gemm_gated_ires_bwd_act_f32(_ptr(x), _ptr(gate), _ptr(b_kn), _ptr(da), _ptr(d), _ptr(a), _ptr(t), _ptr(du),
+                                                _ptr(dp), _ptr(seg), M, N, K, x.stride(0), b_kn.stride(0), rows_per_seg or 0,
+                                                _ptr(ws), _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_gemm_gated_ires_bwd_act_f32")
+    return du, dp, seg
 
 
 def gemm_sin(a, b_nk, bias=None, bias2=None, rows_per_group=1):

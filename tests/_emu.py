@@ -194,6 +194,12 @@ def gemm_ires_bwd_act(x, b_nk, du, d, a, t, want_dt=False, rows_per_seg=None):
     return ires_bwd_act(gemm(x, b_nk, trans_b=True), du, d, a, t, want_dt, rows_per_seg)
 
 
+def gemm_gated_ires_bwd_act(x, gate, b_kn, da, d, a, t, rows_per_seg=None):
+    du = gemm(x, b_kn, gate=gate)
+    dp, _, seg = ires_bwd_act(da, du, d, a, t, False, rows_per_seg)
+    return du, dp, seg
+
+
 def _dropout_mask_unavailable(drop_p):
     if drop_p > 0:
         raise NotImplementedError("Philox dropout masks exist only in the HIP kernel")

@@ -277,6 +277,24 @@ def test_gemm_ires_bwd_act_equals_the_two_steps(M, N, K, rps):
     assert hip.gemm_ires_bwd_act(xd[:512], bd, dud[:512], dd[:512], ad[:512], td[:512]) is None   # too few tiles
 
 
+@pytest.mark.parametrize("M,N,K,rps", [(57344, 512, 512, 1024), (65536, 128, 64, 256)])
+def test_gemm_gated_ires_bwd_act_equals_the_two_steps(M, N, K, rps):
+    """the level whose GEMM produces du (gated NN): du, dp and the segment sums BIT-identical to gemm(gate=) followed by
+    ires_bwd_act, with and without segment sums"""
+    x, g, b = rnd(M, K, seed=1), rnd(M, K, seed=5), rnd(K, N, seed=2, scale=0.2)
+    da, d, a, t = (rnd(M, N, seed=10 + i) for i in range(4))
+    xd, gd, bd, dad, dd, ad, td = (z.to(DEV) for z in (x, g, b, da, d, a, t))
+    du = hip.gemm(xd, bd, gate=gd)
+    for seg in (rps, None):
+        out = hip.gemm_gated_ires_bwd_act(xd, gd, bd, dad, dd, ad, td, seg)
+        assert out is not None, "problem should be covered"
+        assert hip.lib().indm_igemm_last_variant().decode() == "glds256x128,gated,ires_bwd_act"
+        dp, _, sg = hip.ires_bwd_act(dad, du, dd, ad, td, False, seg)
+        assert torch.equal(out[0], du) and torch.equal(out[1], dp)
+        assert (sg is None) == (out[2] is None) and (sg is None or torch.equal(out[2], sg))
+    assert hip.gemm_gated_ires_bwd_act(xd[:512], gd[:512], bd, dad[:512], dd[:512], ad[:512], td[:512]) is None
+
+
 # ---- "bf16 compute / fp32 accumulate" mode (BASELINE configs #3-#5) -----------------------------------------------
 def _r16(t):
     return t.bfloat16().float()
