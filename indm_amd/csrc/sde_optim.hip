@@ -146,51 +146,64 @@ __global__ __launch_bounds__(256) void langevin_step_kernel(const float* __restr
   }
 }
 
-// log|det W| and W^-1 of one n x n (n <= 64) matrix: Gauss-Jordan with partial pivoting, one wavefront,
-// the augmented [n][2n] system lives in LDS (lane i owns row i).
-__global__ __launch_bounds__(64) void slogdet_inv_kernel(const float* __restrict__ W, int n, float* __restrict__ logdet,
-                                                          float* __restrict__ inv) {
+// log|det W| and W^-1 of one n x n (n <= 64) matrix: Gauss-Jordan with partial pivoting; the augmented [n][2n] system lives
+// in LDS.  Round 5: 1024 threads -- thread (row = tid % 64, part = tid / 64) owns 8 columns of its row -- instead of one
+// wavefront walking all 128 columns of every row per pivot (350 us per call, twice per training step, with the GPU otherwise
+// idle).  Wave 0 searches the pivot exactly as before and publishes it through LDS; every element still sees the same
+// operations in the same order (a[r][j] /= piv; a[r][j] -= f * a[k][j]): bit-identical results.
+constexpr int SLD_PARTS = 8, SLD_COLS = 128 / SLD_PARTS;
+__global__ __launch_bounds__(64 * SLD_PARTS) void slogdet_inv_kernel(const float* __restrict__ W, int n, float* __restrict__ logdet,
+                                                                     float* __restrict__ inv) {
   __shared__ float a[64][129];
-  const int lane = threadIdx.x;
+  __shared__ int piv_row;
+  const int row = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int n2 = 2 * n;
-  for (int j = 0; j < n2; ++j)
-    if (lane < n) a[lane][j] = j < n ? W[lane * n + j] : (j - n == lane ? 1.f : 0.f);
+  const int j0 = part * SLD_COLS, j1 = min(n2, j0 + SLD_COLS);
+  if (row < n)
+    for (int j = j0; j < j1; ++j) a[row][j] = j < n ? W[row * n + j] : (j - n == row ? 1.f : 0.f);
   __syncthreads();
   float ld = 0.f;
   for (int k = 0; k < n; ++k) {
-    // pivot search over rows >= k
-    float v = (lane >= k && lane < n) ? fabsf(a[lane][k]) : -1.f;
-    int idx = lane;
+    if (part == 0) {   // pivot search over rows >= k (one wavefront; column k was last written before the previous barrier)
+      float v = (row >= k && row < n) ? fabsf(a[row][k]) : -1.f;
+      int idx = row;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(v, o, 64);
-      const int oi = __shfl_xor(idx, o, 64);
-      if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+      }
+      if (row == 0) piv_row = idx;
     }
-    const int p = idx;
-    if (p != k) {
-      for (int j = lane; j < n2; j += 64) {
-        const float t = a[k][j];
-        a[k][j] = a[p][j];
-        a[p][j] = t;
+    __syncthreads();                       // B1: the pivot row is known; last step's column fix is done
+    const int p = piv_row;
+    const float piv = a[p][k];             // (= a[k][k] after the swap)
+    ld += logf(fabsf(piv));
+    __syncthreads();                       // B2: everybody has read the pivot before its column is rewritten
+    if (row == 0) {                        // swap rows k and p and scale the new row k: one thread per part, its columns
+      for (int j = j0; j < j1; ++j) {
+        const float tk = a[k][j], tp = a[p][j];
+        if (p != k) a[p][j] = tk;
+        a[k][j] = tp / piv;
       }
     }
-    __syncthreads();
-    const float piv = a[k][k];
-    ld += logf(fabsf(piv));
-    __syncthreads();
-    for (int j = lane; j < n2; j += 64) a[k][j] /= piv;
-    __syncthreads();
-    if (lane < n && lane != k) {
-      const float f = a[lane][k];
+    __syncthreads();                       // B3
+    float f = 0.f;
+    if (row < n && row != k) {
+      f = a[row][k];
       if (f != 0.f)
-        for (int j = 0; j < n2; ++j) a[lane][j] -= f * a[k][j];
+        for (int j = j0; j < j1; ++j)
+          if (j != k) a[row][j] -= f * a[k][j];
     }
-    __syncthreads();
+    __syncthreads();                       // B4: every part of a row has read its f
+    // column k of the eliminated rows (a[row][k] -= f * a[k][k], a[k][k] == piv / piv): by the part that owns column k, after
+    // the barrier, so that no part reads an already-cleared f.  The next pivot search reads column k + 1: no conflict.
+    if (f != 0.f && k >= j0 && k < j1) a[row][k] = f - f * a[k][k];
   }
-  if (lane == 0) logdet[0] = ld;
-  for (int j = 0; j < n; ++j)
-    if (lane < n) inv[lane * n + j] = a[lane][n + j];
+  __syncthreads();
+  if (threadIdx.x == 0) logdet[0] = ld;
+  if (row < n)
+    for (int j = max(j0, n); j < j1; ++j) inv[row * n + (j - n)] = a[row][j];
 }
 
 }  // namespace
@@ -438,7 +451,7 @@ INDM_API int indm_ema_update_f32(float* s, const float* p, long n, float one_min
 // torch.slogdet(weight.to('cpu')), flows/permutation.py:107-108, and provides d logdet/dW = inv^T)
 INDM_API int indm_slogdet_inv_f32(const float* W, int n, float* logdet, float* inv, void* stream) {
   if (n <= 0 || n > 64) return INDM_E_SHAPE;
-  hipLaunchKernelGGL(slogdet_inv_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, W, n, logdet, inv);
+  hipLaunchKernelGGL(slogdet_inv_kernel, dim3(1), dim3(64 * SLD_PARTS), 0, (hipStream_t)stream, W, n, logdet, inv);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }
