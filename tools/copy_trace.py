@@ -1,6 +1,9 @@
-"""Where do the device-to-device copies (and other short torch-side kernels) of one training step come from?  Runs the bench
-workload (batch 128 unless INDM_TRACE_BATCH), profiles ONE step with torch.profiler (stacks on) and prints, per Python call
-site, the count and GPU time of every Memcpy DtoD and every aten kernel shorter than 10 us.  (run on the GPU box)"""
+"""Where do the device-to-device copies (and other short torch-side kernels) of one STEADY-STATE training step come from?  Runs
+the bench workload (batch 128 unless INDM_TRACE_BATCH), profiles ONE step with torch.profiler and prints (i) the Python-level
+call sites of copy_ / clone / contiguous / to / zero_ / fill_ on GPU tensors, (ii) the profiler's totals for copies and
+memsets, (iii) count and GPU time of every aten op whose kernels are all shorter than 10 us.  Round 5's finding: 13 Memcpy
+DtoD and ~ 300 short aten kernels (1.3 ms) per step -- rocprofv3's 490 copyBuffer "per step" were start-up copies of a
+4-step profile.  (run on the GPU box)"""
 import collections, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -51,27 +54,12 @@ print("profiler totals:")
 for a in prof.key_averages():
     if any(t in a.key for t in ("copy", "Memcpy", "clone", "contiguous", "Memset", "zero_", "fill_")):
         print(f"  {a.count:6d} calls  cpu {a.cpu_time_total / 1e3:8.3f} ms  gpu {a.device_time_total / 1e3:8.3f} ms  {a.key}")
-ev = prof.events()
-by = collections.defaultdict(lambda: [0, 0.0])
+print("short aten kernels (< 10 us each) and copies of the step, per op:")
 tot = collections.defaultdict(lambda: [0, 0.0])
-for e in ev:
-    if e.device_type != torch.autograd.DeviceType.CPU:
+for e in prof.events():
+    if e.device_type != torch.autograd.DeviceType.CPU or not e.kernels:
         continue
-    gpu_us = sum(k.duration for k in e.kernels) if e.kernels else 0.0
-    if not e.kernels:
-        continue
-    names = {k.name for k in e.kernels}
-    short = all(k.duration < 10 for k in e.kernels)
-    memcpy = any("Memcpy" in n or "copyBuffer" in n for n in names)
-    if not (memcpy or (short and e.name.startswith("aten::"))):
-        continue
-    st = [f for f in (e.stack or []) if "/indm_amd/" in f or "bench.py" in f or "autograd" in f][:3]
-    key = (e.name, " <- ".join(s.split("/")[-1] for s in st) or "(no python frame: autograd engine)")
-    by[key][0] += len(e.kernels); by[key][1] += gpu_us
-    tot[e.name][0] += len(e.kernels); tot[e.name][1] += gpu_us
-print("per op:")
+    if all(k.duration < 10 for k in e.kernels) and e.name.startswith("aten::"):
+        tot[e.name][0] += len(e.kernels); tot[e.name][1] += sum(k.duration for k in e.kernels)
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"  {v[0]:5d} launches {v[1] / 1e3:8.3f} ms  {k}")
-print("per call site:")
-for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:60]:
-    print(f"  {v[0]:5d} launches {v[1] / 1e3:8.3f} ms  {k[0]:28s} {k[1]}")
