@@ -224,7 +224,8 @@ def test_conv3x3_thin_act_equals_the_two_steps(N, H, W, C, Co, mode):
     assert hip.conv3x3_thin_act(rnd(2, 64, 64, 3).to(DEV), rnd(27, 512).to(DEV)) is None
 
 
-@pytest.mark.parametrize("M,N,K,rpg", [(57344, 512, 512, 1024), (57344 + 72, 128, 64, 8), (65536, 256, 48, 256)])
+@pytest.mark.parametrize("M,N,K,rpg", [(57344, 512, 512, 1024), (57344 + 72, 128, 64, 8), (65536, 256, 48, 256), (57344, 192, 16, 64),
+                                        (114688 + 8, 64, 32, 1)])
 def test_gemm_sin_equals_the_two_steps(M, N, K, rpg):
     """GEMM + Sin in one launch (the g-net's second level inside the block drivers): (a, d) BIT-identical to gemm(trans_b) followed
     by sincos_fwd -- bias, per-image bias, both, neither; a ragged last tile; a short K -- and within the GEMM's tolerance of the
@@ -250,7 +251,8 @@ def test_gemm_sin_equals_the_two_steps(M, N, K, rpg):
     assert hip.gemm_sin(rnd(57344, 24).to(DEV), rnd(128, 24).to(DEV)) is None        # K % 16
 
 
-@pytest.mark.parametrize("M,N,K,rps", [(57344, 512, 512, 1024), (65536, 128, 64, 256), (114688, 256, 32, 64)])
+@pytest.mark.parametrize("M,N,K,rps", [(57344, 512, 512, 1024), (65536, 128, 64, 256), (114688, 256, 32, 64), (57344 + 64, 192, 48, 64),
+                                        (114688 + 128, 64, 16, 128)])
 def test_gemm_ires_bwd_act_equals_the_two_steps(M, N, K, rps):
     """GEMM + Sin-level backward in one launch (the block drivers' da1 = dp2 W2^T -> dp1, dt2, per-image sums): dp, dt and the
     segment sums BIT-identical to gemm(trans_b) followed by ires_bwd_act (the epilogue adds a chunk's rows in the elementwise
@@ -277,7 +279,7 @@ def test_gemm_ires_bwd_act_equals_the_two_steps(M, N, K, rps):
     assert hip.gemm_ires_bwd_act(xd[:512], bd, dud[:512], dd[:512], ad[:512], td[:512]) is None   # too few tiles
 
 
-@pytest.mark.parametrize("M,N,K,rps", [(57344, 512, 512, 1024), (65536, 128, 64, 256)])
+@pytest.mark.parametrize("M,N,K,rps", [(57344, 512, 512, 1024), (65536, 128, 64, 256), (57344 + 192, 192, 48, 64)])
 def test_gemm_gated_ires_bwd_act_equals_the_two_steps(M, N, K, rps):
     """the level whose GEMM produces du (gated NN): du, dp and the segment sums BIT-identical to gemm(gate=) followed by
     ires_bwd_act, with and without segment sums"""
