@@ -343,7 +343,9 @@ int launch_rows(const RowsArgs& a, hipStream_t st) {
   // copies the next tile -- 112 us with four k-steps of weight fragments in flight, 140 us with eight (spills at the
   // 168-register cap of a nine-wave workgroup): with two waves per SIMD the weight-fragment latency is exposed; the
   // two-workgroups-per-CU form hides it behind four waves per SIMD.  (Round 5: SIX k-steps of weight fragments in flight in THIS
-  // form -- 128 VGPRs, no spills -- measured the same: GEMM 90.4 / 91.5 us, chain 103.7 / 103.8 us.)  Starting the second workgroup of every CU 6 - 18 us late
+  // form -- 128 VGPRs, no spills -- measured the same: GEMM 90.4 / 91.5 us, chain 103.7 / 103.8 us.  Starting a tile when the FIRST
+  // half of its A image has landed does not survive the compiler: its own `s_waitcnt vmcnt(6 / 7)` in front of every k-step count
+  // only the fragment loads it knows, vmcnt retires in order, so the first counted wait drains the older asm-issued copies too.)  Starting the second workgroup of every CU 6 - 18 us late
   // (so that one streams while the other multiplies) only added the delay: 101 -> 105 / 114 / 126 us.  What the numbers
   // point at: every workgroup pulls the whole 512 KB of packed weights out of L2 per tile -- 1 GB per launch at 64-row tiles
   // (10 TB/s of L2 -> CU traffic next to 2.6 TB/s of HBM traffic), 2 GB at 32-row tiles (15.6 TB/s, and slower).
