@@ -268,6 +268,36 @@ int indm_f16_thin_wgrad(const float* thin, const void* wide, const void* gate, f
 int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y, float* out, long M, float alpha, int transpose,
                         float* ws, long ws_floats, void* stream);
 
+/* ---- bf16 STORAGE of the score network's activations ("H16", BASELINE configs #3-#5; csrc/unet_h16.hip) -------------
+ * NHWC rows of bf16 (two values per dword); accumulators, biases, per-image embeddings, weight gradients and the fp32
+ * master weights stay fp32.  The workloads: ResnetBlockBigGANpp's 3x3 / 1x1 convolutions (models/layerspp.py:225-287,
+ * models/layers.py:88-124), NIN (models/layers.py:546-556), the NCSN++ graph of models/ncsnpp.py:251-414. */
+/* Packed bf16 copies of the convolution weights, one launch for the whole network.  jobs: DEVICE array of
+ * struct indm_h16_pack_job {const float* src; void* fwd; void* dg; int T, Cin, Cout, tile0;}:
+ *   src  fp32 RSCK [T][Cin][Cout] (1x1 / NIN: T = 1)
+ *   fwd  bf16 [Cout][T][Cin]        -- B operand of the forward convolution (may be NULL)
+ *   dg   bf16 [Cin][T][Cout], taps flipped: dg[ci][t][co] = src[T-1-t][ci][co] -- B operand of the data gradient (may be NULL)
+ *   tile0 = running sum of T * ceil(Cin/32) * ceil(Cout/32) over the preceding jobs; ntiles = the total. */
+struct indm_h16_pack_job { const float* src; void* fwd; void* dg; int T, Cin, Cout, tile0; };
+int indm_h16_pack_weights(const void* jobs, int njobs, int ntiles, void* stream);
+/* y[n,oh,ow,co] = alpha * (sum x[n, oh s + kh - pad, ow s + kw - pad, ci] wp[co][(kh,kw,ci)] + bias[co] + bias2[n][co]) + beta * R
+ * x bf16 NHWC, wp packed `fwd` form, y bf16 (out_f32 != 0: fp32, no R), R bf16 of y's shape (ddpm_conv3x3 / conv1x1 / NIN,
+ * models/layers.py:88-124,546-556, with the temb bias, residual and 1/sqrt(2) of layerspp.py:262-287 in the epilogue).  The data
+ * gradient of a stride-1 convolution is the same call on dy with the `dg` pack and pad' = K - 1 - pad; KH = KW = 1 is a plain
+ * NT GEMM.  ws: fp32 split-K workspace.  Returns 1 (not an error) when the geometry is not covered (Cin % 32, Cout % 2,
+ * OW / OH*OW not powers of two, >= 2 GB tensors, unaligned pointers). */
+int indm_h16_conv2d(const void* x, const void* wp, void* y, int Nimg, int H, int W, int Cin, int Cout, int KH, int KW,
+                    int stride, int pad, int OH, int OW, float alpha, const float* bias, const float* bias2,
+                    const void* R, float beta, int out_f32, float* ws, long ws_floats, void* stream);
+/* dw[kh,kw,ci,co] = alpha * sum_{n,oh,ow} x[n, oh s + kh - pad, ow s + kw - pad, ci] dy[n,oh,ow,co]  (fp32 RSCK; autograd of
+ * F.conv2d w.r.t. the weight): x, dy bf16 NHWC; deterministic split over the pixels into ws (>= KH KW Cin Cout floats).
+ * Returns 1 when not covered (Cin % 8, Cout % 8, pixels % 32, OW / OH*OW not powers of two, >= 2 GB tensors). */
+int indm_h16_conv2d_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, int OH, int OW, float alpha, float* ws, long ws_floats, void* stream);
+/* fp32 <-> bf16 (round to nearest even); n even, 16-byte aligned pointers; to_f32 scales by alpha */
+int indm_h16_from_f32(const float* x, void* y, long n, void* stream);
+int indm_h16_to_f32(const void* x, float* y, long n, float alpha, void* stream);
+
 /* act 1 SiLU (models/layers.py:38-39), 2 ELU (resnet_batchnorm.py:27) */
 int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);
 int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);

@@ -134,6 +134,12 @@ _SIGS = {
     "indm_f16_wgrad_ws_floats": [c_l, c_i],
     "indm_f16_thin_wgrad": [c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_l, c_p, c_l, c_p],
     "indm_f16_wgrad_gemm": [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p, c_l, c_p],
+    "indm_h16_pack_weights": [c_p, c_i, c_i, c_p],
+    "indm_h16_conv2d": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_i,
+                        c_p, c_l, c_p],
+    "indm_h16_conv2d_wgrad": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
+    "indm_h16_from_f32": [c_p, c_p, c_l, c_p],
+    "indm_h16_to_f32": [c_p, c_p, c_l, c_f, c_p],
     "indm_timer_create": [c_i, c_p],
     "indm_timer_destroy": [c_p],
     "indm_timer_reset": [c_p, c_i],
@@ -1471,6 +1477,122 @@ def f16_wgrad_gemm(X, Y, M, gate=None, alpha=1.0, transpose=False):
         return None
     _chk(st, "indm_f16_wgrad_gemm")
     return out
+
+
+# --------------------------------------------------------------------------- bf16 storage of the score network (csrc/unet_h16.hip)
+H16 = {"on": os.environ.get("INDM_H16", "1") != "0"}   # tools / tests: bf16 compute on fp32 activations (rounds 2-5)
+_H16_STATS = {"conv": 0, "conv_fallback": 0, "wgrad": 0, "wgrad_fallback": 0}
+
+
+def h16(on=None):
+    """bf16 STORAGE of the score network's activations in bf16 compute mode (default on; INDM_H16=0 or h16(False) keeps
+    the U-Net on fp32 tensors with bf16 MFMA inputs, the round 2-5 behaviour)."""
+    if on is not None:
+        H16["on"] = bool(on)
+    return H16["on"] and _MFMA["dtype"] == "bf16"
+
+
+def h16_stats(reset=False):
+    """launch counts of the H16 kernels vs their fp32-storage fallbacks since the last reset (tests assert coverage)"""
+    out = dict(_H16_STATS)
+    if reset:
+        for k in _H16_STATS:
+            _H16_STATS[k] = 0
+    return out
+
+
+def to_bf16(x):
+    """fp32 tensor -> bf16 (RNE), same shape"""
+    x = x if x.is_contiguous() else x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    n = x.numel()
+    if n % 2 or x.data_ptr() % 16:
+        return x.to(torch.bfloat16)   # (odd sizes never occur on the NHWC activations; ATen's converter rounds the same way)
+    _chk(lib().indm_h16_from_f32(_ptr(x), y.data_ptr(), n, _stream()), "indm_h16_from_f32")
+    return y
+
+
+def to_f32(x, alpha=1.0):
+    """bf16 tensor -> fp32 (exact), scaled by alpha"""
+    x = x if x.is_contiguous() else x.contiguous()
+    n = x.numel()
+    if n % 2 or x.data_ptr() % 16:
+        return x.float() * alpha if alpha != 1.0 else x.float()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _chk(lib().indm_h16_to_f32(_ptr16(x), _ptr(y), n, alpha, _stream()), "indm_h16_to_f32")
+    return y
+
+
+def h16_pack_weights(weights, want_dg=True):
+    """weights: list of fp32 RSCK [KH,KW,Cin,Cout] (or [Cin,Cout]) tensors -> list of (fwd, dg) bf16 packs
+    (fwd [Cout, T*Cin]; dg [Cin, T*Cout] with flipped taps, or None), ONE launch.  The job table is rebuilt per call
+    (the packs are fresh tensors: the forward's autograd nodes keep them alive for the backward)."""
+    import numpy as np
+    if not weights:
+        return []
+    dev = weights[0].device
+    shapes = []
+    for w in weights:
+        if w.dim() == 4:
+            T, Ci, Co = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
+        else:
+            T, Ci, Co = 1, w.shape[0], w.shape[1]
+        shapes.append((T, Ci, Co))
+    total = sum(T * Ci * Co for T, Ci, Co in shapes)
+    flat = torch.empty(total * (2 if want_dg else 1), dtype=torch.bfloat16, device=dev)
+    job = np.zeros(len(weights), dtype=np.dtype([("src", "<u8"), ("fwd", "<u8"), ("dg", "<u8"), ("T", "<i4"), ("Cin", "<i4"),
+                                                 ("Cout", "<i4"), ("tile0", "<i4")]))
+    out, off, tiles = [], 0, 0
+    base = flat.data_ptr()
+    for i, (w, (T, Ci, Co)) in enumerate(zip(weights, shapes)):
+        n = T * Ci * Co
+        fwd = flat[off:off + n].view(Co, T * Ci)
+        dg = flat[total + off:total + off + n].view(Ci, T * Co) if want_dg else None
+        job[i] = (_ptr(w), base + 2 * off, base + 2 * (total + off) if want_dg else 0, T, Ci, Co, tiles)
+        tiles += T * ((Ci + 31) // 32) * ((Co + 31) // 32)
+        off += n
+        out.append((fwd, dg))
+    tab = to_device(torch.from_numpy(job.view(np.uint8).copy()), dev)
+    _chk(lib().indm_h16_pack_weights(tab.data_ptr(), len(weights), tiles, _stream()), "indm_h16_pack_weights")
+    out[0][0]._h16_keep = tab    # the table must outlive the (asynchronous) launch
+    return out
+
+
+def h16_conv2d(x, wp, KH, KW, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0, out_f32=False):
+    """bf16 NHWC x [N,H,W,Cin], wp packed bf16 [Cout, KH*KW*Cin] -> y [N,OH,OW,Cout] (bf16, or fp32 with out_f32);
+    None when the H16 kernel does not cover the geometry (the caller converts and takes the fp32-storage path)."""
+    N, H, W, Ci = x.shape
+    Co = wp.shape[0]
+    if wp.shape[1] != KH * KW * Ci:
+        raise RuntimeError("h16_conv2d: packed weight does not match the input")
+    OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    y = torch.empty((N, OH, OW, Co), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    ws = _ws(SPLITK_WS_FLOATS, x.device)
+    st = lib().indm_h16_conv2d(_ptr16(x), _ptr16(wp), y.data_ptr(), N, H, W, Ci, Co, KH, KW, stride, pad, OH, OW, alpha,
+                               _ptr(bias), _ptr(bias2), _ptr16(res), beta, int(out_f32), _ptr(ws), SPLITK_WS_FLOATS,
+                               _stream())
+    if st == 1:
+        _H16_STATS["conv_fallback"] += 1
+        return None
+    _chk(st, "indm_h16_conv2d")
+    _H16_STATS["conv"] += 1
+    return y
+
+
+def h16_conv2d_wgrad(x, dy, KH, KW, stride=1, pad=1, alpha=1.0):
+    """bf16 x [N,H,W,Cin], dy [N,OH,OW,Cout] -> fp32 dw [KH,KW,Cin,Cout]; None when not covered"""
+    N, H, W, Ci = x.shape
+    _, OH, OW, Co = dy.shape
+    dw = torch.empty((KH, KW, Ci, Co), dtype=torch.float32, device=x.device)
+    ws = _ws(SPLITK_WS_FLOATS, x.device)
+    st = lib().indm_h16_conv2d_wgrad(_ptr16(x), _ptr16(dy), _ptr(dw), N, H, W, Ci, Co, KH, KW, stride, pad, OH, OW, alpha,
+                                     _ptr(ws), SPLITK_WS_FLOATS, _stream())
+    if st == 1:
+        _H16_STATS["wgrad_fallback"] += 1
+        return None
+    _chk(st, "indm_h16_conv2d_wgrad")
+    _H16_STATS["wgrad"] += 1
+    return dw
 
 
 # --------------------------------------------------------------------------- block-level drivers (csrc/iresblock.hip)
