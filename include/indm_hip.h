@@ -298,6 +298,29 @@ int indm_h16_conv2d_wgrad(const void* x, const void* dy, float* dw, int Nimg, in
 int indm_h16_from_f32(const float* x, void* y, long n, void* stream);
 int indm_h16_to_f32(const void* x, float* y, long n, float alpha, void* stream);
 
+/* GroupNorm(min(C/4,32), C, eps) [+ SiLU] [+ dropout] on bf16 NHWC (models/layerspp.py:232-279, models/layers.py:38-39): x, y, dy,
+ * dx bf16 [N, HW, C]; gamma, beta, mean, rstd [N, G], dgamma, dbeta fp32; same Philox dropout mask as indm_groupnorm_*_f32 for
+ * the same seed.  indm_h16_groupnorm_ok: 1 when covered (C % 8 == 0, (C / G) % 4 == 0, a block of whole groups of <= 32 channels
+ * fits one workgroup's registers); fwd / bwd return 1 otherwise.  ws (bwd): indm_h16_groupnorm_ws_floats(N, C) floats. */
+int indm_h16_groupnorm_ok(int HW, int C, int G);
+long indm_h16_groupnorm_ws_floats(int N, int C);
+int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                           int N, int HW, int C, int G, float eps, int act, float drop_p, unsigned long long seed, void* stream);
+int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                           const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G, int act,
+                           float drop_p, unsigned long long seed, float* ws, void* stream);
+/* out[s][c] = alpha * sum_{r < rps} x[(s rps + r) C + c], x bf16 [nseg rps, C], out fp32 [nseg, C]: the bias and per-image
+ * temb-bias gradients of the convolutions (layerspp.py:262-263); C % 8 == 0, C <= 2048; ws: indm_h16_segreduce_ws_floats floats */
+long indm_h16_segreduce_ws_floats(long nseg, long rps, int C);
+int indm_h16_segreduce(const void* x, float* out, long nseg, long rps, int C, float alpha, float* ws, void* stream);
+/* y = a x (bf16), n % 8 == 0;  out (bf16) = a x (fp32) + b y (bf16): an fp32-computed edge joining the bf16 trunk (the input
+ * pyramid's skinny convolution, models/ncsnpp.py:339-347) */
+int indm_h16_scale(const void* x, void* y, long n, float a, void* stream);
+int indm_h16_axpby_mixed(const float* x, const void* y, void* out, long n, float a, float b, void* stream);
+/* naive_upsample_2d / naive_downsample_2d (models/up_or_down_sampling.py:59-69) on bf16 NHWC, C % 8 == 0 */
+int indm_h16_upsample2x(const void* x, void* y, int N, int H, int W, int C, float alpha, void* stream);
+int indm_h16_downsample2x(const void* x, void* y, int N, int H, int W, int C, float alpha, void* stream);
+
 /* act 1 SiLU (models/layers.py:38-39), 2 ELU (resnet_batchnorm.py:27) */
 int indm_act_fwd_f32(const float* x, float* y, long n, int act, void* stream);
 int indm_act_bwd_f32(const float* dy, const float* x, float* dx, long n, int act, void* stream);

@@ -138,6 +138,16 @@ _SIGS = {
     "indm_h16_conv2d": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_i,
                         c_p, c_l, c_p],
     "indm_h16_conv2d_wgrad": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
+    "indm_h16_groupnorm_ok": [c_i, c_i, c_i],
+    "indm_h16_groupnorm_ws_floats": [c_i, c_i],
+    "indm_h16_groupnorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p],
+    "indm_h16_groupnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_p, c_p],
+    "indm_h16_segreduce_ws_floats": [c_l, c_l, c_i],
+    "indm_h16_segreduce": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
+    "indm_h16_scale": [c_p, c_p, c_l, c_f, c_p],
+    "indm_h16_axpby_mixed": [c_p, c_p, c_p, c_l, c_f, c_f, c_p],
+    "indm_h16_upsample2x": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "indm_h16_downsample2x": [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "indm_h16_from_f32": [c_p, c_p, c_l, c_p],
     "indm_h16_to_f32": [c_p, c_p, c_l, c_f, c_p],
     "indm_timer_create": [c_i, c_p],
@@ -147,7 +157,8 @@ _SIGS = {
 }
 _LONG_RET = {"indm_groupnorm_ws_floats", "indm_colreduce_ws_floats", "indm_segreduce_ws_floats", "indm_rowreduce_ws_floats",
              "indm_dsm_ws_floats", "indm_sqnorm_ws_floats", "indm_ires_bwd_act_ws_floats", "indm_iresblock_ws_floats",
-             "indm_pc_step_ws_floats", "indm_hutch_div_ws_floats", "indm_f16_bwd_act_ok", "indm_f16_wgrad_ws_floats"}
+             "indm_pc_step_ws_floats", "indm_hutch_div_ws_floats", "indm_f16_bwd_act_ok", "indm_f16_wgrad_ws_floats",
+             "indm_h16_groupnorm_ws_floats", "indm_h16_segreduce_ws_floats"}
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGS))
 
@@ -1523,38 +1534,54 @@ def to_f32(x, alpha=1.0):
     return y
 
 
-def h16_pack_weights(weights, want_dg=True):
-    """weights: list of fp32 RSCK [KH,KW,Cin,Cout] (or [Cin,Cout]) tensors -> list of (fwd, dg) bf16 packs
-    (fwd [Cout, T*Cin]; dg [Cin, T*Cout] with flipped taps, or None), ONE launch.  The job table is rebuilt per call
-    (the packs are fresh tensors: the forward's autograd nodes keep them alive for the backward)."""
-    import numpy as np
+class H16Packer:
+    """Packed bf16 copies of a fixed list of fp32 weights (RSCK [KH,KW,Cin,Cout] or [Cin,Cout]): persistent destination
+    buffers and a persistent device job table, so that re-packing is ONE kernel launch with no host->device traffic (and
+    can sit inside a captured hipGraph).  pack() returns [(fwd [Cout, T*Cin], dg [Cin, T*Cout] taps flipped)], views of the
+    persistent buffer: every forward call re-packs (the fused optimiser rewrites parameter memory with no version counter
+    to watch), a backward reads the pack of its own forward -- valid as long as no parameter update sits between a forward
+    and its backward."""
+
+    def __init__(self, weights):
+        import numpy as np
+        self.key = tuple(w.data_ptr() for w in weights)
+        dev = weights[0].device
+        shapes = []
+        for w in weights:
+            if w.dim() == 4:
+                shapes.append((w.shape[0] * w.shape[1], w.shape[2], w.shape[3]))
+            else:
+                shapes.append((1, w.shape[0], w.shape[1]))
+        total = sum(T * Ci * Co for T, Ci, Co in shapes)
+        self.flat = torch.empty(2 * total, dtype=torch.bfloat16, device=dev)
+        job = np.zeros(len(weights), dtype=np.dtype([("src", "<u8"), ("fwd", "<u8"), ("dg", "<u8"), ("T", "<i4"), ("Cin", "<i4"),
+                                                     ("Cout", "<i4"), ("tile0", "<i4")]))
+        self.views, off, tiles = [], 0, 0
+        base = self.flat.data_ptr()
+        for i, (w, (T, Ci, Co)) in enumerate(zip(weights, shapes)):
+            n = T * Ci * Co
+            self.views.append((self.flat[off:off + n].view(Co, T * Ci), self.flat[total + off:total + off + n].view(Ci, T * Co)))
+            job[i] = (_ptr(w), base + 2 * off, base + 2 * (total + off), T, Ci, Co, tiles)
+            tiles += T * ((Ci + 31) // 32) * ((Co + 31) // 32)
+            off += n
+        self.tab = torch.from_numpy(job.view(np.uint8).copy()).to(dev)
+        self.n, self.tiles = len(weights), tiles
+
+    def valid_for(self, weights):
+        return self.key == tuple(w.data_ptr() for w in weights)
+
+    def pack(self):
+        _chk(lib().indm_h16_pack_weights(self.tab.data_ptr(), self.n, self.tiles, _stream()), "indm_h16_pack_weights")
+        return self.views
+
+
+def h16_pack_weights(weights):
+    """one-off pack of a list of fp32 weights -> [(fwd, dg)] (tests / weights that belong to no H16Packer)"""
     if not weights:
         return []
-    dev = weights[0].device
-    shapes = []
-    for w in weights:
-        if w.dim() == 4:
-            T, Ci, Co = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
-        else:
-            T, Ci, Co = 1, w.shape[0], w.shape[1]
-        shapes.append((T, Ci, Co))
-    total = sum(T * Ci * Co for T, Ci, Co in shapes)
-    flat = torch.empty(total * (2 if want_dg else 1), dtype=torch.bfloat16, device=dev)
-    job = np.zeros(len(weights), dtype=np.dtype([("src", "<u8"), ("fwd", "<u8"), ("dg", "<u8"), ("T", "<i4"), ("Cin", "<i4"),
-                                                 ("Cout", "<i4"), ("tile0", "<i4")]))
-    out, off, tiles = [], 0, 0
-    base = flat.data_ptr()
-    for i, (w, (T, Ci, Co)) in enumerate(zip(weights, shapes)):
-        n = T * Ci * Co
-        fwd = flat[off:off + n].view(Co, T * Ci)
-        dg = flat[total + off:total + off + n].view(Ci, T * Co) if want_dg else None
-        job[i] = (_ptr(w), base + 2 * off, base + 2 * (total + off) if want_dg else 0, T, Ci, Co, tiles)
-        tiles += T * ((Ci + 31) // 32) * ((Co + 31) // 32)
-        off += n
-        out.append((fwd, dg))
-    tab = to_device(torch.from_numpy(job.view(np.uint8).copy()), dev)
-    _chk(lib().indm_h16_pack_weights(tab.data_ptr(), len(weights), tiles, _stream()), "indm_h16_pack_weights")
-    out[0][0]._h16_keep = tab    # the table must outlive the (asynchronous) launch
+    pk = H16Packer([w.detach() for w in weights])
+    out = pk.pack()
+    out[0][0]._h16_keep = pk    # the job table must outlive the (asynchronous) launch
     return out
 
 
@@ -1593,6 +1620,82 @@ def h16_conv2d_wgrad(x, dy, KH, KW, stride=1, pad=1, alpha=1.0):
     _chk(st, "indm_h16_conv2d_wgrad")
     _H16_STATS["wgrad"] += 1
     return dw
+
+
+def h16_groupnorm_ok(HW, C, G):
+    return bool(lib().indm_h16_groupnorm_ok(HW, C, G))
+
+
+def h16_groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
+    """bf16 x [N,..,C] -> (y bf16, mean, rstd fp32 [N,G]); None when the geometry is not covered"""
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    if not h16_groupnorm_ok(HW, C, G):
+        return None
+    y = torch.empty_like(x)
+    mean = torch.empty((N, G), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    st = lib().indm_h16_groupnorm_fwd(_ptr16(x), _ptr(gamma), _ptr(beta), y.data_ptr(), _ptr(mean), _ptr(rstd), N, HW, C, G,
+                                      eps, act, drop_p, seed, _stream())
+    _chk(st, "indm_h16_groupnorm_fwd")
+    return y, mean, rstd
+
+
+def h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty_like(gamma)
+    dbeta = torch.empty_like(beta)
+    ws = _ws(lib().indm_h16_groupnorm_ws_floats(N, C), x.device)
+    st = lib().indm_h16_groupnorm_bwd(_ptr16(dy), _ptr16(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), dx.data_ptr(),
+                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _ptr(ws), _stream())
+    _chk(st, "indm_h16_groupnorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def h16_segreduce(x, rows_per_seg, alpha=1.0):
+    """bf16 x viewed [rows, C] -> fp32 [rows / rows_per_seg, C] column sums per segment (C % 8 == 0)"""
+    C = x.shape[-1]
+    R = x.numel() // C
+    if R % rows_per_seg:
+        raise RuntimeError("h16_segreduce: rows do not divide into segments")
+    nseg = R // rows_per_seg
+    out = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
+    ws = _ws(lib().indm_h16_segreduce_ws_floats(nseg, rows_per_seg, C), x.device)
+    _chk(lib().indm_h16_segreduce(_ptr16(x), _ptr(out), nseg, rows_per_seg, C, alpha, _ptr(ws), _stream()), "indm_h16_segreduce")
+    return out
+
+
+def h16_scale(x, a):
+    if x.numel() % 8:
+        return (x.float() * a).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    _chk(lib().indm_h16_scale(_ptr16(x), y.data_ptr(), x.numel(), a, _stream()), "indm_h16_scale")
+    return y
+
+
+def h16_axpby_mixed(x32, y16, a, b):
+    """bf16(a * x32 + b * y16)"""
+    if x32.numel() % 8:
+        return (a * x32 + b * y16.float()).to(torch.bfloat16)
+    out = torch.empty_like(y16)
+    _chk(lib().indm_h16_axpby_mixed(_ptr(x32), _ptr16(y16), out.data_ptr(), x32.numel(), a, b, _stream()), "indm_h16_axpby_mixed")
+    return out
+
+
+def h16_upsample2x(x, alpha=1.0):
+    N, H, W, C = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=x.device)
+    _chk(lib().indm_h16_upsample2x(_ptr16(x), y.data_ptr(), N, H, W, C, alpha, _stream()), "indm_h16_upsample2x")
+    return y
+
+
+def h16_downsample2x(x, alpha=0.25):
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=torch.bfloat16, device=x.device)
+    _chk(lib().indm_h16_downsample2x(_ptr16(x), y.data_ptr(), N, H, W, C, alpha, _stream()), "indm_h16_downsample2x")
+    return y
 
 
 # --------------------------------------------------------------------------- block-level drivers (csrc/iresblock.hip)

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import hip, ops
 
 
 # ----------------------------------------------------------------------------- initialisers (models/layers.py:54-91)
@@ -40,7 +40,7 @@ class Conv3x3(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_ch))
 
     def forward(self, x, bias2=None, res=None, alpha=1.0, beta=1.0):
-        return ops.conv2d(x, self.weight, self.bias, bias2, res, 1, 1, alpha, beta)
+        return ops.conv2d(x, self.weight, self.bias, bias2, res, 1, 1, alpha, beta, pack=self.__dict__.pop("h16_pack", None))
 
 
 class Conv1x1(nn.Module):
@@ -54,7 +54,7 @@ class Conv1x1(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_ch))
 
     def forward(self, x, res=None, alpha=1.0, beta=1.0):
-        return ops.conv1x1(x, self.weight, self.bias, None, res, alpha, beta)
+        return ops.conv1x1(x, self.weight, self.bias, None, res, alpha, beta, pack=self.__dict__.pop("h16_pack", None))
 
 
 class Dense(nn.Module):
@@ -217,6 +217,8 @@ class AttnBlockpp(nn.Module):
         self.skip_rescale = skip_rescale
 
     def forward(self, x):
+        if x.dtype == torch.bfloat16:   # H16 storage: the attention block runs on fp32 copies (bf16 MFMA inputs), 6 of 50 blocks
+            return ops.to_bf16(self.forward(ops.to_f32(x)))
         B, H, W, C = x.shape
         T = H * W
         h = self.GroupNorm_0(x).reshape(B * T, C)
@@ -247,13 +249,16 @@ class PyramidDownsample(nn.Module):
             self.Conv_0 = inner
 
     def forward(self, x, res=None, alpha=1.0, beta=1.0):
+        c = self.Conv2d_0 if self.fir else self.Conv_0
         if self.fir:
             x = self.firop.pre_conv_down(x)
-            c = self.Conv2d_0
-            return ops.conv2d(x, c.weight, c.bias, None, res, 2, 0, alpha, beta)
-        x = torch.nn.functional.pad(x, (0, 0, 0, 1, 0, 1))  # NHWC: pad W then H by (0,1)
-        c = self.Conv_0
-        return ops.conv2d(x, c.weight, c.bias, None, res, 2, 0, alpha, beta)
+        else:
+            x = torch.nn.functional.pad(x, (0, 0, 0, 1, 0, 1))  # NHWC: pad W then H by (0,1)
+        pack = c.__dict__.pop("h16_pack", None)
+        if res is not None and res.dtype == torch.bfloat16 and x.dtype != torch.bfloat16:
+            # the first pyramid level convolves the fp32 3-channel image: computed in fp32, joined to the bf16 trunk afterwards
+            return ops.axpby_mixed(ops.conv2d(x, c.weight, c.bias, None, None, 2, 0, alpha, 1.0), res, 1.0, beta)
+        return ops.conv2d(x, c.weight, c.bias, None, res, 2, 0, alpha, beta, pack=pack)
 
 
 class NCSNpp(nn.Module):
@@ -366,7 +371,11 @@ class NCSNpp(nn.Module):
         if not self.config.data.centered:
             h0 = ops.axpby(h0, None, 2.0, 0.0, -1.0)  # 2x-1 (ncsnpp.py:278-280)
         input_pyramid = h0 if self.progressive_input != "none" else None
-        hs = [mods[i](h0)]; i += 1
+        h16 = hip.h16() and x.is_cuda     # bf16 compute mode: the trunk's activations are stored bf16 (csrc/unet_h16*.hip)
+        if h16:
+            self._h16_pack_weights()
+        first = mods[i](h0); i += 1      # 3 -> nf channels: the thin fp32 kernel either way
+        hs = [ops.to_bf16(first) if h16 else first]
         a = ops.INV_SQRT2 if self.skip_rescale else 1.0
         for lvl in range(self.num_resolutions):
             for _ in range(self.num_res_blocks):
@@ -398,11 +407,35 @@ class NCSNpp(nn.Module):
                 h = mods[i](h, temb_act, rng); i += 1
         assert not hs
         h = mods[i](h, silu=True); i += 1
-        h = mods[i](h); i += 1
+        h = mods[i](ops.to_f32(h)); i += 1   # nf -> 3 channels: the skinny-output fp32 path either way
         assert i == len(mods)
         if self.config.model.scale_by_sigma:
             h = ops.scale_rows(h, 1.0 / used_sigmas.float())
         return h if nhwc else ops.to_nchw(h)
+
+    def _h16_pack_weights(self):
+        """bf16 packs of every convolution weight the H16 kernels can take, ONE launch per forward call (hip.H16Packer);
+        each module finds its (fwd, dg) pair in `h16_pack` and hands it to ops.conv2d."""
+        pk = self.__dict__.get("_h16_packer")
+        if pk is None or not pk[0].valid_for([w for _, w in pk[1]]):
+            mods = []
+            for m in self.modules():
+                c = m
+                if isinstance(m, PyramidDownsample):
+                    c = m.Conv2d_0 if m.fir else m.Conv_0
+                elif not isinstance(m, (Conv3x3, Conv1x1)):
+                    continue
+                w = c.weight
+                ci, co = (w.shape[2], w.shape[3]) if w.dim() == 4 else (w.shape[0], w.shape[1])
+                if ci % 32 == 0 and co % 2 == 0:
+                    mods.append((c, w))
+            if not mods:
+                self.__dict__["_h16_packer"] = None
+                return
+            pk = (hip.H16Packer([w.detach() for _, w in mods]), mods)
+            self.__dict__["_h16_packer"] = pk
+        for (c, _), pair in zip(pk[1], pk[0].pack()):
+            c.__dict__["h16_pack"] = pair
 
     # ------------------------------------------------------------------ checkpoint boundary
     def _layout(self, key, t, to_reference):

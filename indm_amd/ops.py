@@ -79,8 +79,10 @@ def linear(x, w, bias=None):
     return y.reshape(*shp[:-1], w.shape[0])
 
 
-def conv1x1(x, w, bias=None, bias2=None, res=None, alpha=1.0, beta=1.0):
+def conv1x1(x, w, bias=None, bias2=None, res=None, alpha=1.0, beta=1.0, pack=None):
     """1x1 convolution / NIN on NHWC as a plain GEMM; w is [Cin, Cout]; bias2 is [N, Cout]."""
+    if x.dtype == torch.bfloat16:
+        return _Conv2dH16.apply(x, w, bias, bias2, res, 1, 0, alpha, beta, pack)
     N, H, W, C = x.shape
     r = res.reshape(-1, w.shape[1]) if res is not None else None
     y = gemm(x.reshape(-1, C), w, bias, bias2, r, alpha=alpha, beta=beta, rows_per_group=H * W, weight_b=True)
@@ -121,8 +123,11 @@ class _Conv2d(Function):
         return dx, dw, dbias, dbias2, dres, None, None, None, None
 
 
-def conv2d(x, w, bias=None, bias2=None, res=None, stride=1, pad=1, alpha=1.0, beta=1.0):
-    """y = alpha*(conv(x, w) + bias + bias2[n]) + beta*res ; x NHWC, w RSCK."""
+def conv2d(x, w, bias=None, bias2=None, res=None, stride=1, pad=1, alpha=1.0, beta=1.0, pack=None):
+    """y = alpha*(conv(x, w) + bias + bias2[n]) + beta*res ; x NHWC, w RSCK.
+    bf16 x (H16 storage): bf16 result; pack = the weight's (fwd, dg) bf16 packs when the caller holds them."""
+    if x.dtype == torch.bfloat16:
+        return _Conv2dH16.apply(x, w, bias, bias2, res, stride, pad, alpha, beta, pack)
     return _Conv2d.apply(x, w, bias, bias2, res, stride, pad, alpha, beta)
 
 
@@ -160,6 +165,145 @@ def conv2d_t(v, w, in_hw, stride=1, pad=1, gate=None):
     return _Conv2dT.apply(v, w, in_hw, stride, pad, gate)
 
 
+# ----------------------------------------------------------------------------- bf16-stored activations ("H16", csrc/unet_h16*.hip)
+class _ToBf16(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return hip.to_bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return hip.to_f32(g)
+
+
+class _ToF32(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return hip.to_f32(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return hip.to_bf16(g)
+
+
+def to_bf16(x):
+    """fp32 -> bf16 activations (the gradient comes back as fp32)"""
+    return x if x.dtype == torch.bfloat16 else _ToBf16.apply(x)
+
+
+def to_f32(x):
+    return x if x.dtype == torch.float32 else _ToF32.apply(x)
+
+
+class _AxpbyMixed(Function):
+    """bf16(a * x + b * y) for an fp32 x and a bf16 y"""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        ctx.ab = (a, b)
+        return hip.h16_axpby_mixed(_c(x), _c(y), a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.ab
+        g = _c(g)
+        gx = hip.to_f32(g, a) if ctx.needs_input_grad[0] else None
+        gy = (g if b == 1.0 else hip.h16_scale(g, b)) if ctx.needs_input_grad[1] else None
+        return gx, gy, None, None
+
+
+def axpby_mixed(x32, y16, a=1.0, b=1.0):
+    return _AxpbyMixed.apply(x32, y16, a, b)
+
+
+class _Conv2dH16(Function):
+    """conv2d / conv1x1 on bf16 NHWC activations: forward, data-grad and weight-grad on the H16 kernels; a geometry they do not
+    cover (channel counts of the mini test configs, strided data-grads) runs on fp32 copies through the fp32-storage kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, bias2, res, stride, pad, alpha, beta, pack):
+        x, res = _c(x), _c(res)
+        w4 = w if w.dim() == 4 else w.view(1, 1, *w.shape)
+        KH, KW, Ci, Co = w4.shape
+        y = None
+        dg = None
+        if Ci % 32 == 0 and Co % 2 == 0:
+            if pack is None:
+                pack = hip.h16_pack_weights([w4])[0]
+            fwd, dg = pack
+            y = hip.h16_conv2d(x, fwd, KH, KW, stride, pad, alpha, _c(bias), _c(bias2), res, beta)
+        if y is None:
+            r32 = None if res is None else hip.to_f32(res)
+            y = hip.to_bf16(hip.conv2d(hip.to_f32(x), _c(w4), stride, pad, alpha, _c(bias), _c(bias2), r32, beta))
+        ctx.save_for_backward(x, w, dg)
+        ctx.cfg = (stride, pad, alpha, beta, bias is not None, bias2 is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, dg = ctx.saved_tensors
+        stride, pad, alpha, beta, has_bias, has_bias2, has_res = ctx.cfg
+        w4 = w if w.dim() == 4 else w.view(1, 1, *w.shape)
+        KH, KW, Ci, Co = w4.shape
+        dy = _c(dy)
+        N, OH, OW, _ = dy.shape
+        dx = dw = dbias = dbias2 = dres = None
+        dy32 = None
+        if ctx.needs_input_grad[0]:
+            if dg is not None and stride == 1 and Co % 32 == 0:
+                dx = hip.h16_conv2d(dy, dg, KH, KW, 1, KH - 1 - pad, alpha)
+            if dx is None:
+                dy32 = hip.to_f32(dy)
+                dx = hip.to_bf16(hip.conv2d_dgrad(dy32, _c(w4), (x.shape[1], x.shape[2]), stride, pad, alpha))
+        if ctx.needs_input_grad[1]:
+            dw = hip.h16_conv2d_wgrad(x, dy, KH, KW, stride, pad, alpha)
+            if dw is None:
+                dy32 = hip.to_f32(dy) if dy32 is None else dy32
+                dw = hip.conv2d_wgrad(hip.to_f32(x), dy32, KH, KW, stride, pad, alpha)
+            dw = dw.view_as(w)
+        if Co % 8 == 0:
+            if has_bias2 and ctx.needs_input_grad[3]:
+                dbias2 = hip.h16_segreduce(dy, OH * OW, alpha)
+            if has_bias and ctx.needs_input_grad[2]:
+                dbias = hip.colreduce(dbias2, None, 0) if dbias2 is not None else hip.h16_segreduce(dy, N * OH * OW, alpha).view(Co)
+        else:
+            dy32 = hip.to_f32(dy) if dy32 is None else dy32
+            if has_bias2 and ctx.needs_input_grad[3]:
+                dbias2 = hip.segreduce(dy32, OH * OW, alpha)
+            if has_bias and ctx.needs_input_grad[2]:
+                dbias = hip.colreduce(dbias2, None, 0) if dbias2 is not None else hip.colreduce(dy32, None, 0, alpha)
+        if has_res and ctx.needs_input_grad[4]:
+            dres = dy if beta == 1.0 else hip.h16_scale(dy, beta)
+        return dx, dw, dbias, dbias2, dres, None, None, None, None, None
+
+
+class _GroupNormH16(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, act, drop_p, seed):
+        x = _c(x)
+        out = hip.h16_groupnorm_fwd(x, gamma, beta, G, eps, act, drop_p, seed)
+        ctx.h16 = out is not None
+        if out is None:
+            y32, mean, rstd = hip.groupnorm_fwd(hip.to_f32(x), gamma, beta, G, eps, act, drop_p, seed)
+            out = (hip.to_bf16(y32), mean, rstd)
+        y, mean, rstd = out
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (G, act, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, act, drop_p, seed = ctx.cfg
+        dy = _c(dy)
+        if ctx.h16:
+            dx, dg, db = hip.h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act, drop_p, seed)
+        else:
+            dx, dg, db = hip.groupnorm_bwd(hip.to_f32(dy), hip.to_f32(x), gamma, beta, mean, rstd, G, act, drop_p, seed)
+            dx = hip.to_bf16(dx)
+        return dx, dg, db, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------- normalisation / softmax
 class _GroupNorm(Function):
     @staticmethod
@@ -181,7 +325,8 @@ class _GroupNorm(Function):
 def group_norm(x, gamma, beta, eps=1e-6, silu=False, drop_p=0.0, seed=0):
     """nn.GroupNorm(min(C/4,32), C, eps) [+ SiLU] [+ dropout], fused (models/layerspp.py:232-279)."""
     C = x.shape[-1]
-    return _GroupNorm.apply(x, gamma, beta, min(C // 4, 32), eps, 1 if silu else 0, float(drop_p), int(seed))
+    fn = _GroupNormH16 if x.dtype == torch.bfloat16 else _GroupNorm
+    return fn.apply(x, gamma, beta, min(C // 4, 32), eps, 1 if silu else 0, float(drop_p), int(seed))
 
 
 class _BatchNormAct(Function):
@@ -526,6 +671,13 @@ class _Resample(Function):
 
     @staticmethod
     def run(kind, x, alpha=None):
+        if x.dtype == torch.bfloat16:   # H16 storage: nearest / mean resampling on bf16 (other kinds never see bf16)
+            if kind not in ("up", "down"):
+                raise RuntimeError(f"_Resample: {kind} on a bfloat16 tensor")
+            if x.shape[-1] % 8:
+                return hip.to_bf16(_Resample.run(kind, hip.to_f32(x), alpha))
+            return hip.h16_upsample2x(x, 1.0 if alpha is None else alpha) if kind == "up" else \
+                hip.h16_downsample2x(x, 0.25 if alpha is None else alpha)
         if kind == "up":
             return hip.upsample2x(x, 1.0 if alpha is None else alpha)
         if kind == "down":
@@ -580,6 +732,9 @@ class _UpFirDn2d(Function):
     @staticmethod
     def forward(ctx, x, kernel, up, down, pad):
         x = _c(x)
+        ctx.h16 = x.dtype == torch.bfloat16     # H16 storage: the FIR runs on an fp32 copy (VE configs only)
+        if ctx.h16:
+            x = hip.to_f32(x)
         px0, px1, py0, py1 = pad
         N, H, W, C = x.shape
         kh, kw = kernel.shape
@@ -588,15 +743,18 @@ class _UpFirDn2d(Function):
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, (H, W), (kw - px0 - 1, W * up[0] - ow * down[0] + px0 - up[0] + 1,
                                      kh - py0 - 1, H * up[1] - oh * down[1] + py0 - up[1] + 1))
-        return y
+        return hip.to_bf16(y) if ctx.h16 else y
 
     @staticmethod
     def backward(ctx, gy):
         (kernel,) = ctx.saved_tensors
         up, down, _, gp = ctx.cfg
         gk = torch.flip(kernel, [0, 1]).contiguous()
-        gx = hip.upfirdn2d(_c(gy), gk, down[0], down[1], up[0], up[1], gp[0], gp[1], gp[2], gp[3], 1)
-        return gx, None, None, None, None
+        gy = _c(gy)
+        if ctx.h16:
+            gy = hip.to_f32(gy)
+        gx = hip.upfirdn2d(gy, gk, down[0], down[1], up[0], up[1], gp[0], gp[1], gp[2], gp[3], 1)
+        return (hip.to_bf16(gx) if ctx.h16 else gx), None, None, None, None
 
 
 def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):

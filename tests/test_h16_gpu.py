@@ -164,3 +164,139 @@ def test_h16_declines_what_it_does_not_cover():
     (fwd, _), = hip.h16_pack_weights([rnd(3, 3, 32, 32).to(DEV)])
     assert hip.h16_conv2d(x, fwd, 3, 3) is None
     assert hip.h16_conv2d_wgrad(x, bf(rnd(2, 6, 6, 32)).to(DEV), 3, 3) is None
+
+
+# ------------------------------------------------------------------------------------------------ HBM-bound H16 passes
+GN_CASES = [(4, 16, 16, 128), (2, 32, 32, 128), (3, 8, 8, 384), (2, 4, 4, 512), (2, 16, 16, 16), (2, 32, 32, 256), (5, 16, 16, 48),
+            (2, 64, 64, 128)]
+
+
+def _gn_ref(x, gamma, beta, G, eps, act):
+    xd = bf(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+    y = F.group_norm(xd, G, gamma.double(), beta.double(), eps)
+    if act:
+        y = y * torch.sigmoid(y)
+    return xd, y
+
+
+@pytest.mark.parametrize("case", GN_CASES)
+@pytest.mark.parametrize("act", [0, 1])
+def test_h16_groupnorm(case, act):
+    N, H, W, C = case
+    G = min(C // 4, 32)
+    x, gamma, beta = rnd(N, H, W, C, seed=1, scale=2.0) + 0.3, rnd(C, seed=2) + 1.0, rnd(C, seed=3)
+    dy = rnd(N, H, W, C, seed=4)
+    assert hip.h16_groupnorm_ok(H * W, C, G)
+    y, mean, rstd = hip.h16_groupnorm_fwd(bf(x).to(DEV), gamma.to(DEV), beta.to(DEV), G, 1e-6, act)
+    xd, yref = _gn_ref(x, gamma, beta, G, 1e-6, act)
+    close_bf16(y, yref.permute(0, 2, 3, 1), 1, name="gn fwd")
+    dx, dg, db = hip.h16_groupnorm_bwd(bf(dy).to(DEV), bf(x).to(DEV), gamma.to(DEV), beta.to(DEV), mean, rstd, G, act)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y2 = F.group_norm(xd, G, gd, bd, 1e-6)
+    if act:
+        y2 = y2 * torch.sigmoid(y2)
+    gx, gg, gb = torch.autograd.grad(y2, (xd, gd, bd), bf(dy).double().permute(0, 3, 1, 2))
+    g, r = dx.cpu().double(), gx.permute(0, 2, 3, 1)
+    scale = r.abs().max().item()
+    assert ((g - r).abs() <= 2.0 ** -7 * r.abs() + 2e-3 * scale).all(), f"gn dx: {(g - r).abs().max().item():.3e} of {scale:.3e}"
+    for a, b, nm in ((dg, gg, "dgamma"), (db, gb, "dbeta")):
+        e = (a.cpu().double() - b).abs().max().item()
+        assert e <= 2e-4 * b.abs().max().item() + 1e-5, f"gn {nm}: {e:.3e}"
+
+
+def test_h16_groupnorm_dropout_mask_is_the_fp32_kernels():
+    """same seed -> same Philox mask as indm_groupnorm_fwd_f32 (forward and backward regenerate it)"""
+    N, H, W, C, G, p, seed = 3, 16, 16, 128, 32, 0.3, 1234567
+    x, gamma, beta = rnd(N, H, W, C, seed=1), rnd(C, seed=2) + 1.0, rnd(C, seed=3)
+    x16 = bf(x).to(DEV)
+    y, mean, rstd = hip.h16_groupnorm_fwd(x16, gamma.to(DEV), beta.to(DEV), G, 1e-6, 1, p, seed)
+    y32, _, _ = hip.groupnorm_fwd(x16.float(), gamma.to(DEV), beta.to(DEV), G, 1e-6, 1, p, seed)
+    assert torch.equal(y == 0, y32.to(torch.bfloat16) == 0)
+    assert (y.float() - y32).abs().max().item() <= 2.0 ** -7 * y32.abs().max().item()
+    dy = bf(rnd(N, H, W, C, seed=4)).to(DEV)
+    dx, dg, db = hip.h16_groupnorm_bwd(dy, x16, gamma.to(DEV), beta.to(DEV), mean, rstd, G, 1, p, seed)
+    dx32, dg32, db32 = hip.groupnorm_bwd(dy.float(), x16.float(), gamma.to(DEV), beta.to(DEV), mean, rstd, G, 1, p, seed)
+    assert (dx.float() - dx32).abs().max().item() <= 2.0 ** -7 * dx32.abs().max().item() + 1e-6
+    assert (dg - dg32).abs().max().item() <= 1e-4 * dg32.abs().max().item()
+    assert (db - db32).abs().max().item() <= 1e-4 * db32.abs().max().item()
+
+
+@pytest.mark.parametrize("shape,rps", [((8, 16, 16, 128), 256), ((4, 32, 32, 256), 1024), ((2, 4, 4, 512), 16), ((3, 8, 8, 40), 192),
+                                       ((128, 4, 4, 256), 16)])
+def test_h16_segreduce(shape, rps):
+    x = bf(rnd(*shape, seed=1)).to(DEV)
+    out = hip.h16_segreduce(x, rps, 0.5)
+    ref = 0.5 * x.cpu().double().reshape(-1, rps, shape[-1]).sum(1)
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() * math.sqrt(rps)
+
+
+def test_h16_elementwise():
+    x = bf(rnd(3, 8, 8, 64, seed=1)).to(DEV)
+    assert torch.equal(hip.h16_scale(x, 0.70710678), (x.float() * 0.70710678).to(torch.bfloat16))
+    y32 = rnd(3, 8, 8, 64, seed=2).to(DEV)
+    assert torch.equal(hip.h16_axpby_mixed(y32, x, 0.5, -2.0), (0.5 * y32 - 2.0 * x.float()).to(torch.bfloat16))
+    up = hip.h16_upsample2x(x, 1.0)
+    assert torch.equal(up, x.repeat_interleave(2, 1).repeat_interleave(2, 2))
+    dn = hip.h16_downsample2x(up, 0.25)
+    assert torch.equal(dn, x)     # mean of four equal bf16 values is exact
+    xr = bf(rnd(2, 16, 16, 32, seed=3)).to(DEV)
+    ref = 0.25 * (xr.float()[:, 0::2, 0::2] + xr.float()[:, 0::2, 1::2] + xr.float()[:, 1::2, 0::2] + xr.float()[:, 1::2, 1::2])
+    assert (hip.h16_downsample2x(xr, 0.25).float() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ the score network on H16 storage
+def _score_cfg(nf=32, image=16, fir=False, prog="none", nrb=1):
+    import golden_utils as gu
+    cfg = gu.mini_config("mini_ve" if fir else "mini_vp_nll")
+    m = cfg.model
+    m.nf, m.num_res_blocks, m.dropout = nf, nrb, 0.0
+    m.fir, m.progressive_input = fir, prog
+    cfg.data.image_size = image
+    m.attn_resolutions = (image // 2,)
+    return cfg
+
+
+@pytest.mark.parametrize("variant", ["vp", "ve_fir_residual"])
+def test_score_network_on_h16_storage_matches_fp32(variant):
+    """NCSN++ (nf = 32: every trunk convolution is on the H16 kernels) forward + backward in bf16 mode with H16 storage vs the
+    fp32 path on the same weights: per-image output within 3 %, parameter gradients within 4 % in the aggregate."""
+    from indm_amd import ncsnpp
+    cfg = _score_cfg(fir=(variant != "vp"), prog="residual" if variant != "vp" else "none")
+    torch.manual_seed(0)
+    net = ncsnpp.NCSNpp(cfg).to(DEV).train()
+    with torch.no_grad():    # init_scale = 0 leaves the residual branches and the output at ~0: give them weight
+        for n_, p_ in net.named_parameters():
+            if p_.abs().max() < 1e-6 and p_.dim() >= 2:
+                p_.copy_(torch.randn_like(p_) * 0.05)
+    B = 4
+    x = torch.randn(B, cfg.data.num_channels, 16, 16, device=DEV)
+    t = (torch.rand(B, device=DEV) * 998 + 1) if variant == "vp" else torch.exp(torch.rand(B, device=DEV) * 3)
+    gout = torch.randn(B, cfg.data.num_channels, 16, 16, device=DEV)
+
+    def run(dtype, h16):
+        hip.set_compute_dtype(dtype)
+        hip.h16(h16)
+        hip.h16_stats(reset=True)
+        for p_ in net.parameters():
+            p_.grad = None
+        out = net(x, t)
+        out.backward(gout)
+        return out.detach().clone(), {n_: p_.grad.detach().clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
+
+    try:
+        o32, g32 = run("f32", True)
+        assert hip.h16_stats()["conv"] == 0
+        o16, g16 = run("bf16", True)
+        st = hip.h16_stats()
+        assert st["conv"] > 20 and st["wgrad"] > 10, st
+        if variant == "vp":
+            assert st["conv_fallback"] == 0 and st["wgrad_fallback"] == 0, st
+    finally:
+        hip.set_compute_dtype("f32")
+        hip.h16(True)
+    rel = ((o16 - o32).flatten(1).norm(dim=1) / o32.flatten(1).norm(dim=1)).max().item()
+    assert rel < 3e-2, f"output differs by {rel:.3e}"
+    num = sum((g16[k] - g32[k]).double().pow(2).sum().item() for k in g32)
+    den = sum(g32[k].double().pow(2).sum().item() for k in g32)
+    assert set(g16) == set(g32)
+    assert math.sqrt(num / den) < 4e-2, f"gradients differ by {math.sqrt(num / den):.3e}"
