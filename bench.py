@@ -30,9 +30,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak of the same guide
 # what "bf16" means in this build: which tensors live in HBM as bf16, which only enter the MFMAs as bf16
 BF16_TENSORS = {
     "stored_bf16": "the flow's [pixels, 512] tensors a1, d1, a2, d2, t3, t2 and the temporaries of its backward, at the scales the "
-                   "F16 kernels cover (C <= 12 channels, >= 1024 pixels: both CIFAR scales, CelebA's first)",
-    "stored_fp32_rounded_to_bf16_at_the_mfma": "everything else that enters a contraction: the score network's activations, weights (fp32 "
-                                               "masters), the flow's 3- / 12-channel side, CelebA's 48-channel scale",
+                   "F16 kernels cover (C <= 12 channels, >= 1024 pixels: both CIFAR scales, CelebA's first); round 6: the score "
+                   "network's trunk -- NHWC activations and their gradients of every ResnetBlockBigGANpp, the skip concatenations, "
+                   "the resampling -- and a per-call bf16 pack of its convolution weights (csrc/unet_h16*.hip)",
+    "stored_fp32_rounded_to_bf16_at_the_mfma": "the score network's attention blocks (6 of 50 blocks: an fp32-storage island), its "
+                                               "first 3 -> nf and last nf -> 3 convolutions, the time embedding; the flow's 3- / "
+                                               "12-channel side, CelebA's 48-channel scale",
     "fp32_always": "accumulators, GroupNorm / BatchNorm statistics, reductions, log-dets, losses, optimiser state, gradients",
     "step_roofline_peak": "2.5 PFLOP/s dense bf16 for the WHOLE step, although part of it is fp32-stored: read `frac` with this list",
 }
@@ -610,7 +613,8 @@ def main():
             "config": {"workload": "configs/vp/CIFAR10/indm_nll.py train step (flow 16-16 idim 512 + NCSN++ nf128), "
                                    f"batch {args.batch}/GPU, 32x32x3, "
                                    + ("fp32" if args.dtype == "f32" else "bf16 MFMA inputs / fp32 accumulate, bf16 storage of "
-                                      "the flow's 512-wide tensors (NOT the fp32 parity configuration)")
+                                      "the flow's 512-wide tensors and of the score network's trunk (NOT the fp32 parity "
+                                      "configuration)")
                                    + ", dropout 0.1, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "last_loss_mean": r["last_loss_mean"], "n_bar": r["n_bar"]},
@@ -646,12 +650,16 @@ def main():
             try:
                 if args.dtype == "f32":
                     # BASELINE configs #3-#5 compute in bf16: the same workload in that mode, as a sub-leg of the default run
-                    b = run_training(args, "vp/CIFAR10/indm_nll", args.batch, "bf16", steps=min(args.steps, 8), warmup=2,
+                    # (round 6: as many timed steps as the headline, at least 16 -- the 8-step leg moved with host noise)
+                    nb = max(args.steps, 16)
+                    b = run_training(args, "vp/CIFAR10/indm_nll", args.batch, "bf16", steps=nb, warmup=3,
                                      rank=0, world=1, dev=dev)
                     out["bf16"] = {"value": b["images_per_s"], "unit": "images/s", "ms_per_step": b["ms_per_step"],
-                                   "ms_per_step_median": b["median_ms"], "steps": min(args.steps, 8), "warmup": 2,
+                                   "ms_per_step_median": b["median_ms"],
+                                   "value_at_median_step": args.batch / (b["median_ms"] * 1e-3), "steps": nb, "warmup": 3,
                                    "roofline": b["roofline"], "last_loss_mean": b["last_loss_mean"], "n_bar": b["n_bar"],
-                                   "dtype": "bf16 MFMA inputs, fp32 accumulate, bf16 storage of the flow's 512-wide tensors",
+                                   "dtype": "bf16 MFMA inputs, fp32 accumulate, bf16 storage of the flow's 512-wide tensors and "
+                                            "of the score network's trunk",
                                    "bf16_tensors": BF16_TENSORS}
                     del b
                     torch.cuda.empty_cache()

@@ -34,6 +34,11 @@ extern "C" {
 int indm_upfirdn2d_f32(const float* x, const float* kernel, float* y, int N, int C, int in_h, int in_w, int kh,
                        int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
                        int pad_y1, int layout, void* stream);
+/* the same op on bf16 tensors (the reference kernel's half instantiation, op/upfirdn2d_kernel.cu:311): fp32 taps and
+ * accumulation, one rounding at the store */
+int indm_upfirdn2d_bf16(const void* x, const float* kernel, void* y, int N, int C, int in_h, int in_w, int kh,
+                       int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                       int pad_y1, int layout, void* stream);
 
 /* y = act(x + bias[(i/step_b) % size_b]) * scale.  Replaces fused.fused_bias_act(input, bias, refer, act, grad,
  * alpha, scale) -- op/fused_bias_act.cpp:11-21, op/fused_bias_act_kernel.cu:18-99 (act 1 linear, 3 leaky-ReLU;
@@ -125,6 +130,9 @@ int indm_conv3x3_thin_act_bf16(const float* x, const float* w, float* a, float* 
 /* Name of the kernel variant this thread's last dense launch (gemm / conv2d_*) was dispatched to, e.g.
  * "glds256x128,gated", "big256x256", "thin128x128", "128x32": bench.py labels its live per-kernel timings with it. */
 const char* indm_igemm_last_variant(void);
+/* "<abi major>.<minor> gfx950": major changes when an existing entry point changes, minor when entry points are added
+ * (the pybind modules of op/upfirdn2d.cpp:22-23 / op/fused_bias_act.cpp:20-21 carry no version; a binding can check this one) */
+const char* indm_version(void);
 
 /* "bf16 compute / fp32 accumulate" variants (BASELINE configs #3-#5): identical contracts and fp32 tensors, but the
  * MFMA inputs are rounded to bf16 (round-to-nearest-even) and multiplied with v_mfma_f32_32x32x16_bf16. */

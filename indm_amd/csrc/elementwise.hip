@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void tap_spread_kernel(const float* __restrict
 INDM_API int indm_sincos_act_fwd_f32(const float* p, float* a, float* d, long n, void* stream) {
   return ew_launch(n, (hipStream_t)stream, [=] __device__(long i) {
     float s, c;
-    sincosf(TWO_PI * p[i], &s, &c);
+    indm_sincos(TWO_PI * p[i], s, c);
     a[i] = s * INV_TWO_PI;
     if (d) d[i] = c;
   });

@@ -339,7 +339,7 @@ __device__ __forceinline__ void epilogue_block(const IgemmParams& p, const Acc& 
     for (int r = 0; r < 16; ++r) {
       const int m = mbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
       float sn, cs;
-      sincosf(SIN_TWO_PI * v[r], &sn, &cs);
+      indm_sincos(SIN_TWO_PI * v[r], sn, cs);
       if ((ok >> r) & 1) {
         C[(long)m * ldc + n] = sn * SIN_INV_TWO_PI;
         p.act_d[(long)m * ldc + n] = cs;
@@ -2043,6 +2043,9 @@ int run(IgemmParams& p, int am, int bm, float* ws, long ws_floats, hipStream_t s
 
 // Kernel variant chosen by this thread's last dense launch ("glds256x128,gated", "big256x256", "thin128x128", ...).
 INDM_API const char* indm_igemm_last_variant(void) { return last_variant; }
+// Library version: "<major>.<minor> gfx950" -- major = the build round that last changed the C ABI's existing entry points,
+// minor = the round that last added entry points (the reference's native ops carry no version: op/upfirdn2d.cpp:22-23)
+INDM_API const char* indm_version(void) { return "6.6 gfx950"; }
 
 // 3x3 / pad 1 / stride 1 convolution with a SKINNY input (the flow's 3-/12-channel edges) as a thin-K GEMM whose operand
 // loader gathers the 9 taps itself (no [pixels, 9C] panel in HBM):

@@ -550,7 +550,7 @@ constexpr int TR_LDW = TK_TN + 4;   // weight slice rows: [28 VW][128 + 4]
 // `s * INV_TWO_PI` expressions as indm_sincos_act_fwd_f32 (bit-identical), one 268 MB write and one 268 MB read less per
 // g-pass at batch 128.  The conversion work (~60 VALU per element) runs next to the stores of a write-bound kernel.
 template <int VW, int NWV, bool BF16, bool UNIT, int JB, bool COAL = false, bool ACT = false>
-__global__ __launch_bounds__(NWV * 64, (VW == 1 ? (ACT ? 3 : 4) : 2)) void thin_conv_rows_kernel(ThinGemmArgs p) {   // (ACT: sincosf spills 14 registers under 128)
+__global__ __launch_bounds__(NWV * 64, (VW == 1 ? 4 : 2)) void thin_conv_rows_kernel(ThinGemmArgs p) {   // (round 6: indm_sincos fits the ACT epilogue into 128 registers; libm sincosf spilled 14)
   __shared__ __attribute__((aligned(16))) float wsm[28 * VW * TR_LDW];
   __shared__ __attribute__((aligned(16))) float bsm[NWV * TK_TN];   // per wave: bias[n] + bias2[image][n] of its current image
   // COAL: a 32 x 32 block leaves through a per-wave LDS transpose (four ds_write_b128 + four ds_read_b128, no workgroup
@@ -688,10 +688,10 @@ __global__ __launch_bounds__(NWV * 64, (VW == 1 ? (ACT ? 3 : 4) : 2)) void thin_
           if constexpr (!UNIT) { v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha; }
           if constexpr (ACT) {   // (a, d) = Sin(v); the cosines wait in the accumulator registers for their turn to leave
             float sn, cs;
-            sincosf(TWO_PI * v.x, &sn, &cs); v.x = sn * INV_TWO_PI; acc[j][4 * a] = cs;
-            sincosf(TWO_PI * v.y, &sn, &cs); v.y = sn * INV_TWO_PI; acc[j][4 * a + 1] = cs;
-            sincosf(TWO_PI * v.z, &sn, &cs); v.z = sn * INV_TWO_PI; acc[j][4 * a + 2] = cs;
-            sincosf(TWO_PI * v.w, &sn, &cs); v.w = sn * INV_TWO_PI; acc[j][4 * a + 3] = cs;
+            indm_sincos(TWO_PI * v.x, sn, cs); v.x = sn * INV_TWO_PI; acc[j][4 * a] = cs;
+            indm_sincos(TWO_PI * v.y, sn, cs); v.y = sn * INV_TWO_PI; acc[j][4 * a + 1] = cs;
+            indm_sincos(TWO_PI * v.z, sn, cs); v.z = sn * INV_TWO_PI; acc[j][4 * a + 2] = cs;
+            indm_sincos(TWO_PI * v.w, sn, cs); v.w = sn * INV_TWO_PI; acc[j][4 * a + 3] = cs;
           }
           if constexpr (COAL) *(float4*)(tsm + (wave * 32 + l31) * 36 + 8 * a + 4 * lhi) = v;
           else *(float4*)(crow + (j0 + j) * 32 + 8 * a) = v;

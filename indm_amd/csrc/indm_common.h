@@ -30,6 +30,25 @@ __device__ __forceinline__ indm_bf16x8 indm_pack_bf16x8(float a, float b, float 
   return __builtin_convertvector(v, indm_bf16x8);
 }
 
+// sin / cos of t (radians) for the flow's Sin activation a = sin(2 pi p) / (2 pi), d = cos(2 pi p), with t = fl(2 pi p) -- the
+// argument the reference hands to torch.sin / torch.cos (flows/resflow/layers/base/activations.py:7-12).  Branch-free:
+// quadrant k = rint(t * 2 / pi), three-term Cody-Waite reduction r = t - k pi/2 (the products are exact for |k| < 2^13,
+// i.e. |p| < 2000), the Cephes sinf / cosf kernels on [-pi/4, pi/4]: <= 1.5 ulp of sin(t) / cos(t) for |p| <= 100 (measured
+// against fp64 on 2 M normal samples per scale; libm's sincosf is in the same error class but costs ~3x the instructions, has
+// a slow path behind branches and spilled 14 registers inside the GEMM epilogues).  Every Sin site of the library calls this
+// one function (the fused epilogues stay bit-identical to the two-step form); -ffp-contract=off keeps the evaluation as written.
+__device__ __forceinline__ void indm_sincos(float t, float& s, float& c) {
+  const float k = __builtin_rintf(t * 0.63661977236758134308f);
+  const float r = ((t - k * 1.5703125f) - k * 4.837512969970703125e-4f) - k * 7.549789948768648e-8f;
+  const float z = r * r;
+  const float sr = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z + -1.6666654611e-1f) * z * r + r;
+  const float cr = ((2.443315711809948e-5f * z + -1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+  const int q = (int)k;
+  const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Opt-in for more than 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize), once per kernel AND per device:

@@ -399,17 +399,30 @@ __global__ __launch_bounds__(256) void h16_colpart_kernel(const i32x4* __restric
     for (int j = 0; j < 8; ++j) part[(long)blockIdx.x * C + 8 * tid + j] = t[j];
   }
 }
-// stage 2: out[s][c] = alpha * sum of the segment's pps partial rows (fixed order)
+// stage 2: out[s][c] = alpha * sum of the segment's pps partial rows.  One workgroup per (segment, 64 columns): four row lanes
+// each add every fourth partial row (eight loads in flight), LDS folds the four -- a fixed order, deterministic
 __global__ __launch_bounds__(256) void h16_colfinal_kernel(const float* __restrict__ part, float* __restrict__ out, long nseg,
                                                             int pps, int C, float alpha) {
-  const long total = nseg * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long s = i / C;
-    const int c = (int)(i - s * C);
-    float a = 0.f;
-    for (int p = 0; p < pps; ++p) a += part[(s * pps + p) * C + c];
-    out[i] = alpha * a;
+  __shared__ float sh[256];
+  const int cb = (C + 63) / 64;
+  const long s = blockIdx.x / cb;
+  const int c = (blockIdx.x % cb) * 64 + (threadIdx.x & 63), ty = threadIdx.x >> 6;
+  float a = 0.f;
+  if (c < C) {
+    const float* q = part + s * pps * (long)C + c;
+    int p = ty;
+    for (; p + 28 < pps; p += 32) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = q[(long)(p + 4 * j) * C];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a += v[j];
+    }
+    for (; p < pps; p += 4) a += q[(long)p * C];
   }
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (ty == 0 && c < C) out[s * C + c] = alpha * ((sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]));
 }
 static long seg_parts(long nseg, long rps, int C) {   // partial rows per segment (a power of two dividing rps)
   long S = 1;
@@ -580,7 +593,7 @@ INDM_API int indm_h16_segreduce(const void* x, float* out, long nseg, long rps, 
   const long S = seg_parts(nseg, rps, C);
   hipLaunchKernelGGL(h16_colpart_kernel, dim3((unsigned)(nseg * S)), dim3(256), 0, st, (const i32x4*)x, ws, nseg * rps, C, rps / S);
   INDM_CHECK_LAUNCH();
-  hipLaunchKernelGGL(h16_colfinal_kernel, dim3(ew_grid(nseg * C, 256)), dim3(256), 0, st, ws, out, nseg, (int)S, C, alpha);
+  hipLaunchKernelGGL(h16_colfinal_kernel, dim3((unsigned)(nseg * ((C + 63) / 64))), dim3(256), 0, st, ws, out, nseg, (int)S, C, alpha);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

@@ -16,10 +16,36 @@
 
 namespace {
 
+// I/O element types: float, or bf16 (the reference kernel's half instantiation, op/upfirdn2d_kernel.cu:311, in the storage type
+// of this library's bf16 mode): taps and accumulation are fp32 either way, the LDS patch holds fp32
+struct bf16_t { unsigned short v; };
+__device__ __forceinline__ float ld1(const float* q) { return *q; }
+__device__ __forceinline__ float ld1(const bf16_t* q) { return __uint_as_float((unsigned)q->v << 16); }
+__device__ __forceinline__ void st1(float* q, float v) { *q = v; }
+__device__ __forceinline__ void st1(bf16_t* q, float v) {
+  const __bf16 h = (__bf16)v;
+  q->v = *(const unsigned short*)&h;
+}
+__device__ __forceinline__ float4 ld4(const float* q) { return *(const float4*)q; }
+__device__ __forceinline__ float4 ld4(const bf16_t* q) {
+  const uint2 w = *(const uint2*)q;
+  return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                     __uint_as_float(w.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* q, const float4& v) { *(float4*)q = v; }
+__device__ __forceinline__ void st4(bf16_t* q, const float4& v) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2_t ha = __builtin_convertvector(a, bf16x2_t), hb = __builtin_convertvector(b, bf16x2_t);
+  *(uint2*)q = make_uint2(*(const unsigned*)&ha, *(const unsigned*)&hb);
+}
+
+template <class T>
 struct UfdParams {
-  const float* x;
+  const T* x;
   const float* k;  // [kh, kw]
-  float* y;
+  T* y;
   int N, C, in_h, in_w, out_h, out_w;
   int up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw;
   long xs_n, xs_c, xs_h, xs_w;  // input strides (elements)
@@ -33,7 +59,8 @@ __device__ __forceinline__ int floor_div(int a, int b) {
   return q;
 }
 
-__global__ __launch_bounds__(256) void upfirdn2d_kernel(UfdParams p) {
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(UfdParams<T> p) {
   __shared__ float sk[64];
   const int ktaps = p.kh * p.kw;
   for (int i = threadIdx.x; i < ktaps; i += blockDim.x) {
@@ -57,7 +84,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UfdParams p) {
       c = (int)(r % p.C);
       n = (int)(r / p.C);
     }
-    const float* xb = p.x + n * p.xs_n + c * p.xs_c;
+    const T* xb = p.x + n * p.xs_n + c * p.xs_c;
     // position in the zero-inserted, padded signal: u = o*down + k - pad ; source = u/up when divisible
     const int uy0 = oy * p.down_y - p.pad_y0, ux0 = ox * p.down_x - p.pad_x0;
     float acc = 0.f;
@@ -71,10 +98,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(UfdParams p) {
         if (ux < 0) continue;
         const int ix = ux / p.up_x;
         if (ix * p.up_x != ux || ix >= p.in_w) continue;
-        acc += xb[iy * p.xs_h + ix * p.xs_w] * sk[ky * p.kw + kx];
+        acc += ld1(xb + iy * p.xs_h + ix * p.xs_w) * sk[ky * p.kw + kx];
       }
     }
-    p.y[n * p.ys_n + c * p.ys_c + oy * p.ys_h + ox * p.ys_w] = acc;
+    st1(p.y + n * p.ys_n + c * p.ys_c + oy * p.ys_h + ox * p.ys_w, acc);
   }
 }
 
@@ -86,7 +113,8 @@ __device__ __forceinline__ int pos_mod(int a, int b) {
 }
 // ut_sh = log2(output tile edge): 16 x 16 outputs when the patch stays small (up-sampling / same-size filtering), 8 x 8
 // for decimation (the patch is 19 x 19 pixels there)
-__global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(UfdParams p, int tiles_x, int tiles_y, int cchunks, int IH, int IW,
+template <class T>
+__global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(UfdParams<T> p, int tiles_x, int tiles_y, int cchunks, int IH, int IW,
                                                              int ut_sh) {
   extern __shared__ __attribute__((aligned(16))) float patch[];  // [IH][IW][UC]
   __shared__ float sk[64];
@@ -104,14 +132,14 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(UfdParams p, int ti
   const int oy0 = ty * UT, ox0 = tx * UT, c0 = cc * UC;
   const int nc4 = min(UC, p.C - c0) >> 2;                           // float4 groups of this chunk (C % 4 == 0)
   const int iy0 = floor_div(oy0 * p.down_y - p.pad_y0, p.up_y), ix0 = floor_div(ox0 * p.down_x - p.pad_x0, p.up_x);
-  const float* xb = p.x + (long)n * p.xs_n + c0;
+  const T* xb = p.x + (long)n * p.xs_n + c0;
   for (int i = threadIdx.x; i < IH * IW * (UC / 4); i += 256) {
     const int c4 = i & (UC / 4 - 1), pix = i >> 3;
     const int r = pix / IW, c = pix - r * IW;
     const int iy = iy0 + r, ix = ix0 + c;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < nc4 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
-      v = *(const float4*)(xb + (long)iy * p.xs_h + (long)ix * p.xs_w + 4 * c4);
+      v = ld4(xb + (long)iy * p.xs_h + (long)ix * p.xs_w + 4 * c4);
     *(float4*)(patch + (long)pix * UC + 4 * c4) = v;
   }
   __syncthreads();
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(UfdParams p, int ti
         acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
       }
     }
-    *(float4*)(p.y + (long)n * p.ys_n + (long)oy * p.ys_h + (long)ox * p.ys_w + c0 + 4 * c4) = acc;
+    st4(p.y + (long)n * p.ys_n + (long)oy * p.ys_h + (long)ox * p.ys_w + c0 + 4 * c4, acc);
   }
 }
 
@@ -167,12 +195,13 @@ __global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __rest
 
 // Generic-stride upfirdn2d.  out_h = (in_h*up_y + pad_y0 + pad_y1 - kh)/down_y + 1 (floor), same for w;
 // pads may be negative (crop).  layout: 0 = planar [N,C,H,W] (reference view), 1 = NHWC.
-INDM_API int indm_upfirdn2d_f32(const float* x, const float* kernel, float* y, int N, int C, int in_h, int in_w,
-                                int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
-                                int pad_y0, int pad_y1, int layout, void* stream) {
+template <class T>
+static int upfirdn2d_impl(const T* x, const float* kernel, T* y, int N, int C, int in_h, int in_w,
+                          int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                          int pad_y0, int pad_y1, int layout, void* stream) {
   if (N < 0 || C <= 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || kh * kw > 64) return INDM_E_SHAPE;
   if (up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1) return INDM_E_ARG;
-  UfdParams p;
+  UfdParams<T> p;
   p.x = x; p.k = kernel; p.y = y; p.N = N; p.C = C; p.in_h = in_h; p.in_w = in_w;
   p.out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;
   p.out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
@@ -190,7 +219,7 @@ INDM_API int indm_upfirdn2d_f32(const float* x, const float* kernel, float* y, i
   }
   const long total = (long)N * C * p.out_h * p.out_w;
   if (total == 0) return INDM_OK;
-  if (layout == 1 && (C & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+  if (layout == 1 && (C & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & (4 * sizeof(T) - 1)) == 0) {
     // input rows / columns an output tile touches (the accumulation order over taps equals the generic kernel's)
     int ut_sh = 4;
     int IH = (((1 << ut_sh) - 1) * down_y + kh - 1) / up_y + 2, IW = (((1 << ut_sh) - 1) * down_x + kw - 1) / up_x + 2;
@@ -205,16 +234,30 @@ INDM_API int indm_upfirdn2d_f32(const float* x, const float* kernel, float* y, i
       const int tiles_x = cdiv(p.out_w, UT), tiles_y = cdiv(p.out_h, UT), cchunks = cdiv(C, UC);
       const long blocks = (long)N * tiles_y * tiles_x * cchunks;
       if (blocks < (1L << 31)) {
-        hipLaunchKernelGGL(upfirdn2d_tile_kernel, dim3((unsigned)blocks), dim3(256), bytes, (hipStream_t)stream, p, tiles_x,
+        hipLaunchKernelGGL(upfirdn2d_tile_kernel<T>, dim3((unsigned)blocks), dim3(256), bytes, (hipStream_t)stream, p, tiles_x,
                            tiles_y, cchunks, IH, IW, ut_sh);
         INDM_CHECK_LAUNCH();
         return INDM_OK;
       }
     }
   }
-  hipLaunchKernelGGL(upfirdn2d_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(upfirdn2d_kernel<T>, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
+}
+
+INDM_API int indm_upfirdn2d_f32(const float* x, const float* kernel, float* y, int N, int C, int in_h, int in_w,
+                                int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                                int pad_y0, int pad_y1, int layout, void* stream) {
+  return upfirdn2d_impl<float>(x, kernel, y, N, C, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                               pad_y1, layout, stream);
+}
+// the same op on bf16 tensors (x, y: bf16; taps fp32; fp32 accumulation, one rounding at the store)
+INDM_API int indm_upfirdn2d_bf16(const void* x, const float* kernel, void* y, int N, int C, int in_h, int in_w,
+                                 int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                                 int pad_y0, int pad_y1, int layout, void* stream) {
+  return upfirdn2d_impl<bf16_t>((const bf16_t*)x, kernel, (bf16_t*)y, N, C, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y,
+                                pad_x0, pad_x1, pad_y0, pad_y1, layout, stream);
 }
 
 // y = act(x + bias[(i/step_b) % size_b]) * scale ; act 1 = linear, 3 = leaky-ReLU(alpha);

@@ -54,6 +54,7 @@ _SIGS = {
     "indm_segreduce_ws_floats": [c_l, c_l, c_i],
     "indm_segreduce_f32": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
     "indm_igemm_last_variant": [],
+    "indm_version": [],
     "indm_conv3x3_thin_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_conv3x3_thin_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_p],
     "indm_gemm_ires_bwd_act_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_l, c_l, c_l, c_p, c_p],
@@ -120,6 +121,8 @@ _SIGS = {
     "indm_bn_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p],
     "indm_upfirdn2d_f32": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                            c_p],
+    "indm_upfirdn2d_bf16": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                            c_p],
     "indm_fused_bias_act_f32": [c_p, c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_f, c_p],
     "indm_iresblock_ws_floats": [c_i, c_i, c_i, c_i, c_i, c_i],
     "indm_iresblock_fwd_logdet": [c_p, c_p],
@@ -175,7 +178,7 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = c_l if name in _LONG_RET else (ctypes.c_char_p if name == "indm_igemm_last_variant" else c_i)
+            fn.restype = c_l if name in _LONG_RET else (ctypes.c_char_p if name in ("indm_igemm_last_variant", "indm_version") else c_i)
         _lib = L
     return _lib
 
@@ -243,6 +246,11 @@ def _ws(nfloats, device):
 
 
 SPLITK_WS_FLOATS = 1 << 25  # 128 MiB of fp32 partial slabs for weight-grad split-K
+
+
+def version():
+    """indm_version() of the loaded library, e.g. '6.6 gfx950'"""
+    return lib().indm_version().decode()
 
 
 def debug_state():
@@ -1355,7 +1363,11 @@ def upfirdn2d(x, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad
     oh = (H * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
     ow = (W * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
     shape = (N, C, oh, ow) if layout == 0 else (N, oh, ow, C)
-    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    y = torch.empty(shape, dtype=x.dtype, device=x.device)
+    if x.dtype == torch.bfloat16:   # bf16 in, bf16 out (fp32 taps and accumulation)
+        _chk(lib().indm_upfirdn2d_bf16(_ptr16(x), _ptr(kernel), y.data_ptr(), N, C, H, W, kh, kw, up_x, up_y, down_x, down_y,
+                                       pad_x0, pad_x1, pad_y0, pad_y1, layout, _stream()), "indm_upfirdn2d_bf16")
+        return y
     _chk(lib().indm_upfirdn2d_f32(_ptr(x), _ptr(kernel), _ptr(y), N, C, H, W, kh, kw, up_x, up_y, down_x, down_y,
                                   pad_x0, pad_x1, pad_y0, pad_y1, layout, _stream()), "indm_upfirdn2d_f32")
     return y

@@ -731,10 +731,7 @@ class _UpFirDn2d(Function):
 
     @staticmethod
     def forward(ctx, x, kernel, up, down, pad):
-        x = _c(x)
-        ctx.h16 = x.dtype == torch.bfloat16     # H16 storage: the FIR runs on an fp32 copy (VE configs only)
-        if ctx.h16:
-            x = hip.to_f32(x)
+        x = _c(x)                               # fp32, or bf16 (H16 storage: indm_upfirdn2d_bf16)
         px0, px1, py0, py1 = pad
         N, H, W, C = x.shape
         kh, kw = kernel.shape
@@ -743,18 +740,15 @@ class _UpFirDn2d(Function):
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, (H, W), (kw - px0 - 1, W * up[0] - ow * down[0] + px0 - up[0] + 1,
                                      kh - py0 - 1, H * up[1] - oh * down[1] + py0 - up[1] + 1))
-        return hip.to_bf16(y) if ctx.h16 else y
+        return y
 
     @staticmethod
     def backward(ctx, gy):
         (kernel,) = ctx.saved_tensors
         up, down, _, gp = ctx.cfg
         gk = torch.flip(kernel, [0, 1]).contiguous()
-        gy = _c(gy)
-        if ctx.h16:
-            gy = hip.to_f32(gy)
-        gx = hip.upfirdn2d(gy, gk, down[0], down[1], up[0], up[1], gp[0], gp[1], gp[2], gp[3], 1)
-        return (hip.to_bf16(gx) if ctx.h16 else gx), None, None, None, None
+        gx = hip.upfirdn2d(_c(gy), gk, down[0], down[1], up[0], up[1], gp[0], gp[1], gp[2], gp[3], 1)
+        return gx, None, None, None, None
 
 
 def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):

@@ -328,12 +328,19 @@ def test_full_size_step_at_the_per_rank_shard_matches_oracle(name, B):
         assert hip.compute_dtype() == "bf16" and hip.block_drivers() and hip.storage_dtype() == "bf16"
         score.train(); fl.train()
         hip.f16_stats(reset=True)
+        hip.h16_stats(reset=True)
         rng = ReplayRng(events, dev)
         got16 = step_fn(state, fstate, x.to(dev), rng=rng)
         assert rng.done()
         stats = hip.f16_stats(reset=True)
+        ustats = hip.h16_stats(reset=True)
     finally:
         hip.set_compute_dtype("f32")
+    # round 6: the score network's trunk ran on bf16-STORED activations (csrc/unet_h16*.hip): convolutions / data grads /
+    # weight grads on the H16 kernels; only the strided data grads of the VE input pyramid may fall back to fp32 copies
+    print(f"{name}: H16 launches {ustats}")
+    assert hip.h16() is False and ustats["conv"] >= 150 and ustats["wgrad"] >= 80, ustats
+    assert ustats["conv_fallback"] <= (8 if S == 32 else 0) and ustats["wgrad_fallback"] == 0, ustats
     if S == 32:
         assert stats == {(3, 32, 32): [16, 0], (12, 16, 16): [16, 0]}, stats
     else:
@@ -390,10 +397,13 @@ def test_bf16_storage_loss_curve_on_both_scales_vs_oracle():
             rec = RecordingRng()
             want = O.flow_step_fn_nll(cfg, O.get_sde(cfg), ost, ofst, x, rec)
             hip.f16_stats(reset=True)
+            hip.h16_stats(reset=True)
             rng = ReplayRng(rec.events, dev)
             got = step_fn(state, fstate, x.to(dev), rng=rng)
             assert rng.done()
             assert hip.f16_stats(reset=True) == {(3, 32, 32): [16, 0], (12, 16, 16): [16, 0]}
+            ustats = hip.h16_stats(reset=True)   # ... and the score network's trunk on bf16-stored activations (round 6)
+            assert ustats["conv"] >= 150 and ustats["wgrad"] >= 80 and ustats["conv_fallback"] == 0 and ustats["wgrad_fallback"] == 0, ustats
             for nm, a, b in zip(("loss", "score", "flow", "logp"), got, want):
                 a, b = a.double().cpu(), b.double()
                 assert torch.isfinite(a).all()

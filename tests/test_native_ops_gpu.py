@@ -65,3 +65,20 @@ def test_bench_rccl_path_single_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_upfirdn2d_bf16_matches_the_fp32_kernel_on_the_same_values():
+    """indm_upfirdn2d_bf16 (the reference kernel's half instantiation, op/upfirdn2d_kernel.cu:311): bf16 in / out, fp32 taps and
+    accumulation -- equal to rounding the fp32 kernel's result on the bf16-rounded input, on the tile and on the generic path"""
+    import torch
+    from indm_amd import hip
+    g = torch.Generator().manual_seed(5)
+    k = torch.tensor([1., 3., 3., 1.])
+    k = (torch.outer(k, k) / 64).cuda()
+    for shape, cfg in (((2, 16, 16, 32), (2, 2, 1, 1, 2, 1, 2, 1)), ((3, 16, 16, 64), (1, 1, 2, 2, 1, 1, 1, 1)),
+                       ((2, 9, 9, 6), (1, 1, 1, 1, 2, 1, 2, 1)), ((1, 8, 8, 128), (2, 2, 1, 1, 2, 1, 2, 1))):
+        x = (torch.rand(*shape, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+        y16 = hip.upfirdn2d(x, k * (cfg[0] * cfg[1]), *cfg, 1)
+        y32 = hip.upfirdn2d(x.float(), k * (cfg[0] * cfg[1]), *cfg, 1)
+        assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16)), shape
+    assert hip.version().endswith("gfx950")

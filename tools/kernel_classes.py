@@ -5,6 +5,12 @@ import sys
 
 path, steps = sys.argv[1], float(sys.argv[2])
 CLASSES = [
+    ("H16 score net: conv / dgrad / 1x1", lambda n: "h16_conv_kernel" in n),
+    ("H16 score net: weight grads", lambda n: "h16_wgrad_kernel" in n),
+    ("H16 score net: split-K reduce", lambda n: "h16_reduce_kernel" in n),
+    ("H16 score net: GroupNorm", lambda n: "h16_gn_" in n),
+    ("H16 score net: bias-grad sums", lambda n: "h16_col" in n),
+    ("H16 score net: pack / convert / resample", lambda n: "h16_" in n),
     ("F16 flow: 64-row GEMM / chain / thin-N", lambda n: "f16_rows_kernel" in n),
     ("F16 flow: thin conv", lambda n: "f16_thin_conv" in n),
     ("F16 flow: weight grads", lambda n: "f16_thin_wgrad" in n or "f16_wgrad" in n),
