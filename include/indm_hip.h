@@ -153,16 +153,18 @@ int indm_conv2d_wgrad_bf16(const float* x, const float* dy, float* dw, int Nimg,
 /* ---- normalisation / softmax / reductions --------------------------------------------------------------- */
 
 /* GroupNorm(G, C, eps) [+SiLU] [+Philox dropout], fused.  Replaces nn.GroupNorm + nn.SiLU + nn.Dropout at
- * models/layerspp.py:232,244,256,277-278, models/layers.py:38-39.  act 0 none / 1 SiLU. */
+ * models/layerspp.py:232,244,256,277-278, models/layers.py:38-39.  act 0 none / 1 SiLU.
+ * The Philox key of the dropout mask is seed + (seed_dev ? *seed_dev : 0): seed_dev (may be NULL) points at a uint64 in DEVICE
+ * memory, read when the kernel runs -- a launch captured into a hipGraph draws a fresh mask on every replay. */
 long indm_groupnorm_ws_floats(int N, int HW, int C, int G);
 int indm_groupnorm_fused(int HW, int C, int G); /* 1: single-pass register-resident kernels for this geometry, 0: stats / finalize / apply */
 int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                            float* rstd, int N, int HW, int C, int G, float eps, int act, float drop_p,
-                           unsigned long long seed, float* ws, void* stream);
+                           unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream);
 int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
                            const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, int N,
-                           int HW, int C, int G, int act, float drop_p, unsigned long long seed, float* ws,
-                           void* stream);
+                           int HW, int C, int G, int act, float drop_p, unsigned long long seed,
+                           const unsigned long long* seed_dev, float* ws, void* stream);
 
 /* Training-mode BatchNorm2d (+ELU) of the flow encoder: nnet/resnets/resnet_batchnorm.py:23-76. */
 int indm_bn_stats_f32(const float* x, float* mean, float* var, float* rstd, long R, int C, float eps, float* ws,
@@ -313,10 +315,11 @@ int indm_h16_to_f32(const void* x, float* y, long n, float alpha, void* stream);
 int indm_h16_groupnorm_ok(int HW, int C, int G);
 long indm_h16_groupnorm_ws_floats(int N, int C);
 int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                           int N, int HW, int C, int G, float eps, int act, float drop_p, unsigned long long seed, void* stream);
+                           int N, int HW, int C, int G, float eps, int act, float drop_p, unsigned long long seed,
+                           const unsigned long long* seed_dev, void* stream);
 int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                            const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G, int act,
-                           float drop_p, unsigned long long seed, float* ws, void* stream);
+                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream);
 /* out[s][c] = alpha * sum_{r < rps} x[(s rps + r) C + c], x bf16 [nseg rps, C], out fp32 [nseg, C]: the bias and per-image
  * temb-bias gradients of the convolutions (layerspp.py:262-263); C % 8 == 0, C <= 2048; ws: indm_h16_segreduce_ws_floats floats */
 long indm_h16_segreduce_ws_floats(long nseg, long rps, int C);

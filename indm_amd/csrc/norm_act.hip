@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                         const float* __restrict__ beta, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ y,
                                                         long total4, int HW, int C, int G, int act, float drop_p,
-                                                        uint64_t seed) {
+                                                        uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   const int C4 = C >> 2;
   const int cpg = C / G;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -126,7 +127,9 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ gpart, float* __restrict__ cpart, int HW,
-                                                            int C, int G, int S, int act, float drop_p, uint64_t seed) {
+                                                            int C, int G, int S, int act, float drop_p, uint64_t seed,
+                                                            const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   extern __shared__ float sh[];  // [2][pstride][C] partials, then [2][C] channel sums
   const int n = blockIdx.y, s = blockIdx.x;
   const int C4 = C >> 2, cpg = C / G;
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gsum, float* __restrict__ dx,
                                                             long total4, int HW, int C, int G, int act, float drop_p,
-                                                            uint64_t seed, float inv_cnt) {
+                                                            uint64_t seed, float inv_cnt, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   const int C4 = C >> 2, cpg = C / G;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
@@ -297,7 +301,8 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_kernel(const float* __restri
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int N, int HW,
                                                             int C, int G, int GS, float eps, int act, float drop_p,
-                                                            uint64_t seed) {
+                                                            uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   __shared__ float sh[4 * GNF_MAXG * 2];   // [wave][group][sum, sum of squares]
   // every kernel argument is loaded HERE, not where it is first used (hipcc otherwise issues the scalar loads of gamma /
   // beta / y / mean / rstd after the statistics phase; see tools/late_kernarg_scan.py and DESIGN.md section 6)
@@ -407,7 +412,8 @@ __global__ __launch_bounds__(256) void gn_fused_fwd_serial_kernel(const float* _
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int N, int HW,
                                                             int C, int G, int GS, float eps, int act, float drop_p,
-                                                            uint64_t seed) {
+                                                            uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   if constexpr (PIN) INDM_PIN_ARGS9(gamma, beta, y, mean, rstd, eps, act, drop_p, seed);   // INDM_GN_FUSED=3: the A/B arm "serial fold, arguments loaded at the start"
   __shared__ float sh[2 * 256];
   __shared__ float st[2 * GNF_MAXG];
@@ -480,7 +486,9 @@ __global__ __launch_bounds__(256) void gn_fused_bwd_kernel(const float* __restri
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ dx, float* __restrict__ cpart, int N, int HW,
-                                                            int C, int G, int GS, int act, float drop_p, uint64_t seed) {
+                                                            int C, int G, int GS, int act, float drop_p, uint64_t seed,
+                                                            const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   __shared__ float sh[4 * 8 * 8];         // [wave][quad][4: sum d, 4: sum d*xh]
   INDM_PIN_ARGS9(gamma, beta, mean, rstd, dx, cpart, act, drop_p, seed);
   __shared__ float chs[2 * 32];           // channel sums of the slab (CS <= 32)
@@ -870,10 +878,12 @@ INDM_API int indm_groupnorm_fused(int HW, int C, int G) {
 // y = dropout(act(GroupNorm(x)));  x,y: [N, HW, C];  mean,rstd: [N, G] (saved for backward)
 INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y,
                                     float* mean, float* rstd, int N, int HW, int C, int G, float eps, int act,
-                                    float drop_p, unsigned long long seed, float* ws, void* stream) {
+                                    float drop_p, unsigned long long seed, const unsigned long long* seed_dev_, float* ws,
+                                    void* stream) {
   if (N <= 0) return INDM_OK;
   if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / 4) > 256) return INDM_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const uint64_t* seed_dev = (const uint64_t*)seed_dev_;
   const GnFused ff = gn_fused_geom(HW, C, G);
   if (ff.nf4) {   // single pass: one workgroup per (image, group block) keeps its slab in registers
     const dim3 grid((G / ff.gs) * N), block(ff.bs);
@@ -881,11 +891,11 @@ INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const fl
 #define GNF_FWD(NF)                                                                                                          \
   do {                                                                                                                       \
     if (serial == 2) hipLaunchKernelGGL((gn_fused_fwd_serial_kernel<NF, false>), grid, block, 0, st, x, gamma, beta, y, mean,  \
-                                        rstd, N, HW, C, G, ff.gs, eps, act, drop_p, (uint64_t)seed);                         \
+                                        rstd, N, HW, C, G, ff.gs, eps, act, drop_p, (uint64_t)seed, seed_dev);                         \
     else if (serial == 3) hipLaunchKernelGGL((gn_fused_fwd_serial_kernel<NF, true>), grid, block, 0, st, x, gamma, beta, y,   \
-                                             mean, rstd, N, HW, C, G, ff.gs, eps, act, drop_p, (uint64_t)seed);              \
+                                             mean, rstd, N, HW, C, G, ff.gs, eps, act, drop_p, (uint64_t)seed, seed_dev);              \
     else hipLaunchKernelGGL(gn_fused_fwd_kernel<NF>, grid, block, 0, st, x, gamma, beta, y, mean, rstd, N, HW, C, G, ff.gs,  \
-                            eps, act, drop_p, (uint64_t)seed);                                                               \
+                            eps, act, drop_p, (uint64_t)seed, seed_dev);                                                               \
   } while (0)
     switch (ff.nf4) {
       case 1: GNF_FWD(1); break;
@@ -907,7 +917,7 @@ INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const fl
   INDM_CHECK_LAUNCH();
   const long total4 = (long)N * HW * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, st, x, gamma, beta, mean, rstd, y,
-                     total4, HW, C, G, act, drop_p, (uint64_t)seed);
+                     total4, HW, C, G, act, drop_p, (uint64_t)seed, seed_dev);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }
@@ -915,15 +925,16 @@ INDM_API int indm_groupnorm_fwd_f32(const float* x, const float* gamma, const fl
 INDM_API int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* beta,
                                     const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
                                     int N, int HW, int C, int G, int act, float drop_p, unsigned long long seed,
-                                    float* ws, void* stream) {
+                                    const unsigned long long* seed_dev_, float* ws, void* stream) {
   if (N <= 0) return INDM_OK;
   if (C % 4 != 0 || G <= 0 || C % G != 0 || (C / 4) > 256) return INDM_E_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  const uint64_t* seed_dev = (const uint64_t*)seed_dev_;
   const GnFused ff = gn_fused_geom(HW, C, G);
   if (ff.nf4) {   // single pass over dy and x + a [N, C] column reduce for dgamma / dbeta
     const dim3 grid((G / ff.gs) * N), block(ff.bs);
 #define GNF_BWD(NF) hipLaunchKernelGGL(gn_fused_bwd_kernel<NF>, grid, block, 0, st, dy, x, gamma, beta, mean, rstd, dx, ws, N, HW, \
-                                       C, G, ff.gs, act, drop_p, (uint64_t)seed)
+                                       C, G, ff.gs, act, drop_p, (uint64_t)seed, seed_dev)
     switch (ff.nf4) {
       case 1: GNF_BWD(1); break;
       case 2: GNF_BWD(2); break;
@@ -942,7 +953,7 @@ INDM_API int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float
   float* cpart = gpart + (long)N * S * 2 * G;
   float* gsum = cpart + (long)N * S * 2 * C;
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(S, N), dim3(256), (2 * (256 / (C / 4)) * C + 2 * C) * sizeof(float), st, dy, x, gamma,
-                     beta, mean, rstd, gpart, cpart, HW, C, G, S, act, drop_p, (uint64_t)seed);
+                     beta, mean, rstd, gpart, cpart, HW, C, G, S, act, drop_p, (uint64_t)seed, seed_dev);
   INDM_CHECK_LAUNCH();
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N * G + C), dim3(256), 0, st, gpart, cpart, gsum, dgamma, dbeta, N, C,
                      G, S);
@@ -950,7 +961,7 @@ INDM_API int indm_groupnorm_bwd_f32(const float* dy, const float* x, const float
   const long total4 = (long)N * HW * C / 4;
   const float inv_cnt = 1.f / ((float)HW * (float)(C / G));
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(total4, 256)), dim3(256), 0, st, dy, x, gamma, beta, mean,
-                     rstd, gsum, dx, total4, HW, C, G, act, drop_p, (uint64_t)seed, inv_cnt);
+                     rstd, gsum, dx, total4, HW, C, G, act, drop_p, (uint64_t)seed, inv_cnt, seed_dev);
   INDM_CHECK_LAUNCH();
   return INDM_OK;
 }

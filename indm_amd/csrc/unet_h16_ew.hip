@@ -96,7 +96,8 @@ __global__ __launch_bounds__(MAXT) void h16_gn_fwd_kernel(const i32x4* __restric
                                                            const float* __restrict__ beta, i32x4* __restrict__ y,
                                                            float* __restrict__ mean, float* __restrict__ rstd, int N, int HW,
                                                            int C, int G, int GS, float eps, int act, float drop_p,
-                                                           uint64_t seed) {
+                                                           uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   __shared__ float shw[GN_MAXW * 4 * 4];    // [wave][q][s1 lo, s2 lo, s1 hi, s2 hi]
   __shared__ float shq[GN_MAXQ * 2];        // [quad][s1, s2]
   __shared__ float shg[GN_MAXQ * 2];        // [group][mean, rstd]
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            i32x4* __restrict__ dx, float* __restrict__ cpart, int N, int HW,
-                                                           int C, int G, int GS, int act, float drop_p, uint64_t seed) {
+                                                           int C, int G, int GS, int act, float drop_p, uint64_t seed,
+                                                           const uint64_t* __restrict__ seed_dev) {
+  if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   __shared__ float shw[GN_MAXW * 4 * 16];   // [wave][q][8: sum d, 8: sum d * xh]
   __shared__ float chs[2 * 32];             // channel sums of the slab
   __shared__ float gs_[2 * GN_MAXQ];        // group sums
@@ -521,7 +524,8 @@ INDM_API long indm_h16_groupnorm_ws_floats(int N, int C) { return 2L * N * C + 1
 // y = dropout(act(GroupNorm(x)));  x, y bf16 [N, HW, C];  mean, rstd fp32 [N, G] (saved for the backward)
 INDM_API int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                     int N, int HW, int C, int G, float eps, int act, float drop_p, unsigned long long seed,
-                                    void* stream) {
+                                    const unsigned long long* seed_dev_, void* stream) {
+  const uint64_t* seed_dev = (const uint64_t*)seed_dev_;
   if (N <= 0) return INDM_OK;
   const GnGeom g = gn_geom(HW, C, G, 16, 1024);
   if (!g.nch) return 1;
@@ -531,11 +535,11 @@ INDM_API int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const flo
 #define H16_GN_FWD(NC)                                                                                                          \
   do {                                                                                                                          \
     if (g.bs <= 256) hipLaunchKernelGGL((h16_gn_fwd_kernel<NC, 256>), grid, block, 0, st, (const i32x4*)x, gamma, beta, (i32x4*)y, \
-                                        mean, rstd, N, HW, C, G, g.gs, eps, act, drop_p, (uint64_t)seed);                        \
+                                        mean, rstd, N, HW, C, G, g.gs, eps, act, drop_p, (uint64_t)seed, seed_dev);                        \
     else if (g.bs <= 512) hipLaunchKernelGGL((h16_gn_fwd_kernel<NC, 512>), grid, block, 0, st, (const i32x4*)x, gamma, beta,      \
-                                             (i32x4*)y, mean, rstd, N, HW, C, G, g.gs, eps, act, drop_p, (uint64_t)seed);        \
+                                             (i32x4*)y, mean, rstd, N, HW, C, G, g.gs, eps, act, drop_p, (uint64_t)seed, seed_dev);        \
     else hipLaunchKernelGGL((h16_gn_fwd_kernel<NC, 1024>), grid, block, 0, st, (const i32x4*)x, gamma, beta, (i32x4*)y, mean,     \
-                            rstd, N, HW, C, G, g.gs, eps, act, drop_p, (uint64_t)seed);                                          \
+                            rstd, N, HW, C, G, g.gs, eps, act, drop_p, (uint64_t)seed, seed_dev);                                          \
   } while (0)
   switch (g.nch) {
     case 1: H16_GN_FWD(1); break;
@@ -552,7 +556,9 @@ INDM_API int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const flo
 // dx (bf16), dgamma, dbeta (fp32) of the above; ws >= indm_h16_groupnorm_ws_floats(N, C) floats
 INDM_API int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                                     const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G,
-                                    int act, float drop_p, unsigned long long seed, float* ws, void* stream) {
+                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev_, float* ws,
+                                    void* stream) {
+  const uint64_t* seed_dev = (const uint64_t*)seed_dev_;
   if (N <= 0) return INDM_OK;
   GnGeom g = gn_geom(HW, C, G, 4, 512);
   if (!g.nch) g = gn_geom(HW, C, G, 4, 1024);   // 64 x 64 maps: 1024 threads x 4 chunks (this variant spills 15 registers)
@@ -563,12 +569,12 @@ INDM_API int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* 
 #define H16_GN_BWD(NC)                                                                                                          \
   do {                                                                                                                          \
     if (g.bs <= 256) hipLaunchKernelGGL((h16_gn_bwd_kernel<NC, 256>), grid, block, 0, st, (const i32x4*)dy, (const i32x4*)x, gamma, \
-                                        beta, mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed);       \
+                                        beta, mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed, seed_dev);       \
     else if (g.bs <= 512) hipLaunchKernelGGL((h16_gn_bwd_kernel<NC, 512>), grid, block, 0, st, (const i32x4*)dy, (const i32x4*)x,  \
                                              gamma, beta, mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p,            \
-                                             (uint64_t)seed);                                                                   \
+                                             (uint64_t)seed, seed_dev);                                                         \
     else hipLaunchKernelGGL((h16_gn_bwd_kernel<NC, 1024>), grid, block, 0, st, (const i32x4*)dy, (const i32x4*)x, gamma, beta,     \
-                            mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed);                         \
+                            mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed, seed_dev);                         \
   } while (0)
   switch (g.nch) {
     case 1: H16_GN_BWD(1); break;

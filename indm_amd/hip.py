@@ -44,9 +44,9 @@ _SIGS = {
                                c_p, c_l, c_p],
     "indm_groupnorm_ws_floats": [c_i, c_i, c_i, c_i],
     "indm_groupnorm_fused": [c_i, c_i, c_i],
-    "indm_groupnorm_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p],
+    "indm_groupnorm_fwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p, c_p],
     "indm_groupnorm_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64,
-                               c_p, c_p],
+                               c_p, c_p, c_p],
     "indm_softmax_fwd_f32": [c_p, c_p, c_l, c_i, c_f, c_p],
     "indm_softmax_bwd_f32": [c_p, c_p, c_p, c_l, c_i, c_f, c_p],
     "indm_colreduce_ws_floats": [c_l, c_i],
@@ -143,8 +143,8 @@ _SIGS = {
     "indm_h16_conv2d_wgrad": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
     "indm_h16_groupnorm_ok": [c_i, c_i, c_i],
     "indm_h16_groupnorm_ws_floats": [c_i, c_i],
-    "indm_h16_groupnorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p],
-    "indm_h16_groupnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_p, c_p],
+    "indm_h16_groupnorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p],
+    "indm_h16_groupnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_p, c_p, c_p],
     "indm_h16_segreduce_ws_floats": [c_l, c_l, c_i],
     "indm_h16_segreduce": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
     "indm_h16_scale": [c_p, c_p, c_l, c_f, c_p],
@@ -722,8 +722,15 @@ def conv2d_wgrad(x, dy, kh, kw, stride=1, pad=1, alpha=1.0, dy_gate=None, x_gate
 
 
 # --------------------------------------------------------------------------- norms / softmax
-def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
-    """x [N,..spatial..,C] -> y, mean[N,G], rstd[N,G]. act: 0 none, 1 SiLU. dropout via Philox(seed)."""
+SEED_DEV = [None]   # a [1] int64 device tensor while a hipGraph of the score network is captured (indm_amd/graphed.py), else None
+
+
+def _seed_ptr(seed_dev):
+    return None if seed_dev is None else seed_dev.data_ptr()
+
+
+def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0, seed_dev=None):
+    """x [N,..spatial..,C] -> y, mean[N,G], rstd[N,G]. act: 0 none, 1 SiLU. dropout via Philox(seed + *seed_dev)."""
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
     y = torch.empty_like(x)
@@ -731,12 +738,12 @@ def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
     rstd = torch.empty_like(mean)
     ws = _ws(lib().indm_groupnorm_ws_floats(N, HW, C, G), x.device)
     st = lib().indm_groupnorm_fwd_f32(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), N, HW, C, G,
-                                      eps, act, drop_p, seed, _ptr(ws), _stream())
+                                      eps, act, drop_p, seed, _seed_ptr(seed_dev), _ptr(ws), _stream())
     _chk(st, "indm_groupnorm_fwd_f32")
     return y, mean, rstd
 
 
-def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0, seed_dev=None):
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x)
@@ -744,7 +751,8 @@ def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
     dbeta = torch.empty_like(beta)
     ws = _ws(lib().indm_groupnorm_ws_floats(N, HW, C, G), x.device)
     st = lib().indm_groupnorm_bwd_f32(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _ptr(ws), _stream())
+                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _seed_ptr(seed_dev), _ptr(ws),
+                                      _stream())
     _chk(st, "indm_groupnorm_bwd_f32")
     return dx, dgamma, dbeta
 
@@ -1121,6 +1129,21 @@ def multi_copy(srcs, dsts):
     table = _lop_table(rows, dsts[0].device)
     _chk(lib().indm_multi_copy_f32(table.data_ptr(), len(rows), max(r[2] for r in rows), _stream()),
          "indm_multi_copy_f32")
+
+
+def multi_copy_table(srcs, dsts):
+    """a PERSISTENT device table for multi_copy of fixed (src, dst) pairs -> handle for multi_copy_run (indm_amd/graphed.py:
+    the static gradient buffers of a captured backward graph -> their slices of the flat gradient buffer)"""
+    if not srcs:
+        return None
+    rows = [[_ptr(s_), _ptr(d), d.numel()] for s_, d in zip(srcs, dsts)]
+    tab = torch.tensor(rows, dtype=torch.int64).to(dsts[0].device)
+    return (tab, len(rows), max(r[2] for r in rows))
+
+
+def multi_copy_run(handle):
+    if handle is not None:
+        _chk(lib().indm_multi_copy_f32(handle[0].data_ptr(), handle[1], handle[2], _stream()), "indm_multi_copy_f32")
 
 
 _tables = {}  # (device, rows) -> (pinned host staging tensor, device table): both stay alive with the entry
@@ -1638,7 +1661,7 @@ def h16_groupnorm_ok(HW, C, G):
     return bool(lib().indm_h16_groupnorm_ok(HW, C, G))
 
 
-def h16_groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
+def h16_groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0, seed_dev=None):
     """bf16 x [N,..,C] -> (y bf16, mean, rstd fp32 [N,G]); None when the geometry is not covered"""
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
@@ -1648,12 +1671,12 @@ def h16_groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
     mean = torch.empty((N, G), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
     st = lib().indm_h16_groupnorm_fwd(_ptr16(x), _ptr(gamma), _ptr(beta), y.data_ptr(), _ptr(mean), _ptr(rstd), N, HW, C, G,
-                                      eps, act, drop_p, seed, _stream())
+                                      eps, act, drop_p, seed, _seed_ptr(seed_dev), _stream())
     _chk(st, "indm_h16_groupnorm_fwd")
     return y, mean, rstd
 
 
-def h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
+def h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0, seed_dev=None):
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x)
@@ -1661,7 +1684,8 @@ def h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed
     dbeta = torch.empty_like(beta)
     ws = _ws(lib().indm_h16_groupnorm_ws_floats(N, C), x.device)
     st = lib().indm_h16_groupnorm_bwd(_ptr16(dy), _ptr16(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), dx.data_ptr(),
-                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _ptr(ws), _stream())
+                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _seed_ptr(seed_dev), _ptr(ws),
+                                      _stream())
     _chk(st, "indm_h16_groupnorm_bwd")
     return dx, dgamma, dbeta
 

@@ -9,7 +9,7 @@ flat-buffer all-reduce (if distributed) and one fused clip+AdamW+EMA pass per ne
 import numpy as np
 import torch
 
-from . import hip, ops, sde_lib
+from . import graphed, hip, ops, sde_lib
 from .flow import flow_forward
 from .optim import FusedAdamW
 from .rng import DeviceRng, default_rng, mix64
@@ -115,7 +115,11 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
         set_mode(net, train)
         x_nhwc = ops.to_nhwc(batch)
         xt = ops.sde_perturb(x_nhwc, z, hip.to_device(mc, dev), hip.to_device(std, dev))
-        out = net(xt, hip.to_device(labels, dev), rng=rng, nhwc=True)
+        if train and config.training.likelihood_weighting and not recon_loss and config.optim.num_micro_batch == 1:
+            # the NLL step's one training call of the score network: two captured hipGraphs (graphed.py); eager when disabled
+            out = graphed.score_call(net, net.__dict__.get("_flat"), xt, hip.to_device(labels, dev), rng)
+        else:
+            out = net(xt, hip.to_device(labels, dev), rng=rng, nhwc=True)
         if importance_sampling or not config.training.likelihood_weighting:
             w = (0.5 * Z) * torch.ones(B)
             mode = 0

@@ -281,25 +281,26 @@ class _GroupNormH16(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, G, eps, act, drop_p, seed):
         x = _c(x)
-        out = hip.h16_groupnorm_fwd(x, gamma, beta, G, eps, act, drop_p, seed)
+        sd = hip.SEED_DEV[0] if drop_p > 0 else None
+        out = hip.h16_groupnorm_fwd(x, gamma, beta, G, eps, act, drop_p, seed, sd)
         ctx.h16 = out is not None
         if out is None:
-            y32, mean, rstd = hip.groupnorm_fwd(hip.to_f32(x), gamma, beta, G, eps, act, drop_p, seed)
+            y32, mean, rstd = hip.groupnorm_fwd(hip.to_f32(x), gamma, beta, G, eps, act, drop_p, seed, sd)
             out = (hip.to_bf16(y32), mean, rstd)
         y, mean, rstd = out
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.cfg = (G, act, drop_p, seed)
+        ctx.cfg = (G, act, drop_p, seed, sd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
-        G, act, drop_p, seed = ctx.cfg
+        G, act, drop_p, seed, sd = ctx.cfg
         dy = _c(dy)
         if ctx.h16:
-            dx, dg, db = hip.h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act, drop_p, seed)
+            dx, dg, db = hip.h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act, drop_p, seed, sd)
         else:
-            dx, dg, db = hip.groupnorm_bwd(hip.to_f32(dy), hip.to_f32(x), gamma, beta, mean, rstd, G, act, drop_p, seed)
+            dx, dg, db = hip.groupnorm_bwd(hip.to_f32(dy), hip.to_f32(x), gamma, beta, mean, rstd, G, act, drop_p, seed, sd)
             dx = hip.to_bf16(dx)
         return dx, dg, db, None, None, None, None, None
 
@@ -309,16 +310,17 @@ class _GroupNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, G, eps, act, drop_p, seed):
         x = _c(x)
-        y, mean, rstd = hip.groupnorm_fwd(x, gamma, beta, G, eps, act, drop_p, seed)
+        sd = hip.SEED_DEV[0] if drop_p > 0 else None
+        y, mean, rstd = hip.groupnorm_fwd(x, gamma, beta, G, eps, act, drop_p, seed, sd)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.cfg = (G, act, drop_p, seed)
+        ctx.cfg = (G, act, drop_p, seed, sd)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
-        G, act, drop_p, seed = ctx.cfg
-        dx, dg, db = hip.groupnorm_bwd(_c(dy), x, gamma, beta, mean, rstd, G, act, drop_p, seed)
+        G, act, drop_p, seed, sd = ctx.cfg
+        dx, dg, db = hip.groupnorm_bwd(_c(dy), x, gamma, beta, mean, rstd, G, act, drop_p, seed, sd)
         return dx, dg, db, None, None, None, None, None
 
 

@@ -87,6 +87,15 @@ class GradReducer:
             flat.gather_grads()
             self.pending[key] = (flat, self._launch(flat.g, async_op=True))
 
+    def grads_ready(self, flat):
+        """every gradient of `flat` is in its slice of the flat buffer already (the captured backward graph of the score
+        network, graphed.py, delivers them with one copy instead of one AccumulateGrad per parameter): what the last
+        per-parameter hook would have done"""
+        a = self.armed.pop(id(flat), None)
+        if a is not None:
+            flat.gather_grads()
+            self.pending[id(flat)] = (flat, self._launch(flat.g, async_op=True))
+
     def __call__(self, flats=None):
         self.armed.clear()
         if flats is None:

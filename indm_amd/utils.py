@@ -40,6 +40,7 @@ def build_states(config, score_model=None, flow_model=None, device=None):
     if flow_model is None:
         flow_model = create_flow_model(config).to(device)
     (fs, ff), flat_p, flat_g = flatten_models([score_model, flow_model])
+    score_model.__dict__["_flat"] = fs      # graphed.score_call delivers the captured backward's gradients into its flat buffer
     opt = losses.get_optimizer(config, fs)
     fopt = losses.get_optimizer(config, ff, lr=config.flow.lr)
     state = dict(optimizer=opt, model=score_model, ema=ExponentialMovingAverage(fs, config.model.ema_rate), step=0)

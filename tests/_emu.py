@@ -213,7 +213,7 @@ def _gn_u(x, gamma, beta, mean, rstd, G):
     return xh, xh * gamma + beta
 
 
-def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
+def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0, seed_dev=None):
     _dropout_mask_unavailable(drop_p)
     N, C = x.shape[0], x.shape[-1]
     xs = x.reshape(N, -1, G, C // G)
@@ -225,7 +225,7 @@ def groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0):
     return y.contiguous(), mean, rstd
 
 
-def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0):
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0, seed_dev=None):
     _dropout_mask_unavailable(drop_p)
     N, C = x.shape[0], x.shape[-1]
     xh, u = _gn_u(x, gamma, beta, mean, rstd, G)
