@@ -141,6 +141,7 @@ def score_call(net, flat, x, labels, rng):
     graphs enabled, gradients on, the network's FlatParams known, a noise source that can seed dropout), else eagerly."""
     drop = float(net.config.model.dropout) if net.training else 0.0
     if not (ENABLED["on"] and x.is_cuda and net.training and torch.is_grad_enabled() and flat is not None
+            and not hip._Profile.enabled                      # per-launch HIP-event timing (bench / tests) needs the launches
             and not torch.cuda.is_current_stream_capturing()):
         return net(x, labels, rng=rng, nhwc=True)
     seed = None

@@ -115,8 +115,12 @@ def get_sde_loss_fn(config, sde, train, variance="scoreflow"):
         set_mode(net, train)
         x_nhwc = ops.to_nhwc(batch)
         xt = ops.sde_perturb(x_nhwc, z, hip.to_device(mc, dev), hip.to_device(std, dev))
-        if train and config.training.likelihood_weighting and not recon_loss and config.optim.num_micro_batch == 1:
-            # the NLL step's one training call of the score network: two captured hipGraphs (graphed.py); eager when disabled
+        if (train and not recon_loss and config.optim.num_micro_batch == 1
+                and (config.training.likelihood_weighting or not config.training.st)):
+            # the step's training calls of the score network: two captured hipGraphs (graphed.py; eager when disabled).  The
+            # captured backward OVERWRITES the score slice of the flat gradient buffer, so the two cases in which gradients of
+            # several backward passes add up stay eager: micro-batches, and the two-phase fid step with training.st (its second
+            # phase accumulates onto the re-scaled first-phase gradients, losses.py:378-397)
             out = graphed.score_call(net, net.__dict__.get("_flat"), xt, hip.to_device(labels, dev), rng)
         else:
             out = net(xt, hip.to_device(labels, dev), rng=rng, nhwc=True)

@@ -235,10 +235,11 @@ def test_full_size_step_at_batch_128_matches_oracle():
 
 
 @pytest.mark.timeout(3000)
-@pytest.mark.parametrize("name,B", [("ve/CIFAR10/indm", 64), ("vp/CELEBA/indm_fid", 32)])
+@pytest.mark.parametrize("name,B", [("ve/CIFAR10/indm", 64), ("vp/CELEBA/indm_fid", 32), ("vp/CIFAR10/indm_nll#nrb8", 32)])
 def test_full_size_step_at_the_per_rank_shard_matches_oracle(name, B):
-    """BASELINE configs #3 / #4 at THEIR per-rank shards on 8 GPUs (512 / 8 = 64 images of 32x32 on the FIR / Fourier VE
-    network; 256 / 8 = 32 images of 64x64 on the squeeze flow + 5-level U-Net, two-phase fid step): one full-size
+    """BASELINE configs #3 / #4 / #5 at THEIR per-rank shards on 8 GPUs (512 / 8 = 64 images of 32x32 on the FIR / Fourier VE
+    network; 256 / 8 = 32 images of 64x64 on the squeeze flow + 5-level U-Net, two-phase fid step; round 6: 256 / 8 = 32
+    images on the deep score network of config #5, model.num_res_blocks = 8 -- 76 residual blocks): one full-size
     optimisation step on the production launch geometry -- 256-row direct-to-LDS tiles at M = 32 * 4096 and 64 * 1024,
     big-tile weight grads, the three-kernel GroupNorm the 64x64 maps fall back to, the LDS-tiled FIR kernels -- against the
     CPU oracle on identical weights and noise.  The oracle evaluates the step in chunks (flow_step_fn_nll_chunked /
@@ -246,7 +247,9 @@ def test_full_size_step_at_the_per_rank_shard_matches_oracle(name, B):
     from indm_amd import hip
     torch.manual_seed(64)
     np.random.seed(64)
-    cfg = configs.get_config(name)
+    cfg = configs.get_config(name.split("#")[0])
+    if name.endswith("#nrb8"):
+        cfg.model.num_res_blocks = 8
     cfg.model.dropout = 0.0
     cfg.training.batch_size = B
     dev = torch.device("cuda")
@@ -352,6 +355,8 @@ def test_full_size_step_at_the_per_rank_shard_matches_oracle(name, B):
         assert torch.isfinite(a).all()
         if nm == "loss":   # the objective: per image, and its batch mean
             err = ((a - b).abs() / (b.abs() + 1e-2 / 3e-2)).max().item()
+            print(f"{name} batch {B} bf16 (H16 + F16 storage) vs the fp32 oracle: worst per-image loss deviation {err:.2e}, "
+                  f"batch mean {abs(float(a.mean() - b.mean())) / abs(float(b.mean())):.2e}")
             assert err <= 3e-2, (name, "bf16", nm, err, a, b)
             assert abs(float(a.mean() - b.mean())) <= 1e-2 * abs(float(b.mean())), (name, "bf16 mean", a.mean(), b.mean())
         else:              # its three terms (they cancel in part): relative to the largest entry of the vector
