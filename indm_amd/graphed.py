@@ -47,7 +47,9 @@ class _SeedRng:
 
 class _Replay(Function):
     @staticmethod
-    def forward(ctx, g, x, labels):
+    def forward(ctx, g, x, labels, anchor):
+        # (anchor: a leaf that requires grad -- the parameters are not inputs of this node, and x may be detached (the fid
+        # step's second phase): the node must be differentiable regardless, its backward delivers the parameter gradients)
         g.sx.copy_(x)
         g.sl.copy_(labels)
         g.fwd.replay()
@@ -60,7 +62,7 @@ class _Replay(Function):
         g.sgout.copy_(gout)
         g.bwd.replay()
         g.deliver_param_grads()
-        return None, g.sgx.detach(), None
+        return None, g.sgx.detach(), None, None
 
 
 class GraphedScore:
@@ -73,6 +75,7 @@ class GraphedScore:
         dev = x.device
         self.key = self.signature(net, x, labels)
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.anchor = torch.zeros(1, device=dev, requires_grad=True)
         self.sx = x.detach().clone().requires_grad_(True)
         self.sl = labels.detach().clone()
         params = [p for _, p in flat.named]
@@ -130,7 +133,7 @@ class GraphedScore:
     def __call__(self, x, labels, seed):
         if seed is not None:
             self.seed_dev.fill_(int(seed) & ((1 << 62) - 1))
-        return _Replay.apply(self, x, labels)
+        return _Replay.apply(self, x, labels, self.anchor)
 
 
 _cache = {}
