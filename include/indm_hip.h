@@ -283,12 +283,14 @@ int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y, float* 
  * master weights stay fp32.  The workloads: ResnetBlockBigGANpp's 3x3 / 1x1 convolutions (models/layerspp.py:225-287,
  * models/layers.py:88-124), NIN (models/layers.py:546-556), the NCSN++ graph of models/ncsnpp.py:251-414. */
 /* Packed bf16 copies of the convolution weights, one launch for the whole network.  jobs: DEVICE array of
- * struct indm_h16_pack_job {const float* src; void* fwd; void* dg; int T, Cin, Cout, tile0;}:
+ * struct indm_h16_pack_job {const float* src; void* fwd; void* dg; int T, Cin, Cout, tile0, dg_ld, pad;}:
  *   src  fp32 RSCK [T][Cin][Cout] (1x1 / NIN: T = 1)
  *   fwd  bf16 [Cout][T][Cin]        -- B operand of the forward convolution (may be NULL)
  *   dg   bf16 [Cin][T][Cout], taps flipped: dg[ci][t][co] = src[T-1-t][ci][co] -- B operand of the data gradient (may be NULL)
- *   tile0 = running sum of T * ceil(Cin/32) * ceil(Cout/32) over the preceding jobs; ntiles = the total. */
-struct indm_h16_pack_job { const float* src; void* fwd; void* dg; int T, Cin, Cout, tile0; };
+ *   tile0 = running sum of T * ceil(Cin/32) * ceil(Cout/32) over the preceding jobs; ntiles = the total;
+ *   dg_ld = row stride of dg in elements (0: T * Cout; wider: several weights side by side in one [Cin][sum Cout] pack, the
+ *   q | k | v projections of AttnBlockpp, models/layerspp.py:88-93, as ONE data-gradient operand). */
+struct indm_h16_pack_job { const float* src; void* fwd; void* dg; int T, Cin, Cout, tile0, dg_ld, pad; };
 int indm_h16_pack_weights(const void* jobs, int njobs, int ntiles, void* stream);
 /* y[n,oh,ow,co] = alpha * (sum x[n, oh s + kh - pad, ow s + kw - pad, ci] wp[co][(kh,kw,ci)] + bias[co] + bias2[n][co]) + beta * R
  * x bf16 NHWC, wp packed `fwd` form, y bf16 (out_f32 != 0: fp32, no R), R bf16 of y's shape (ddpm_conv3x3 / conv1x1 / NIN,
@@ -308,6 +310,17 @@ int indm_h16_conv2d_wgrad(const void* x, const void* dy, float* dw, int Nimg, in
 int indm_h16_from_f32(const float* x, void* y, long n, void* stream);
 int indm_h16_to_f32(const void* x, float* y, long n, float alpha, void* stream);
 
+/* AttnBlockpp's single-head attention (models/layerspp.py:88-104) on bf16 q / k / v: h[B T, C] (bf16) = softmax(q k^T scale) v,
+ * lse[B, T] (fp32) = log-sum-exp of the scaled logits per query.  q, k, v: bf16 matrices of row stride ld elements (ld = 3 C: the
+ * three column blocks of a fused QKV product; ld = C: separate tensors); logits and probabilities never leave the registers.
+ * Backward: dq, dk, dv (bf16, row stride ldg) from dh [B T, C], lse and D[B, T] = <dh[q], h[q]> (indm_h16_rowdot).
+ * Return 1 when not covered (T not in {64, 128, 256}, C % 128, ld % 8, alignment): the caller takes the fp32-storage path. */
+int indm_h16_attn_fwd(const void* q, const void* k, const void* v, long ld, void* h, float* lse, int B, int T, int C,
+                      float scale, void* stream);
+int indm_h16_attn_bwd(const void* q, const void* k, const void* v, long ld, const void* dh, const float* lse, const float* D,
+                      void* dq, void* dk, void* dv, long ldg, int B, int T, int C, float scale, void* stream);
+/* out[r] = <a[r], b[r]> for bf16 [R, C] (C even), fp32 out */
+int indm_h16_rowdot(const void* a, const void* b, float* out, long R, int C, void* stream);
 /* GroupNorm(min(C/4,32), C, eps) [+ SiLU] [+ dropout] on bf16 NHWC (models/layerspp.py:232-279, models/layers.py:38-39): x, y, dy,
  * dx bf16 [N, HW, C]; gamma, beta, mean, rstd [N, G], dgamma, dbeta fp32; same Philox dropout mask as indm_groupnorm_*_f32 for
  * the same seed.  indm_h16_groupnorm_ok: 1 when covered (C % 8 == 0, (C / G) % 4 == 0, a block of whole groups of <= 32 channels

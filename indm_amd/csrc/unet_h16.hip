@@ -521,6 +521,8 @@ struct PackJob {
   void* dg;
   int T, Cin, Cout;
   int tile0;   // first workgroup of this job: one workgroup per (tap, 32 x 32 tile of [Cin][Cout])
+  int dg_ld;   // row stride of dg in elements (0: T * Cout).  Wider: several weights side by side in one [Cin][sum Cout] pack --
+  int pad_;    // the q | k | v projections of an attention block as ONE data-grad operand
 };
 __global__ __launch_bounds__(256) void h16_pack_kernel(const PackJob* __restrict__ jobs, int njobs) {
   __shared__ float tile[32][33];
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void h16_pack_kernel(const PackJob* __restrict
     tile[ty + 8 * k][tx] = v;
     if (dg && ci < J.Cin && co < J.Cout) {
       const __bf16 h = (__bf16)v;
-      dg[((long)ci * J.T + (J.T - 1 - t)) * J.Cout + co] = *(const u16*)&h;
+      dg[(long)ci * (J.dg_ld ? J.dg_ld : J.T * J.Cout) + (long)(J.T - 1 - t) * J.Cout + co] = *(const u16*)&h;
     }
   }
   __syncthreads();
@@ -706,7 +708,7 @@ INDM_API int indm_h16_conv2d_wgrad(const void* x, const void* dy, float* dw, int
 }
 
 // jobs: device array of njobs records {src fp32 RSCK, fwd bf16 [Cout][T][Cin] or NULL, dg bf16 [Cin][T][Cout] taps flipped or
-// NULL, T, Cin, Cout, tile0} (struct indm_h16_pack_job, include/indm_hip.h); ntiles = total workgroups = sum over the jobs of
+// NULL, T, Cin, Cout, tile0, dg_ld, pad} (struct indm_h16_pack_job, include/indm_hip.h); ntiles = total workgroups = sum over the jobs of
 // T * ceil(Cin / 32) * ceil(Cout / 32), tile0 = the running sum.
 INDM_API int indm_h16_pack_weights(const void* jobs, int njobs, int ntiles, void* stream) {
   if (njobs < 0 || ntiles < 0) return INDM_E_SHAPE;

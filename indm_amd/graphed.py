@@ -61,6 +61,8 @@ class _Replay(Function):
         g = ctx.g
         g.sgout.copy_(gout)
         g.bwd.replay()
+        for k, v in g.h16_delta.items():
+            hip._H16_STATS[k] += v
         g.deliver_param_grads()
         return None, g.sgx.detach(), None, None
 
@@ -94,6 +96,7 @@ class GraphedScore:
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             pool = torch.cuda.graph_pool_handle()
+            before = dict(hip._H16_STATS)
             self.fwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.fwd, pool=pool):
                 self.sout = net(self.sx, self.sl, rng=_SeedRng(), nhwc=True)
@@ -102,6 +105,9 @@ class GraphedScore:
             with torch.cuda.graph(self.bwd, pool=pool):
                 grads = torch.autograd.grad(self.sout, [self.sx] + params, self.sgout, allow_unused=True)
             self.sgx = grads[0]
+            # what one (forward, backward) pair launches on the H16 kernels: replays add it to hip.h16_stats() -- the coverage
+            # counters keep meaning "launched" when the launches come out of a graph
+            self.h16_delta = {k: hip._H16_STATS[k] - before[k] for k in before}
         finally:
             hip.SEED_DEV[0] = None
             for p, g in zip(params, saved_grads):
@@ -111,7 +117,9 @@ class GraphedScore:
         for (p, dst, _), g in zip(flat.gslices, grads[1:]):
             if g is None:
                 continue
-            srcs.append(g if g.is_contiguous() else g.contiguous())
+            if not g.is_contiguous():   # (a copy made here would be made once, not on every replay)
+                raise RuntimeError("graphed: a parameter gradient left the captured backward non-contiguous")
+            srcs.append(g)
             dsts.append(dst)
             self.views.append((p, dst.view(p.shape)))
         self._static_param_grads = srcs     # keep the graph-pool tensors referenced
@@ -139,12 +147,21 @@ class GraphedScore:
 _cache = {}
 
 
+def _profiling_the_score_net():
+    """a launch profile is being recorded that could contain kernels of the score network (hip.profile_start() without a class,
+    or with a class other than the flow's chain kernel -- bench.py's timed region brackets only that one)"""
+    P = hip._Profile
+    if not P.enabled:
+        return False
+    return P.only is None or not P.only.split(",", 2)[-1].startswith("ires_chain")
+
+
 def score_call(net, flat, x, labels, rng):
     """net(x, labels, rng=rng, nhwc=True) in training mode through the captured graphs when that is possible (GPU tensors,
     graphs enabled, gradients on, the network's FlatParams known, a noise source that can seed dropout), else eagerly."""
     drop = float(net.config.model.dropout) if net.training else 0.0
     if not (ENABLED["on"] and x.is_cuda and net.training and torch.is_grad_enabled() and flat is not None
-            and not hip._Profile.enabled                      # per-launch HIP-event timing (bench / tests) needs the launches
+            and not _profiling_the_score_net()                # per-launch HIP-event timing (bench / tests) needs the launches
             and not torch.cuda.is_current_stream_capturing()):
         return net(x, labels, rng=rng, nhwc=True)
     seed = None

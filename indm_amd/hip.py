@@ -141,6 +141,9 @@ _SIGS = {
     "indm_h16_conv2d": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_i,
                         c_p, c_l, c_p],
     "indm_h16_conv2d_wgrad": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
+    "indm_h16_attn_fwd": [c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
+    "indm_h16_attn_bwd": [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
+    "indm_h16_rowdot": [c_p, c_p, c_p, c_l, c_i, c_p],
     "indm_h16_groupnorm_ok": [c_i, c_i, c_i],
     "indm_h16_groupnorm_ws_floats": [c_i, c_i],
     "indm_h16_groupnorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p],
@@ -1577,7 +1580,9 @@ class H16Packer:
     to watch), a backward reads the pack of its own forward -- valid as long as no parameter update sits between a forward
     and its backward."""
 
-    def __init__(self, weights):
+    def __init__(self, weights, cat_groups=()):
+        """cat_groups: [(first index, count)] -- runs of same-shape 2-D weights [Cin, Cout] whose packs are used side by side
+        (AttnBlockpp's q | k | v projections): group_views[first] = (fwd [count*Cout, Cin], dg [Cin, count*Cout])"""
         import numpy as np
         self.key = tuple(w.data_ptr() for w in weights)
         dev = weights[0].device
@@ -1590,13 +1595,27 @@ class H16Packer:
         total = sum(T * Ci * Co for T, Ci, Co in shapes)
         self.flat = torch.empty(2 * total, dtype=torch.bfloat16, device=dev)
         job = np.zeros(len(weights), dtype=np.dtype([("src", "<u8"), ("fwd", "<u8"), ("dg", "<u8"), ("T", "<i4"), ("Cin", "<i4"),
-                                                     ("Cout", "<i4"), ("tile0", "<i4")]))
-        self.views, off, tiles = [], 0, 0
+                                                     ("Cout", "<i4"), ("tile0", "<i4"), ("dg_ld", "<i4"), ("pad", "<i4")]))
+        member = {}
+        for first, cnt in cat_groups:
+            for j in range(cnt):
+                member[first + j] = (first, cnt, j)
+        self.views, self.group_views, off, tiles, offs = [], {}, 0, 0, []
         base = self.flat.data_ptr()
         for i, (w, (T, Ci, Co)) in enumerate(zip(weights, shapes)):
             n = T * Ci * Co
-            self.views.append((self.flat[off:off + n].view(Co, T * Ci), self.flat[total + off:total + off + n].view(Ci, T * Co)))
-            job[i] = (_ptr(w), base + 2 * off, base + 2 * (total + off), T, Ci, Co, tiles)
+            offs.append(off)
+            if i in member:
+                first, cnt, j = member[i]
+                g0 = offs[first]
+                job[i] = (_ptr(w), base + 2 * off, base + 2 * (total + g0 + j * Co), T, Ci, Co, tiles, cnt * Co, 0)
+                self.views.append(None)
+                if j == cnt - 1:
+                    self.group_views[first] = (self.flat[g0:g0 + cnt * n].view(cnt * Co, Ci),
+                                               self.flat[total + g0:total + g0 + cnt * n].view(Ci, cnt * Co))
+            else:
+                self.views.append((self.flat[off:off + n].view(Co, T * Ci), self.flat[total + off:total + off + n].view(Ci, T * Co)))
+                job[i] = (_ptr(w), base + 2 * off, base + 2 * (total + off), T, Ci, Co, tiles, 0, 0)
             tiles += T * ((Ci + 31) // 32) * ((Co + 31) // 32)
             off += n
         self.tab = torch.from_numpy(job.view(np.uint8).copy()).to(dev)
@@ -1655,6 +1674,30 @@ def h16_conv2d_wgrad(x, dy, KH, KW, stride=1, pad=1, alpha=1.0):
     _chk(st, "indm_h16_conv2d_wgrad")
     _H16_STATS["wgrad"] += 1
     return dw
+
+
+def h16_attn_fwd(qkv, B, T, C, scale):
+    """qkv: bf16 [B*T, 3C] (q | k | v column blocks) -> (h bf16 [B*T, C], lse fp32 [B, T]); None when not covered"""
+    h = torch.empty((B * T, C), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, T), dtype=torch.float32, device=qkv.device)
+    base = _ptr16(qkv)
+    st = lib().indm_h16_attn_fwd(base, base + 2 * C, base + 4 * C, 3 * C, h.data_ptr(), _ptr(lse), B, T, C, scale, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_h16_attn_fwd")
+    return h, lse
+
+
+def h16_attn_bwd(qkv, h, dh, lse, B, T, C, scale):
+    """-> dqkv bf16 [B*T, 3C] (dq | dk | dv)"""
+    D = torch.empty((B, T), dtype=torch.float32, device=qkv.device)
+    _chk(lib().indm_h16_rowdot(_ptr16(dh), _ptr16(h), _ptr(D), B * T, C, _stream()), "indm_h16_rowdot")
+    dqkv = torch.empty_like(qkv)
+    base, gb = _ptr16(qkv), dqkv.data_ptr()
+    st = lib().indm_h16_attn_bwd(base, base + 2 * C, base + 4 * C, 3 * C, _ptr16(dh), _ptr(lse), _ptr(D), gb, gb + 2 * C,
+                                 gb + 4 * C, 3 * C, B, T, C, scale, _stream())
+    _chk(st, "indm_h16_attn_bwd")
+    return dqkv
 
 
 def h16_groupnorm_ok(HW, C, G):

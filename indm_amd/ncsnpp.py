@@ -217,7 +217,15 @@ class AttnBlockpp(nn.Module):
         self.skip_rescale = skip_rescale
 
     def forward(self, x):
-        if x.dtype == torch.bfloat16:   # H16 storage: the attention block runs on fp32 copies (bf16 MFMA inputs), 6 of 50 blocks
+        if x.dtype == torch.bfloat16:   # H16 storage (round 6)
+            B, H, W, C = x.shape
+            pk = self.__dict__.pop("h16_pack", None)
+            if pk is not None and ops.attn_h16_covered(H * W, C):
+                # GroupNorm, ONE QKV GEMM, the fused bf16 attention kernel, the output projection with (x + h) / sqrt(2)
+                a = ops.INV_SQRT2 if self.skip_rescale else 1.0
+                nins = [(m.W, m.b) for m in (self.NIN_0, self.NIN_1, self.NIN_2, self.NIN_3)]
+                return ops.attn_core_h16(self.GroupNorm_0(x), x, nins, pk, float(int(C) ** (-0.5)), a)
+            # geometries the bf16 kernels do not cover (4 x 4 maps: 16 tokens): an fp32-storage island between two converters
             return ops.to_bf16(self.forward(ops.to_f32(x)))
         B, H, W, C = x.shape
         T = H * W
@@ -417,9 +425,17 @@ class NCSNpp(nn.Module):
         """bf16 packs of every convolution weight the H16 kernels can take, ONE launch per forward call (hip.H16Packer);
         each module finds its (fwd, dg) pair in `h16_pack` and hands it to ops.conv2d."""
         pk = self.__dict__.get("_h16_packer")
-        if pk is None or not pk[0].valid_for([w for _, w in pk[1]]):
-            mods = []
+        if pk is None or not pk[0].valid_for(pk[2]):
+            mods, ws, groups, attn = [], [], [], []
             for m in self.modules():
+                if isinstance(m, AttnBlockpp):
+                    C = m.NIN_0.W.shape[0]
+                    if C % 128 == 0:
+                        first = len(ws)
+                        ws += [m.NIN_0.W, m.NIN_1.W, m.NIN_2.W, m.NIN_3.W]
+                        groups.append((first, 3))
+                        attn.append((m, first))
+                    continue
                 c = m
                 if isinstance(m, PyramidDownsample):
                     c = m.Conv2d_0 if m.fir else m.Conv_0
@@ -428,14 +444,19 @@ class NCSNpp(nn.Module):
                 w = c.weight
                 ci, co = (w.shape[2], w.shape[3]) if w.dim() == 4 else (w.shape[0], w.shape[1])
                 if ci % 32 == 0 and co % 2 == 0:
-                    mods.append((c, w))
-            if not mods:
+                    mods.append((c, len(ws)))
+                    ws.append(w)
+            if not ws:
                 self.__dict__["_h16_packer"] = None
                 return
-            pk = (hip.H16Packer([w.detach() for _, w in mods]), mods)
+            pk = (hip.H16Packer([w.detach() for w in ws], groups), (mods, attn), ws)
             self.__dict__["_h16_packer"] = pk
-        for (c, _), pair in zip(pk[1], pk[0].pack()):
-            c.__dict__["h16_pack"] = pair
+        views = pk[0].pack()
+        mods, attn = pk[1]
+        for c, i in mods:
+            c.__dict__["h16_pack"] = views[i]
+        for m, first in attn:
+            m.__dict__["h16_pack"] = pk[0].group_views[first] + views[first + 3]
 
     # ------------------------------------------------------------------ checkpoint boundary
     def _layout(self, key, t, to_reference):

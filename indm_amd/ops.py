@@ -277,6 +277,60 @@ class _Conv2dH16(Function):
         return dx, dw, dbias, dbias2, dres, None, None, None, None, None
 
 
+class _AttnCoreH16(Function):
+    """AttnBlockpp after its GroupNorm on bf16 activations (models/layerspp.py:88-104): the three NIN projections as ONE GEMM
+    (N = 3 C), the fused bf16 attention kernel, the output projection with the skip connection in its epilogue -- and the
+    hand-written backward of that chain.  packs = (fwd_qkv [3C, C], dg_qkv [C, 3C], fwd_3 [C, C], dg_3 [C, C]) bf16."""
+
+    @staticmethod
+    def forward(ctx, h, x, W0, b0, W1, b1, W2, b2, W3, b3, packs, scale, a):
+        h, x = _c(h), _c(x)
+        fwd_qkv, dg_qkv, fwd_3, dg_3 = packs
+        B, H, Wd, C = h.shape
+        T = H * Wd
+        bqkv = torch.cat([b0.detach(), b1.detach(), b2.detach()])
+        qkv = hip.h16_conv2d(h, fwd_qkv, 1, 1, 1, 0, 1.0, bqkv)
+        if qkv is None:
+            raise RuntimeError("indm_h16_conv2d declined the QKV projection (the caller checks the geometry)")
+        out = hip.h16_attn_fwd(qkv.view(B * T, 3 * C), B, T, C, scale)
+        if out is None:
+            raise RuntimeError("indm_h16_attn_fwd declined the launch (the caller checks the geometry)")
+        o, lse = out
+        y = hip.h16_conv2d(o.view(B, H, Wd, C), fwd_3, 1, 1, 1, 0, a, _c(b3), None, x, a)
+        ctx.save_for_backward(h, qkv, o, lse, dg_qkv, dg_3)
+        ctx.cfg = (scale, a)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, qkv, o, lse, dg_qkv, dg_3 = ctx.saved_tensors
+        scale, a = ctx.cfg
+        dy = _c(dy)
+        B, H, Wd, C = h.shape
+        T = H * Wd
+        do = hip.h16_conv2d(dy, dg_3, 1, 1, 1, 0, a)
+        dW3 = hip.h16_conv2d_wgrad(o.view(B, H, Wd, C), dy, 1, 1, 1, 0, a).view(C, C)
+        db3 = hip.h16_segreduce(dy, B * T, a).view(C)
+        dx = dy if a == 1.0 else hip.h16_scale(dy, a)
+        dqkv = hip.h16_attn_bwd(qkv.view(B * T, 3 * C), o, do.view(B * T, C), lse, B, T, C, scale)
+        dq4 = dqkv.view(B, H, Wd, 3 * C)
+        dh = hip.h16_conv2d(dq4, dg_qkv, 1, 1, 1, 0)
+        dWqkv = hip.h16_conv2d_wgrad(h, dq4, 1, 1, 1, 0).view(C, 3 * C)
+        dbqkv = hip.h16_segreduce(dqkv, B * T).view(3 * C)
+        dWs = [dWqkv[:, i * C:(i + 1) * C].contiguous() for i in range(3)]   # (contiguous HERE: inside a captured backward)
+        dbs = [dbqkv[i * C:(i + 1) * C] for i in range(3)]
+        return dh, dx, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2], dW3, db3, None, None, None
+
+
+def attn_core_h16(h, x, nins, packs, scale, a):
+    (W0, b0), (W1, b1), (W2, b2), (W3, b3) = nins
+    return _AttnCoreH16.apply(h, x, W0, b0, W1, b1, W2, b2, W3, b3, packs, scale, a)
+
+
+def attn_h16_covered(T, C):
+    return T in (64, 128, 256) and C >= 128 and C % 128 == 0
+
+
 class _GroupNormH16(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, G, eps, act, drop_p, seed):

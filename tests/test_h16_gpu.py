@@ -300,3 +300,71 @@ def test_score_network_on_h16_storage_matches_fp32(variant):
     den = sum(g32[k].double().pow(2).sum().item() for k in g32)
     assert set(g16) == set(g32)
     assert math.sqrt(num / den) < 4e-2, f"gradients differ by {math.sqrt(num / den):.3e}"
+
+
+@pytest.mark.parametrize("B,T,C", [(3, 256, 256), (2, 64, 128), (2, 128, 384), (5, 256, 128)])
+def test_h16_attention_fwd_bwd(B, T, C):
+    """fused bf16 attention on the q | k | v column blocks of one [B T, 3 C] matrix vs fp64 on the same bf16 values"""
+    qkv = bf(rnd(B * T, 3 * C, seed=1, scale=1.5))
+    dh = bf(rnd(B * T, C, seed=2))
+    scale = float(C) ** -0.5
+    out = hip.h16_attn_fwd(qkv.to(DEV), B, T, C, scale)
+    assert out is not None
+    h, lse = out
+    q, k, v = [t.double().reshape(B, T, C).requires_grad_(True) for t in qkv.split(C, dim=1)]
+    logits = torch.einsum("btc,bsc->bts", q, k) * scale
+    ref = torch.einsum("bts,bsc->btc", torch.softmax(logits, -1), v)
+    g = h.cpu().double().reshape(B, T, C)
+    assert (g - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item(), (g - ref).abs().max().item()
+    assert (lse.cpu().double() - torch.logsumexp(logits, -1)).abs().max().item() <= 1e-3
+    dqkv = hip.h16_attn_bwd(qkv.to(DEV), h, dh.to(DEV), lse, B, T, C, scale)
+    gq, gk, gv = torch.autograd.grad(ref, (q, k, v), dh.double().reshape(B, T, C))
+    for nm, a, r in zip("qkv", dqkv.cpu().double().split(C, dim=1), (gq, gk, gv)):
+        r = r.reshape(B * T, C)
+        err = (a - r).abs().max().item()
+        assert err <= 3e-2 * r.abs().max().item(), (nm, err, r.abs().max().item())
+        assert (a - r).norm().item() <= 1e-2 * r.norm().item(), (nm, (a - r).norm().item() / r.norm().item())
+
+
+def test_score_network_attention_on_h16_kernels():
+    """nf = 64: the attention block of the mini network has 128 channels / 64 tokens -- the bf16 attention path (one QKV GEMM,
+    fused kernel, output projection with the skip in its epilogue) inside the whole network, forward + backward vs fp32"""
+    from indm_amd import ncsnpp
+    cfg = _score_cfg(nf=64)
+    torch.manual_seed(1)
+    net = ncsnpp.NCSNpp(cfg).to(DEV).train()
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if p_.abs().max() < 1e-6 and p_.dim() >= 2:
+                p_.copy_(torch.randn_like(p_) * 0.05)
+            if n_.endswith(".b") or n_.endswith("bias"):
+                p_.copy_(torch.randn_like(p_) * 0.1)
+    B = 4
+    x = torch.randn(B, 3, 16, 16, device=DEV)
+    t = torch.rand(B, device=DEV) * 998 + 1
+    gout = torch.randn(B, 3, 16, 16, device=DEV)
+
+    def run(dtype):
+        hip.set_compute_dtype(dtype)
+        for p_ in net.parameters():
+            p_.grad = None
+        out = net(x, t)
+        out.backward(gout)
+        return out.detach().clone(), {n_: p_.grad.detach().clone() for n_, p_ in net.named_parameters() if p_.grad is not None}
+
+    try:
+        o32, g32 = run("f32")
+        o16, g16 = run("bf16")
+    finally:
+        hip.set_compute_dtype("f32")
+    rel = ((o16 - o32).flatten(1).norm(dim=1) / o32.flatten(1).norm(dim=1)).max().item()
+    assert rel < 3e-2, f"output differs by {rel:.3e}"
+    assert set(g16) == set(g32)
+    for k in g32:
+        if "NIN" in k and not k.endswith("NIN_1.b"):   # the attention block's own parameters, one by one (the key bias has an
+            # exactly zero gradient -- a constant added to a query's logits leaves its softmax alone -- so both sides are noise)
+            e = (g16[k] - g32[k]).norm().item() / (g32[k].norm().item() + 1e-12)
+            assert e < 6e-2, (k, e)
+    num = sum((g16[k] - g32[k]).double().pow(2).sum().item() for k in g32)
+    den = sum(g32[k].double().pow(2).sum().item() for k in g32)
+    assert math.sqrt(num / den) < 4e-2, f"gradients differ by {math.sqrt(num / den):.3e}"
