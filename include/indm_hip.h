@@ -296,16 +296,20 @@ int indm_h16_pack_weights(const void* jobs, int njobs, int ntiles, void* stream)
  * x bf16 NHWC, wp packed `fwd` form, y bf16 (out_f32 != 0: fp32, no R), R bf16 of y's shape (ddpm_conv3x3 / conv1x1 / NIN,
  * models/layers.py:88-124,546-556, with the temb bias, residual and 1/sqrt(2) of layerspp.py:262-287 in the epilogue).  The data
  * gradient of a stride-1 convolution is the same call on dy with the `dg` pack and pad' = K - 1 - pad; KH = KW = 1 is a plain
- * NT GEMM.  ws: fp32 split-K workspace.  Returns 1 (not an error) when the geometry is not covered (Cin % 32, Cout % 2,
+ * NT GEMM.  ws: fp32 split-K workspace; tile_counters: n_counters int32 words in device memory, ZERO at rest (the kernels put
+ * them back), through which the last-arriving workgroup of a tile combines the K-slices inside the launch (NULL: a separate
+ * reduce launch) -- one array per stream that runs these kernels concurrently.  Returns 1 (not an error) when the geometry is not covered (Cin % 32, Cout % 2,
  * OW / OH*OW not powers of two, >= 2 GB tensors, unaligned pointers). */
 int indm_h16_conv2d(const void* x, const void* wp, void* y, int Nimg, int H, int W, int Cin, int Cout, int KH, int KW,
                     int stride, int pad, int OH, int OW, float alpha, const float* bias, const float* bias2,
-                    const void* R, float beta, int out_f32, float* ws, long ws_floats, void* stream);
+                    const void* R, float beta, int out_f32, float* ws, long ws_floats, int* tile_counters, int n_counters,
+                    void* stream);
 /* dw[kh,kw,ci,co] = alpha * sum_{n,oh,ow} x[n, oh s + kh - pad, ow s + kw - pad, ci] dy[n,oh,ow,co]  (fp32 RSCK; autograd of
  * F.conv2d w.r.t. the weight): x, dy bf16 NHWC; deterministic split over the pixels into ws (>= KH KW Cin Cout floats).
  * Returns 1 when not covered (Cin % 8, Cout % 8, pixels % 32, OW / OH*OW not powers of two, >= 2 GB tensors). */
 int indm_h16_conv2d_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout, int KH,
-                          int KW, int stride, int pad, int OH, int OW, float alpha, float* ws, long ws_floats, void* stream);
+                          int KW, int stride, int pad, int OH, int OW, float alpha, float* ws, long ws_floats,
+                          int* tile_counters, int n_counters, void* stream);
 /* fp32 <-> bf16 (round to nearest even); n even, 16-byte aligned pointers; to_f32 scales by alpha */
 int indm_h16_from_f32(const float* x, void* y, long n, void* stream);
 int indm_h16_to_f32(const void* x, float* y, long n, float alpha, void* stream);

@@ -47,6 +47,7 @@ struct H16Args {
   int out_f32;
   int splitk, kps;     // kps: reduction length per split (multiple of 32)
   float* ws;           // fp32 partials [splitk][M][N]
+  int* cnt;            // per-tile arrival counters (zero at rest) for the in-kernel split-K combine, or NULL: separate reduce launch
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int n) {
@@ -160,6 +161,81 @@ __device__ __forceinline__ void h16_epilogue_block(const H16Args& p, const f32x1
     const float got = swap_pair(give);
     const unsigned w = odd ? pack_bf16x2(got, v[2 * j + 1]) : pack_bf16x2(v[2 * j], got);
     if (ok[j]) C[off[j]] = w;
+  }
+}
+
+// One column pair (m, n .. n + 1) of the split-K combine + epilogue: the partial slabs in slab order (fixed: deterministic),
+// eight loads in flight.  Shared by h16_reduce_kernel and the in-kernel combine of the last-arriving workgroup of a tile.
+__device__ __forceinline__ void h16_reduce_pair(const H16Args& p, int m, int n) {
+  const long mn = (long)p.M * p.N;
+  const long e = (long)m * p.N + n;
+  float s0 = 0.f, s1 = 0.f;
+  int kz = 0;
+  for (; kz + 7 < p.splitk; kz += 8) {
+    f32x2 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *(const f32x2*)(p.ws + (long)(kz + j) * mn + e);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0 += v[j][0]; s1 += v[j][1]; }
+  }
+  for (; kz < p.splitk; ++kz) {
+    const f32x2 v = *(const f32x2*)(p.ws + (long)kz * mn + e);
+    s0 += v[0]; s1 += v[1];
+  }
+  if (p.bias) { s0 += p.bias[n]; s1 += p.bias[n + 1]; }
+  if (p.bias2) {
+    const long o = (long)(m / p.rpg) * p.N + n;
+    s0 += p.bias2[o]; s1 += p.bias2[o + 1];
+  }
+  s0 *= p.alpha; s1 *= p.alpha;
+  if (p.out_f32) {
+    if (p.R) {   // (fp32 outputs carry an fp32 residual: the weight-grad accumulate form)
+      s0 += p.beta * ((const float*)p.R)[e];
+      s1 += p.beta * ((const float*)p.R)[e + 1];
+    }
+    *(f32x2*)((float*)p.C + e) = f32x2{s0, s1};
+  } else {
+    if (p.R) {
+      const unsigned w = ((const unsigned*)p.R)[e >> 1];
+      s0 += p.beta * bf16_lo(w);
+      s1 += p.beta * bf16_hi(w);
+    }
+    ((unsigned*)p.C)[e >> 1] = pack_bf16x2(s0, s1);
+  }
+}
+
+// Split-K seam inside the launch (cdna guide, Guideline 16 / the split-K recipe): every K-slice workgroup of a tile has written
+// its fp32 slab; each drains its stores, one lane releases at agent scope and draws a ticket from the tile's counter; the
+// workgroup that draws the last ticket acquires and combines the tile's slabs -- in slab order, so the result does not depend
+// on who arrived last -- instead of a second launch per convolution (232 reduce launches of ~9 us per bf16 training step).
+// MEASURED SLOWER and therefore OFF by default (INDM_H16_FUSED_REDUCE=1 enables it; profiles/r06_h16_fused_reduce_ab.txt): the
+// combine of a tile runs on ONE workgroup (a weight gradient has 5 - 36 tiles of up to 100 slabs: 67 -> 267 us at 32 x 32,
+// 128 -> 128 channels) and every K-slice workgroup pays an agent-scope release (an L2 write-back); the separate reduce launch
+// spreads the same reads over the chip and costs one ~2 us boundary inside the captured graph.
+// The counter is zero at rest: the last arriver puts it back.  `flag` is a word of the (idle) dynamic LDS region.
+template <int NT, int TM>
+__device__ __forceinline__ void h16_splitk_seam(const H16Args& p, int tile, int m0, int n0, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == p.splitk - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  const int cp = threadIdx.x & 63;                 // column pair of the 128-column tile
+  const int n = n0 + 2 * cp;
+  if (n >= p.N) return;
+  for (int r = threadIdx.x >> 6; r < TM; r += NT / 64) {
+    const int m = m0 + r;
+    if (m < p.M) h16_reduce_pair(p, m, n);
   }
 }
 
@@ -302,6 +378,7 @@ __global__ __launch_bounds__(NW * 64, 4) void h16_conv_kernel(H16Args p) {
           if (n < p.N && m < p.M) W[(long)m * p.N + n] = acc[i][j][r];
         }
       }
+    if (p.cnt) h16_splitk_seam<NW * 64, TM>(p, lt, m0, n0, (int*)h16_smem);
     return;
   }
   const bool odd = lane & 1;
@@ -317,43 +394,10 @@ __global__ __launch_bounds__(NW * 64, 4) void h16_conv_kernel(H16Args p) {
 // split-K combine + epilogue (fixed summation order: deterministic), bf16 or fp32 output
 __global__ __launch_bounds__(256) void h16_reduce_kernel(H16Args p) {
   const long total2 = (long)p.M * p.N / 2;   // column pairs (N is even)
-  const long mn = (long)p.M * p.N;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total2; i += (long)gridDim.x * blockDim.x) {
     const long e = 2 * i;
     const int m = (int)(e / p.N), n = (int)(e - (long)m * p.N);
-    float s0 = 0.f, s1 = 0.f;
-    int kz = 0;
-    for (; kz + 7 < p.splitk; kz += 8) {
-      f32x2 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *(const f32x2*)(p.ws + (long)(kz + j) * mn + e);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s0 += v[j][0]; s1 += v[j][1]; }
-    }
-    for (; kz < p.splitk; ++kz) {
-      const f32x2 v = *(const f32x2*)(p.ws + (long)kz * mn + e);
-      s0 += v[0]; s1 += v[1];
-    }
-    if (p.bias) { s0 += p.bias[n]; s1 += p.bias[n + 1]; }
-    if (p.bias2) {
-      const long o = (long)(m / p.rpg) * p.N + n;
-      s0 += p.bias2[o]; s1 += p.bias2[o + 1];
-    }
-    s0 *= p.alpha; s1 *= p.alpha;
-    if (p.out_f32) {
-      if (p.R) {   // (fp32 outputs carry an fp32 residual: the weight-grad accumulate form)
-        s0 += p.beta * ((const float*)p.R)[e];
-        s1 += p.beta * ((const float*)p.R)[e + 1];
-      }
-      *(f32x2*)((float*)p.C + e) = f32x2{s0, s1};
-    } else {
-      if (p.R) {
-        const unsigned w = ((const unsigned*)p.R)[i];
-        s0 += p.beta * bf16_lo(w);
-        s1 += p.beta * bf16_hi(w);
-      }
-      ((unsigned*)p.C)[i] = pack_bf16x2(s0, s1);
-    }
+    h16_reduce_pair(p, m, n);
   }
 }
 
@@ -508,6 +552,7 @@ __global__ __launch_bounds__(512, 4) void h16_wgrad_kernel(H16Args p) {
         if (n < p.N && m < p.M) Wp[(long)m * p.N + n] = acc[i][j][r];
       }
     }
+  if (p.cnt) h16_splitk_seam<512, TM>(p, lt, m0, n0, (int*)h16_smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -618,7 +663,8 @@ static long h16_tuned(const char* name, long dflt) {
 // (Cin % 32, Cout % 2, OH*OW / OW not powers of two, tensors >= 2 GB, unaligned pointers): the caller converts and takes the fp32-storage path.
 INDM_API int indm_h16_conv2d(const void* x, const void* wp, void* y, int Nimg, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, int OH, int OW, float alpha, const float* bias, const float* bias2,
-                             const void* R, float beta, int out_f32, float* ws, long ws_floats, void* stream) {
+                             const void* R, float beta, int out_f32, float* ws, long ws_floats, int* tile_counters,
+                             int n_counters, void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || KH <= 0 || KW <= 0) return INDM_E_SHAPE;
   if (Nimg == 0) return INDM_OK;
   const int ow_sh = ilog2_exact(OW), ohw_sh = ilog2_exact(OH * OW);
@@ -652,6 +698,7 @@ INDM_API int indm_h16_conv2d(const void* x, const void* wp, void* y, int Nimg, i
   }
   p.kps = cdiv(cdiv(p.K, (int)want), 32) * 32;
   p.splitk = cdiv(p.K, p.kps);
+  p.cnt = (p.splitk > 1 && tile_counters && tiles <= n_counters && h16_tuned("INDM_H16_FUSED_REDUCE", 0)) ? tile_counters : nullptr;
   const dim3 grid((unsigned)(tiles * p.splitk));
   if (big) {
     constexpr size_t bytes = 3 * (256 + 128) * 64;
@@ -663,7 +710,7 @@ INDM_API int indm_h16_conv2d(const void* x, const void* wp, void* y, int Nimg, i
     hipLaunchKernelGGL(h16_conv_kernel<4>, grid, dim3(256), bytes, st, p);
   }
   if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
-  if (p.splitk > 1) {
+  if (p.splitk > 1 && !p.cnt) {
     hipLaunchKernelGGL(h16_reduce_kernel, dim3(ew_grid(M * Cout / 2, 256)), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
   }
@@ -676,7 +723,7 @@ INDM_API int indm_h16_conv2d(const void* x, const void* wp, void* y, int Nimg, i
 //   pixels % 32, OH*OW / OW not powers of two, tensors >= 2 GB).
 INDM_API int indm_h16_conv2d_wgrad(const void* x, const void* dy, float* dw, int Nimg, int H, int W, int Cin, int Cout, int KH,
                                    int KW, int stride, int pad, int OH, int OW, float alpha, float* ws, long ws_floats,
-                                   void* stream) {
+                                   int* tile_counters, int n_counters, void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || OH <= 0 || OW <= 0 || KH <= 0 || KW <= 0) return INDM_E_SHAPE;
   if (!dw || !ws) return INDM_E_ARG;
   const int ow_sh = ilog2_exact(OW), ohw_sh = ilog2_exact(OH * OW);
@@ -698,11 +745,13 @@ INDM_API int indm_h16_conv2d_wgrad(const void* x, const void* dy, float* dw, int
   while (want > 1 && want * M * Cout > ws_floats) --want;
   p.kps = cdiv(cdiv(p.K, (int)want), 32) * 32;
   p.splitk = cdiv(p.K, p.kps);
+  p.cnt = (tile_counters && tiles <= n_counters && h16_tuned("INDM_H16_FUSED_REDUCE", 0)) ? tile_counters : nullptr;
   hipStream_t st = (hipStream_t)stream;
   constexpr size_t bytes = 3 * (256 + 128) * 64;
   if (indm_lds_optin<h16_wgrad_kernel>(bytes) != INDM_OK) return INDM_E_LAUNCH;
   hipLaunchKernelGGL(h16_wgrad_kernel, dim3((unsigned)(tiles * p.splitk)), dim3(512), bytes, st, p);
   if (hipGetLastError() != hipSuccess) return INDM_E_LAUNCH;
+  if (p.cnt) return INDM_OK;
   hipLaunchKernelGGL(h16_reduce_kernel, dim3(ew_grid(M * Cout / 2, 256)), dim3(256), 0, st, p);
   return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }

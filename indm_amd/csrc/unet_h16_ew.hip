@@ -69,23 +69,14 @@ __device__ __forceinline__ void gn_decode(int b, int GB, int N, int& n, int& gb)
 constexpr int GN_MAXW = 16;    // waves per workgroup
 constexpr int GN_MAXQ = 8;     // channel quads per slab (CS <= 32 channels)
 
-// Sum `NV` values over the lanes of a wave that own the same slab position q = tid % TP and leave them in lanes 0 .. TP-1
-// (lane == q).  TP a power of two: strided xor butterfly (the lanes of one q are TP apart, 64 % TP == 0); TP == 3: masked
-// full-wave sums.  Fixed order: deterministic.
+// Sum `NV` values over the lanes of a wave that own the same slab position q = tid % TPL and leave them in lanes 0 .. TPL-1
+// (lane == q).  TPL (lanes per pixel) is a power of two: strided xor butterfly (the lanes of one q are TPL apart).  A 24-channel
+// slab (TP = 3 chunks per pixel: the 384-channel maps) runs with TPL = 4 and an idle fourth lane instead of a masked-sum path.
 template <int NV>
-__device__ __forceinline__ void sum_same_q(float (&v)[NV], int TP, int q) {
-  if ((TP & (TP - 1)) == 0) {
-    for (int off = TP; off < 64; off <<= 1) {
+__device__ __forceinline__ void sum_same_q(float (&v)[NV], int TPL) {
+  for (int off = TPL; off < 64; off <<= 1) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) v[j] += __shfl_xor(v[j], off, 64);
-    }
-  } else {   // TP == 3 (24-channel slabs of the 384-channel maps)
-    const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int j = 0; j < NV; ++j) {
-      const float s0 = wave_sum(q == 0 ? v[j] : 0.f), s1 = wave_sum(q == 1 ? v[j] : 0.f), s2 = wave_sum(q == 2 ? v[j] : 0.f);
-      v[j] = lane == 0 ? s0 : lane == 1 ? s1 : s2;
-    }
+    for (int j = 0; j < NV; ++j) v[j] += __shfl_xor(v[j], off, 64);
   }
 }
 
@@ -105,21 +96,24 @@ __global__ __launch_bounds__(MAXT) void h16_gn_fwd_kernel(const i32x4* __restric
   int n, gb;
   gn_decode(blockIdx.x, G / GS, N, n, gb);
   const int cpg = C / G, CS = GS * cpg, TP = CS >> 3, C8 = C >> 3;
-  const int q = tid % TP;
-  const int total = HW * TP;
+  const int TPL = TP == 3 ? 4 : TP;         // lanes per pixel
+  const int ql = tid % TPL;
+  const bool live = ql < TP;
+  const int q = live ? ql : 0;
+  const int total = HW * TPL;
   const long img8 = (long)n * HW * C8;      // 16-byte index of the image
   const int c8_0 = gb * TP;
   i32x4 raw[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    const int pix = min(tid + k * bs, total - 1) / TP;
+    const int pix = min(tid + k * bs, total - 1) / TPL;
     raw[k] = x[img8 + (long)pix * C8 + c8_0 + q];
   }
   __builtin_amdgcn_sched_barrier(0);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    if (tid + k * bs < total) {
+    if (live && tid + k * bs < total) {
       float v[8];
       unpack8(raw[k], v);
       s[0] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -128,7 +122,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_fwd_kernel(const i32x4* __restric
       s[3] += (v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]);
     }
   }
-  sum_same_q<4>(s, TP, q);
+  sum_same_q<4>(s, TPL);
   const int wave = tid >> 6, nw = bs >> 6, lane = tid & 63;
   if (lane < TP) {
 #pragma unroll
@@ -171,7 +165,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_fwd_kernel(const i32x4* __restric
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int f = tid + k * bs;
-    const int pix = min(f, total - 1) / TP;
+    const int pix = min(f, total - 1) / TPL;
     const long i8 = img8 + (long)pix * C8 + c8_0 + q;
     float v[8], o[8];
     forget(raw[k]);
@@ -189,7 +183,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_fwd_kernel(const i32x4* __restric
 #pragma unroll
       for (int j = 0; j < 4; ++j) { o[j] *= f0[j]; o[4 + j] *= f1[j]; }
     }
-    if (f < total) y[i8] = pack8(o);
+    if (live && f < total) y[i8] = pack8(o);
     __builtin_amdgcn_sched_barrier(0);   // one chunk at a time (interleaved, the unrolled chunks spill)
   }
 }
@@ -211,8 +205,11 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
   int n, gb;
   gn_decode(blockIdx.x, G / GS, N, n, gb);
   const int cpg = C / G, CS = GS * cpg, TP = CS >> 3, C8 = C >> 3;
-  const int q = tid % TP;
-  const int total = HW * TP;
+  const int TPL = TP == 3 ? 4 : TP;
+  const int ql = tid % TPL;
+  const bool alive = ql < TP;
+  const int q = alive ? ql : 0;
+  const int total = HW * TPL;
   const long img8 = (long)n * HW * C8;
   const int c8_0 = gb * TP;
   const int glo = (8 * q) / cpg, ghi = (8 * q + 4) / cpg;
@@ -227,7 +224,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
   i32x4 xr[NCH], dr[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
-    const int pix = min(tid + k * bs, total - 1) / TP;
+    const int pix = min(tid + k * bs, total - 1) / TPL;
     const long i8 = img8 + (long)pix * C8 + c8_0 + q;
     xr[k] = x[i8];
     dr[k] = dy[i8];
@@ -243,7 +240,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int f = tid + k * bs;
-    const int pix = min(f, total - 1) / TP;
+    const int pix = min(f, total - 1) / TPL;
     const long i8 = img8 + (long)pix * C8 + c8_0 + q;
     float xv[8], dv[8];
     unpack8(xr[k], xv);
@@ -260,7 +257,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
         kb |= f1[j] != 0.f ? (1u << (4 + j)) : 0u;
       }
     }
-    if (f >= total) kb = 0u;
+    if (!alive || f >= total) kb = 0u;
     keep[k] = kb;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -272,7 +269,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  sum_same_q<16>(a, TP, q);
+  sum_same_q<16>(a, TPL);
   const int wave = tid >> 6, nw = bs >> 6, lane = tid & 63;
   if (lane < TP) {
 #pragma unroll
@@ -304,7 +301,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int f = tid + k * bs;
-    const int pix = min(f, total - 1) / TP;
+    const int pix = min(f, total - 1) / TPL;
     const long i8 = img8 + (long)pix * C8 + c8_0 + q;
     float xv[8], dv[8], o[8];
     forget(xr[k]);
@@ -319,7 +316,7 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
       if (act == 1) d *= silu_grad(h * gm[j] + bt[j]);
       o[j] = r * (gm[j] * d - (j < 4 ? s1lo : s1hi) - h * (j < 4 ? s2lo : s2hi));
     }
-    if (f < total) dx[i8] = pack8(o);
+    if (alive && f < total) dx[i8] = pack8(o);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -355,13 +352,11 @@ static GnGeom gn_geom(int HW, int C, int G, int maxch, int maxbs) {
     if (cs % cpg || C % cs) continue;
     const int gs = cs / cpg, tp = cs / 8;
     if (G % gs || gs > GN_MAXQ) continue;
-    const long total = (long)HW * tp;
-    int bs = tp == 3 ? 192 : 256;
-    if (tp != 3) {
-      if (total <= 64) bs = 64;
-      else if (total <= 128) bs = 128;
-    }
-    while ((total + bs - 1) / bs > maxch && bs * 2 <= maxbs && (bs * 2) % tp == 0) bs *= 2;
+    const long total = (long)HW * (tp == 3 ? 4 : tp);   // (24-channel slabs: four lanes per pixel, the fourth idle)
+    int bs = 256;
+    if (total <= 64) bs = 64;
+    else if (total <= 128) bs = 128;
+    while ((total + bs - 1) / bs > maxch && bs * 2 <= maxbs) bs *= 2;
     const int need = (int)((total + bs - 1) / bs);
     if (need > maxch) continue;
     g.gs = gs; g.bs = bs;
@@ -560,7 +555,10 @@ INDM_API int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* 
                                     void* stream) {
   const uint64_t* seed_dev = (const uint64_t*)seed_dev_;
   if (N <= 0) return INDM_OK;
-  GnGeom g = gn_geom(HW, C, G, 4, 512);
+  static const int t_ch = getenv("INDM_H16_GNB_CH") ? atoi(getenv("INDM_H16_GNB_CH")) : 4;      // tuning hooks (tools/h16_gn_bench.py)
+  static const int t_bs = getenv("INDM_H16_GNB_BS") ? atoi(getenv("INDM_H16_GNB_BS")) : 512;
+  GnGeom g = gn_geom(HW, C, G, t_ch, t_bs);
+  if (!g.nch) g = gn_geom(HW, C, G, 4, 512);
   if (!g.nch) g = gn_geom(HW, C, G, 4, 1024);   // 64 x 64 maps: 1024 threads x 4 chunks (this variant spills 15 registers)
   if (!g.nch) return 1;
   if (!al16(x) || !al16(dy) || !al16(dx) || !ws) return INDM_E_ARG;
@@ -579,7 +577,8 @@ INDM_API int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* 
   switch (g.nch) {
     case 1: H16_GN_BWD(1); break;
     case 2: H16_GN_BWD(2); break;
-    default: H16_GN_BWD(4); break;
+    case 4: H16_GN_BWD(4); break;
+    default: H16_GN_BWD(8); break;
   }
 #undef H16_GN_BWD
   INDM_CHECK_LAUNCH();

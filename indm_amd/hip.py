@@ -139,8 +139,9 @@ _SIGS = {
     "indm_f16_wgrad_gemm": [c_p, c_p, c_p, c_p, c_l, c_f, c_i, c_p, c_l, c_p],
     "indm_h16_pack_weights": [c_p, c_i, c_i, c_p],
     "indm_h16_conv2d": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_f, c_i,
-                        c_p, c_l, c_p],
-    "indm_h16_conv2d_wgrad": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p],
+                        c_p, c_l, c_p, c_i, c_p],
+    "indm_h16_conv2d_wgrad": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_i,
+                              c_p],
     "indm_h16_attn_fwd": [c_p, c_p, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_f, c_p],
     "indm_h16_attn_bwd": [c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
     "indm_h16_rowdot": [c_p, c_p, c_p, c_l, c_i, c_p],
@@ -1639,6 +1640,20 @@ def h16_pack_weights(weights):
     return out
 
 
+_h16_cnt = {}
+H16_COUNTERS = 8192
+
+
+def _h16_counters(device):
+    """per-device tile-arrival counters of the in-kernel split-K combine: zero at rest (the kernels restore them); one array per
+    device is enough because every H16 launch of a process goes to the current stream in program order"""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _h16_cnt.get(key)
+    if t is None:
+        t = _h16_cnt[key] = torch.zeros(H16_COUNTERS, dtype=torch.int32, device=device)
+    return t
+
+
 def h16_conv2d(x, wp, KH, KW, stride=1, pad=1, alpha=1.0, bias=None, bias2=None, res=None, beta=1.0, out_f32=False):
     """bf16 NHWC x [N,H,W,Cin], wp packed bf16 [Cout, KH*KW*Cin] -> y [N,OH,OW,Cout] (bf16, or fp32 with out_f32);
     None when the H16 kernel does not cover the geometry (the caller converts and takes the fp32-storage path)."""
@@ -1651,7 +1666,7 @@ def h16_conv2d(x, wp, KH, KW, stride=1, pad=1, alpha=1.0, bias=None, bias2=None,
     ws = _ws(SPLITK_WS_FLOATS, x.device)
     st = lib().indm_h16_conv2d(_ptr16(x), _ptr16(wp), y.data_ptr(), N, H, W, Ci, Co, KH, KW, stride, pad, OH, OW, alpha,
                                _ptr(bias), _ptr(bias2), _ptr16(res), beta, int(out_f32), _ptr(ws), SPLITK_WS_FLOATS,
-                               _stream())
+                               _h16_counters(x.device).data_ptr(), H16_COUNTERS, _stream())
     if st == 1:
         _H16_STATS["conv_fallback"] += 1
         return None
@@ -1667,7 +1682,7 @@ def h16_conv2d_wgrad(x, dy, KH, KW, stride=1, pad=1, alpha=1.0):
     dw = torch.empty((KH, KW, Ci, Co), dtype=torch.float32, device=x.device)
     ws = _ws(SPLITK_WS_FLOATS, x.device)
     st = lib().indm_h16_conv2d_wgrad(_ptr16(x), _ptr16(dy), _ptr(dw), N, H, W, Ci, Co, KH, KW, stride, pad, OH, OW, alpha,
-                                     _ptr(ws), SPLITK_WS_FLOATS, _stream())
+                                     _ptr(ws), SPLITK_WS_FLOATS, _h16_counters(x.device).data_ptr(), H16_COUNTERS, _stream())
     if st == 1:
         _H16_STATS["wgrad_fallback"] += 1
         return None

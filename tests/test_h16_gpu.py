@@ -368,3 +368,27 @@ def test_score_network_attention_on_h16_kernels():
     num = sum((g16[k] - g32[k]).double().pow(2).sum().item() for k in g32)
     den = sum(g32[k].double().pow(2).sum().item() for k in g32)
     assert math.sqrt(num / den) < 4e-2, f"gradients differ by {math.sqrt(num / den):.3e}"
+
+
+def test_h16_in_kernel_splitk_combine_is_deterministic():
+    """the last-arriving workgroup of a tile combines the K-slices in slab order: the same bits on every run, whoever is last
+    (cdna guide, Guideline 16: agent-scope release / ticket / acquire; counters zero at rest)"""
+    import os
+    x, w = bf(rnd(4, 8, 8, 512, seed=1)).to(DEV), rnd(3, 3, 512, 256, seed=2, scale=0.2).to(DEV)
+    dy = bf(rnd(4, 8, 8, 256, seed=3)).to(DEV)
+    (fwd, _), = hip.h16_pack_weights([w])
+    y_sep = hip.h16_conv2d(x, fwd, 3, 3)        # default: separate reduce launch
+    d_sep = hip.h16_conv2d_wgrad(x, dy, 3, 3)
+    os.environ["INDM_H16_FUSED_REDUCE"] = "1"   # (off by default: measured slower, see csrc/unet_h16.hip)
+    try:
+        y0 = hip.h16_conv2d(x, fwd, 3, 3)
+        d0 = hip.h16_conv2d_wgrad(x, dy, 3, 3)
+        assert torch.equal(y0, y_sep) and torch.equal(d0, d_sep)   # same slab order -> same bits as the reduce kernel
+        noise = torch.randn(64 << 20, device=DEV)
+        for it in range(25):
+            noise.mul_(1.0001)                      # another kernel's traffic between the launches
+            assert torch.equal(hip.h16_conv2d(x, fwd, 3, 3), y0), it
+            assert torch.equal(hip.h16_conv2d_wgrad(x, dy, 3, 3), d0), it
+    finally:
+        del os.environ["INDM_H16_FUSED_REDUCE"]
+    assert int(hip._h16_counters(x.device).abs().sum()) == 0     # the counters are back at rest

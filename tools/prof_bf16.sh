@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 Q="--no-cpu-baseline --no-sampling --no-extra-legs"
 rm -rf $O/prof_bf16
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16 -- python3 $R/bench.py --dtype bf16 --steps 3 --warmup 1 $Q > $O/prof_bf16.log 2>&1
+INDM_SCORE_GRAPH=${INDM_SCORE_GRAPH:-0} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16 -- python3 $R/bench.py --dtype bf16 --steps 3 --warmup 1 $Q > $O/prof_bf16.log 2>&1
 f=$(ls -t $O/prof_bf16/*/*kernel_stats.csv | head -1)
 cp $f $O/prof_bf16_kernel_stats.csv
 python3 $R/tools/kernel_classes.py $f 4
