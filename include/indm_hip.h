@@ -53,7 +53,9 @@ int indm_fused_bias_act_f32(const float* x, const float* bias, const float* ref,
  * vector-Jacobian chain (iresblock.py:253-273) never make a round trip through HBM.
  * Replaces ATen matmul/linear/einsum call sites: NIN models/layers.py:546-556, Dense models/layerspp.py:239-261,
  * attention einsums models/layerspp.py:95-99, LopCondConv2d 1x1 lipschitz.py:429-435, NICEMLPBlock blocks.py:36-43.
- * transA: A stored [K,M]; transB: B stored [N,K].  ws/ws_floats: optional split-K scratch (NULL = no split-K). */
+ * transA: A stored [K,M]; transB: B stored [N,K].  ws/ws_floats: optional split-K scratch (NULL = no split-K).
+ * Size limits (INDM_E_SHAPE beyond them; they also hold for indm_conv2d_*): the epilogue addresses the residual and the
+ * per-group bias with 32-bit element offsets -- M * ldr < 2^32 when R is given, (M / rows_per_group + 1) * N < 2^32 when bias2 is. */
 int indm_gemm_f32(const float* A, const float* gateA, const float* B, float* C, int M, int N, int K, int transA,
                   int transB, long lda,
                   long ldb, long ldc, int batch, long strideA, long strideB, long strideC, float alpha,

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void langevin_step_kernel(const float* __restr
 }
 
 // log|det W| and W^-1 of one n x n (n <= 64) matrix: Gauss-Jordan with partial pivoting; the augmented [n][2n] system lives
-// in LDS.  Round 5: 1024 threads -- thread (row = tid % 64, part = tid / 64) owns 8 columns of its row -- instead of one
+// in LDS.  Round 5: 512 threads (64 rows x SLD_PARTS = 8 parts) -- thread (row = tid % 64, part = tid / 64) owns 16 columns of
+// its row -- instead of one
 // wavefront walking all 128 columns of every row per pivot (350 us per call, twice per training step, with the GPU otherwise
 // idle).  Wave 0 searches the pivot exactly as before and publishes it through LDS; every element still sees the same
 // operations in the same order (a[r][j] /= piv; a[r][j] -= f * a[k][j]): bit-identical results.

@@ -82,6 +82,16 @@ class GraphedScore:
         self.sl = labels.detach().clone()
         params = [p for _, p in flat.named]
         saved_grads = [p.grad for p in params]
+        # The capture differentiates w.r.t. fresh leaf ALIASES of the parameters (same storage), not the parameters themselves:
+        # a parameter's AccumulateGrad node may be kept alive from an earlier eager pass (someone still holds that pass's output);
+        # it remembers the stream it was created on, and autograd would then order the capturing stream after the default
+        # stream -- an illegal dependency inside a capture (it crashed the process, tests/parity_cases.py::case_celeba_squeeze).
+        aliases = {n: p.detach().requires_grad_(True) for n, p in flat.named}
+        leaves = list(aliases.values())
+
+        def run():
+            return torch.func.functional_call(net, aliases, (self.sx, self.sl), {"rng": _SeedRng(), "nhwc": True})
+
         hip.SEED_DEV[0] = self.seed_dev
         try:
             # eager warm-up on a side stream: lazy initialisation (LDS opt-ins, workspaces, tables, packers) happens here,
@@ -90,8 +100,8 @@ class GraphedScore:
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
                 for _ in range(self.WARMUP):
-                    out = net(self.sx, self.sl, rng=_SeedRng(), nhwc=True)
-                    grads = torch.autograd.grad(out, [self.sx] + params, torch.ones_like(out), allow_unused=True)
+                    out = run()
+                    grads = torch.autograd.grad(out, [self.sx] + leaves, torch.ones_like(out), allow_unused=True)
                     del out, grads
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
@@ -99,11 +109,11 @@ class GraphedScore:
             before = dict(hip._H16_STATS)
             self.fwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.fwd, pool=pool):
-                self.sout = net(self.sx, self.sl, rng=_SeedRng(), nhwc=True)
+                self.sout = run()
             self.sgout = torch.zeros_like(self.sout)
             self.bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.bwd, pool=pool):
-                grads = torch.autograd.grad(self.sout, [self.sx] + params, self.sgout, allow_unused=True)
+                grads = torch.autograd.grad(self.sout, [self.sx] + leaves, self.sgout, allow_unused=True)
             self.sgx = grads[0]
             # what one (forward, backward) pair launches on the H16 kernels: replays add it to hip.h16_stats() -- the coverage
             # counters keep meaning "launched" when the launches come out of a graph
@@ -123,6 +133,10 @@ class GraphedScore:
             dsts.append(dst)
             self.views.append((p, dst.view(p.shape)))
         self._static_param_grads = srcs     # keep the graph-pool tensors referenced
+        self._aliases = aliases
+        # the captured kernels hold the raw address of the library's scratch buffer: keep THAT tensor alive even if a later,
+        # larger request replaces the cached one (hip._ws grows by reallocation)
+        self._ws_ref = list(hip._ws_cache.values())
         self.copy_table = hip.multi_copy_table(srcs, dsts)
 
     @staticmethod

@@ -179,7 +179,10 @@ def lib():
                 f"indm_amd: {_LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C indm_amd/csrc`. There is no CPU fallback.")
         L = ctypes.CDLL(_LIB_PATH)
+        partial = os.environ.get("INDM_HIP_LIB_PARTIAL") == "1"   # tools: A/B against an older build that lacks newer entry points
         for name, args in _SIGS.items():
+            if partial and not hasattr(L, name):
+                continue
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = c_l if name in _LONG_RET else (ctypes.c_char_p if name in ("indm_igemm_last_variant", "indm_version") else c_i)
@@ -1908,7 +1911,6 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     dev = x.device
     M = N * H * W
     f16 = storage_dtype() == "bf16" and W2 is not None and _f16_geometry(N, H, W, C, idim)
-    _F16_STATS.setdefault((C, H, W), [0, 0])[0 if f16 else 1] += 1
     new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)  # noqa: E731
     a = _IResFwdArgs()
     a.N, a.H, a.W, a.C, a.idim, a.preact, a.training = N, H, W, C, idim, int(preact), int(training)
@@ -1947,6 +1949,7 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     if st == 1:
         return None
     _chk(st, "indm_iresblock_fwd_logdet")
+    _F16_STATS.setdefault((C, H, W), [0, 0])[0 if f16 else 1] += 1    # counted only when the driver RAN the block
     return y, logdet, saved
 
 

@@ -349,7 +349,7 @@ def test_full_size_step_at_the_per_rank_shard_matches_oracle(name, B):
     else:
         # (the 48-channel scale is declined by the block drivers altogether -- 9 C = 432 > 128 taps -- and runs the op-level
         # composition: bf16 MFMA inputs on fp32 tensors; the counter only sees blocks that reach a driver)
-        assert stats.pop((12, 32, 32)) == [16, 0] and stats in ({}, {(48, 16, 16): [0, 16]}), stats
+        assert stats.pop((12, 32, 32)) == [16, 0] and stats == {}, stats   # (a declined block is not counted: hip.f16_stats)
     for nm, a, b in zip(("loss", "score", "flow", "logp"), got16, want):
         a, b = a.double().cpu(), b.double()
         assert torch.isfinite(a).all()

@@ -1,5 +1,5 @@
 """Probe of the im2col thin convolution (3 -> 512 channels at 32 x 32, batch 128: the flow's `t3 = C3^T v` and conv1): sweeps the
-experiment knobs of igemm_thin_kflat_kernel<true, *> (INDM_THIN_TUNE, read per launch) on the GPU box.
+experiment knobs of igemm_thin_kflat_kernel<true, *> (INDM_THIN_TUNE, read ONCE per process: one setting per run of this script) on the GPU box.
 bits 0-7: start delay of every second workgroup (x 1024 cycles); bit 8: non-temporal stores; bit 9: uncounted waits; bits 13-14: 32-column blocks per MFMA group 2 / 1 / 4;
 bits 10-11: workgroups per CU (0 = default); bit 12: the round-4 LDS-staged kernel instead of thin_conv3_rows_kernel (whose only
 knob is bits 10-11)."""
