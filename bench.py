@@ -241,7 +241,7 @@ def nelbo_leg(cfg, sde, score, flow, dev, oracle_nelbo):
     return out
 
 
-def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
+def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8, dtype="f32"):
     """BASELINE config #5: predictor-only PC sampling (`sampling.method=pc`, Euler-Maruyama, no corrector) of the deep
     NCSN++ (`model.num_res_blocks = 8`, random init) at batch 256.  Times `steps` consecutive sampler steps (the first
     two -- eager warm-up and graph capture -- are excluded), reports the per-step wall time next to the GPU time of
@@ -264,10 +264,13 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
         x = st.rng.randn_image(batch, 3, cfg.data.image_size, cfg.data.image_size)
         ts = torch.linspace(sde.T, cfg.sampling.truncation_time, 1000)
         table = sampling.predictor_table(st, "euler_maruyama", ts[:steps + 2], batch).to(dev)
-        # algorithmic FLOPs of one sampler step: the sum over the dense launches of an eager step (2 M N K each)
+        # algorithmic FLOPs of one sampler step: the sum over the dense launches of an eager fp32 step (2 M N K each; the
+        # bf16-storage kernels are not bracketed per launch, the architecture and hence the count are the same)
+        hip.set_compute_dtype("f32")
         hip.profile_start()
         sampling._GraphedPredictor(st, x, table, use_graph=False).step(0)
         flops_step = sum(q["flops"] for q in hip.profile_stop().values())
+        hip.set_compute_dtype(dtype)
         for mode in ("graph", "eager"):
             gp = sampling._GraphedPredictor(st, x, table, use_graph=(mode == "graph"))
             gp.step(0); gp.step(1)
@@ -290,8 +293,11 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
     g = res["graph"]
     flow.train()
     del score
+    peak_dtype = hip.compute_dtype()
+    hip.set_compute_dtype("f32")
     return {"workload": f"pc_sampler step (EM predictor, no corrector), NCSN++ num_res_blocks={nrb}, batch {batch}, "
-                        f"fp32, {steps} timed steps of a 1000-step schedule",
+                        + ("fp32" if dtype == "f32" else "bf16 MFMA inputs / fp32 accumulate, bf16-stored activations (H16)")
+                        + f", {steps} timed steps of a 1000-step schedule",
             "hipgraph": g, "eager_launches": res["eager"],
             "sampler_steps_per_s": 1e3 / g["wall_ms_per_step"],
             "flow_inverse_s": t_inv,
@@ -299,9 +305,9 @@ def sampling_leg(cfg0, flow, dev, steps=60, batch=256, nrb=8):
             "nfe_per_image": 1000,
             "gflop_per_image_per_step": flops_step / batch / 1e9,
             "achieved_tflops": flops_step / (g["gpu_ms_per_step"] * 1e-3) / 1e12,
-            "peak_tflops": PEAK_BF16_MFMA_TFLOPS if hip.compute_dtype() == "bf16" else PEAK_F32_MFMA_TFLOPS,
+            "peak_tflops": PEAK_BF16_MFMA_TFLOPS if peak_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS,
             "frac": flops_step / (g["gpu_ms_per_step"] * 1e-3) / 1e12
-                    / (PEAK_BF16_MFMA_TFLOPS if hip.compute_dtype() == "bf16" else PEAK_F32_MFMA_TFLOPS)}
+                    / (PEAK_BF16_MFMA_TFLOPS if peak_dtype == "bf16" else PEAK_F32_MFMA_TFLOPS)}
 
 
 def pmc_traffic(kernel_key):
@@ -364,10 +370,11 @@ def run_training(args, cfg_name, batch, dtype, steps, warmup, rank, world, dev, 
     """Build both networks (random init, the full architecture of `cfg_name`) and time `steps` train_step_fn calls after
     `warmup` untimed ones, bracketed by barrier + synchronize.  Returns the measurements of this rank (elapsed is the MAX
     over ranks) plus the live objects the extra legs of the headline run need."""
-    from indm_amd import configs, hip, losses, parallel, sde_lib, utils
+    from indm_amd import configs, graphed, hip, losses, parallel, sde_lib, utils
     from indm_amd.flow import create_flow_model
     from indm_amd.rng import DeviceRng
 
+    graphed.clear()     # the captured graphs of an earlier leg's networks (and their memory pools) are not needed any more
     cfg = configs.get_config(cfg_name)
     cfg.training.batch_size = batch * world
     cfg.device = dev
@@ -658,6 +665,9 @@ def main():
                 out["sampling"] = sampling_leg(cfg, flow, dev)
                 # the per-rank shard of config #5 on 8 GPUs (256 / 8 images): here the captured graph matters
                 out["sampling"]["per_rank_shard_of_8"] = sampling_leg(cfg, flow, dev, steps=60, batch=32)
+                # config #5 is one of the bf16 configurations: the same sampler on bf16-stored activations
+                out["sampling"]["bf16"] = sampling_leg(cfg, flow, dev, steps=60, batch=256, dtype="bf16")
+                out["sampling"]["bf16"]["per_rank_shard_of_8"] = sampling_leg(cfg, flow, dev, steps=60, batch=32, dtype="bf16")
             except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of an extra leg)
                 out["sampling"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_extra_legs:
