@@ -330,7 +330,9 @@ int indm_h16_rowdot(const void* a, const void* b, float* out, long R, int C, voi
 /* GroupNorm(min(C/4,32), C, eps) [+ SiLU] [+ dropout] on bf16 NHWC (models/layerspp.py:232-279, models/layers.py:38-39): x, y, dy,
  * dx bf16 [N, HW, C]; gamma, beta, mean, rstd [N, G], dgamma, dbeta fp32; same Philox dropout mask as indm_groupnorm_*_f32 for
  * the same seed.  indm_h16_groupnorm_ok: 1 when covered (C % 8 == 0, (C / G) % 4 == 0, a block of whole groups of <= 32 channels
- * fits one workgroup's registers); fwd / bwd return 1 otherwise.  ws (bwd): indm_h16_groupnorm_ws_floats(N, C) floats. */
+ * fits one workgroup's registers); fwd / bwd return 1 otherwise.  ws (bwd): indm_h16_groupnorm_ws_floats(N, C) floats.
+ * bwd: add (optional, bf16, x's shape) -- dx += add_scale * add in the same pass: the gradient that reaches x along the skip
+ * connection of its residual block (layerspp.py:283-287), instead of a scale launch and an accumulate launch. */
 int indm_h16_groupnorm_ok(int HW, int C, int G);
 long indm_h16_groupnorm_ws_floats(int N, int C);
 int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
@@ -338,7 +340,8 @@ int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const float* beta,
                            const unsigned long long* seed_dev, void* stream);
 int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                            const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G, int act,
-                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* ws, void* stream);
+                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, const void* add,
+                           float add_scale, float* ws, void* stream);
 /* out[s][c] = alpha * sum_{r < rps} x[(s rps + r) C + c], x bf16 [nseg rps, C], out fp32 [nseg, C]: the bias and per-image
  * temb-bias gradients of the convolutions (layerspp.py:262-263); C % 8 == 0, C <= 2048; ws: indm_h16_segreduce_ws_floats floats */
 long indm_h16_segreduce_ws_floats(long nseg, long rps, int C);

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            i32x4* __restrict__ dx, float* __restrict__ cpart, int N, int HW,
                                                            int C, int G, int GS, int act, float drop_p, uint64_t seed,
-                                                           const uint64_t* __restrict__ seed_dev) {
+                                                           const uint64_t* __restrict__ seed_dev, const i32x4* __restrict__ add,
+                                                           float add_scale) {
   if (seed_dev) seed += *seed_dev;   // graph-captured launches: the per-call seed lives in device memory (indm_amd/graphed.py)
   __shared__ float shw[GN_MAXW * 4 * 16];   // [wave][q][8: sum d, 8: sum d * xh]
   __shared__ float chs[2 * 32];             // channel sums of the slab
@@ -315,6 +316,12 @@ __global__ __launch_bounds__(MAXT) void h16_gn_bwd_kernel(const i32x4* __restric
       float d = ((keep[k] >> j) & 1u) ? dv[j] * kscale : 0.f;
       if (act == 1) d *= silu_grad(h * gm[j] + bt[j]);
       o[j] = r * (gm[j] * d - (j < 4 ? s1lo : s1hi) - h * (j < 4 ? s2lo : s2hi));
+    }
+    if (add) {   // the gradient that reaches x along its OTHER use (the skip connection of the residual block): dx += add_scale * add
+      float av[8];
+      unpack8(add[i8], av);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += add_scale * av[j];
     }
     if (alive && f < total) dx[i8] = pack8(o);
     __builtin_amdgcn_sched_barrier(0);
@@ -551,8 +558,8 @@ INDM_API int indm_h16_groupnorm_fwd(const void* x, const float* gamma, const flo
 // dx (bf16), dgamma, dbeta (fp32) of the above; ws >= indm_h16_groupnorm_ws_floats(N, C) floats
 INDM_API int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                                     const float* rstd, void* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G,
-                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev_, float* ws,
-                                    void* stream) {
+                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev_,
+                                    const void* add, float add_scale, float* ws, void* stream) {
   const uint64_t* seed_dev = (const uint64_t*)seed_dev_;
   if (N <= 0) return INDM_OK;
   static const int t_ch = getenv("INDM_H16_GNB_CH") ? atoi(getenv("INDM_H16_GNB_CH")) : 4;      // tuning hooks (tools/h16_gn_bench.py)
@@ -561,18 +568,19 @@ INDM_API int indm_h16_groupnorm_bwd(const void* dy, const void* x, const float* 
   if (!g.nch) g = gn_geom(HW, C, G, 4, 512);
   if (!g.nch) g = gn_geom(HW, C, G, 4, 1024);   // 64 x 64 maps: 1024 threads x 4 chunks (this variant spills 15 registers)
   if (!g.nch) return 1;
-  if (!al16(x) || !al16(dy) || !al16(dx) || !ws) return INDM_E_ARG;
+  if (!al16(x) || !al16(dy) || !al16(dx) || !al16(add) || !ws) return INDM_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((G / g.gs) * N), block(g.bs);
 #define H16_GN_BWD(NC)                                                                                                          \
   do {                                                                                                                          \
     if (g.bs <= 256) hipLaunchKernelGGL((h16_gn_bwd_kernel<NC, 256>), grid, block, 0, st, (const i32x4*)dy, (const i32x4*)x, gamma, \
-                                        beta, mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed, seed_dev);       \
+                                        beta, mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed, seed_dev, (const i32x4*)add, add_scale); \
     else if (g.bs <= 512) hipLaunchKernelGGL((h16_gn_bwd_kernel<NC, 512>), grid, block, 0, st, (const i32x4*)dy, (const i32x4*)x,  \
                                              gamma, beta, mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p,            \
-                                             (uint64_t)seed, seed_dev);                                                         \
+                                             (uint64_t)seed, seed_dev, (const i32x4*)add, add_scale);                           \
     else hipLaunchKernelGGL((h16_gn_bwd_kernel<NC, 1024>), grid, block, 0, st, (const i32x4*)dy, (const i32x4*)x, gamma, beta,     \
-                            mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed, seed_dev);                         \
+                            mean, rstd, (i32x4*)dx, ws, N, HW, C, G, g.gs, act, drop_p, (uint64_t)seed, seed_dev,                  \
+                            (const i32x4*)add, add_scale);                                                                       \
   } while (0)
   switch (g.nch) {
     case 1: H16_GN_BWD(1); break;

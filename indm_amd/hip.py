@@ -148,7 +148,8 @@ _SIGS = {
     "indm_h16_groupnorm_ok": [c_i, c_i, c_i],
     "indm_h16_groupnorm_ws_floats": [c_i, c_i],
     "indm_h16_groupnorm_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_f, c_u64, c_p, c_p],
-    "indm_h16_groupnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_p, c_p, c_p],
+    "indm_h16_groupnorm_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_p, c_p, c_f,
+                               c_p, c_p],
     "indm_h16_segreduce_ws_floats": [c_l, c_l, c_i],
     "indm_h16_segreduce": [c_p, c_p, c_l, c_l, c_i, c_f, c_p, c_p],
     "indm_h16_scale": [c_p, c_p, c_l, c_f, c_p],
@@ -1737,7 +1738,8 @@ def h16_groupnorm_fwd(x, gamma, beta, G, eps, act=0, drop_p=0.0, seed=0, seed_de
     return y, mean, rstd
 
 
-def h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0, seed_dev=None):
+def h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed=0, seed_dev=None, add=None, add_scale=1.0):
+    """add (optional, bf16, x's shape): dx += add_scale * add inside the same pass"""
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
     dx = torch.empty_like(x)
@@ -1745,8 +1747,8 @@ def h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act=0, drop_p=0.0, seed
     dbeta = torch.empty_like(beta)
     ws = _ws(lib().indm_h16_groupnorm_ws_floats(N, C), x.device)
     st = lib().indm_h16_groupnorm_bwd(_ptr16(dy), _ptr16(x), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), dx.data_ptr(),
-                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _seed_ptr(seed_dev), _ptr(ws),
-                                      _stream())
+                                      _ptr(dgamma), _ptr(dbeta), N, HW, C, G, act, drop_p, seed, _seed_ptr(seed_dev),
+                                      _ptr16(add), add_scale, _ptr(ws), _stream())
     _chk(st, "indm_h16_groupnorm_bwd")
     return dx, dgamma, dbeta
 

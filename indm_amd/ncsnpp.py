@@ -39,8 +39,9 @@ class Conv3x3(nn.Module):
         self.weight = nn.Parameter(w.permute(2, 3, 1, 0).contiguous())
         self.bias = nn.Parameter(torch.zeros(out_ch))
 
-    def forward(self, x, bias2=None, res=None, alpha=1.0, beta=1.0):
-        return ops.conv2d(x, self.weight, self.bias, bias2, res, 1, 1, alpha, beta, pack=self.__dict__.pop("h16_pack", None))
+    def forward(self, x, bias2=None, res=None, alpha=1.0, beta=1.0, res_grad_unscaled=False):
+        return ops.conv2d(x, self.weight, self.bias, bias2, res, 1, 1, alpha, beta, pack=self.__dict__.pop("h16_pack", None),
+                          res_grad_unscaled=res_grad_unscaled)
 
 
 class Conv1x1(nn.Module):
@@ -171,7 +172,14 @@ class ResnetBlockBigGANpp(nn.Module):
     def forward(self, x, temb_act=None, rng=None):
         """x NHWC; temb_act = SiLU(temb) (shared by all blocks, ncsnpp.py passes temb and each block
         applies act -- the activation is hoisted because it is identical for every block)."""
-        h = self.GroupNorm_0(x, silu=True)
+        shortcut = self.in_ch != self.out_ch or self.up or self.down
+        a = ops.INV_SQRT2 if self.skip_rescale else 1.0
+        fused_skip = x.dtype == torch.bfloat16   # H16: both gradients of x come back through the GroupNorm backward kernel
+        if fused_skip:
+            g = self.GroupNorm_0
+            h, x = ops.group_norm_res(x, g.weight, g.bias, 1e-6, True, 0.0, 0, 1.0 if shortcut else a)
+        else:
+            h = self.GroupNorm_0(x, silu=True)
         if self.up:
             if self.fir:
                 h, x = self.firop.upsample(h), self.firop.upsample(x)
@@ -197,11 +205,10 @@ class ResnetBlockBigGANpp(nn.Module):
                 raise RuntimeError("training with dropout > 0 on a replayed noise source: the parity fixtures are "
                                    "recorded with model.dropout = 0")
         h = self.GroupNorm_1(h, silu=True, drop_p=drop, seed=seed)
-        if self.in_ch != self.out_ch or self.up or self.down:
+        if shortcut:
             x = self.Conv_2(x)
-        if self.skip_rescale:
-            return self.Conv_1(h, res=x, alpha=ops.INV_SQRT2, beta=ops.INV_SQRT2)
-        return self.Conv_1(h, res=x, alpha=1.0, beta=1.0)
+        # (fused_skip without a shortcut: x IS the GroupNorm node's skip output, which applies the factor `a` itself)
+        return self.Conv_1(h, res=x, alpha=a, beta=a, res_grad_unscaled=fused_skip and not shortcut)
 
 
 class AttnBlockpp(nn.Module):

@@ -123,11 +123,11 @@ class _Conv2d(Function):
         return dx, dw, dbias, dbias2, dres, None, None, None, None
 
 
-def conv2d(x, w, bias=None, bias2=None, res=None, stride=1, pad=1, alpha=1.0, beta=1.0, pack=None):
+def conv2d(x, w, bias=None, bias2=None, res=None, stride=1, pad=1, alpha=1.0, beta=1.0, pack=None, res_grad_unscaled=False):
     """y = alpha*(conv(x, w) + bias + bias2[n]) + beta*res ; x NHWC, w RSCK.
     bf16 x (H16 storage): bf16 result; pack = the weight's (fwd, dg) bf16 packs when the caller holds them."""
     if x.dtype == torch.bfloat16:
-        return _Conv2dH16.apply(x, w, bias, bias2, res, stride, pad, alpha, beta, pack)
+        return _Conv2dH16.apply(x, w, bias, bias2, res, stride, pad, alpha, beta, pack, res_grad_unscaled)
     return _Conv2d.apply(x, w, bias, bias2, res, stride, pad, alpha, beta)
 
 
@@ -221,8 +221,9 @@ class _Conv2dH16(Function):
     cover (channel counts of the mini test configs, strided data-grads) runs on fp32 copies through the fp32-storage kernels."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, bias2, res, stride, pad, alpha, beta, pack):
+    def forward(ctx, x, w, bias, bias2, res, stride, pad, alpha, beta, pack, res_grad_unscaled=False):
         x, res = _c(x), _c(res)
+        ctx.res_grad_unscaled = res_grad_unscaled   # the consumer of d(res) applies beta itself (group_norm_res)
         w4 = w if w.dim() == 4 else w.view(1, 1, *w.shape)
         KH, KW, Ci, Co = w4.shape
         y = None
@@ -273,8 +274,52 @@ class _Conv2dH16(Function):
             if has_bias and ctx.needs_input_grad[2]:
                 dbias = hip.colreduce(dbias2, None, 0) if dbias2 is not None else hip.colreduce(dy32, None, 0, alpha)
         if has_res and ctx.needs_input_grad[4]:
-            dres = dy if beta == 1.0 else hip.h16_scale(dy, beta)
-        return dx, dw, dbias, dbias2, dres, None, None, None, None, None
+            dres = dy if (beta == 1.0 or ctx.res_grad_unscaled) else hip.h16_scale(dy, beta)
+        return dx, dw, dbias, dbias2, dres, None, None, None, None, None, None
+
+
+class _GroupNormResH16(Function):
+    """(y, x_skip) = (GroupNorm[+SiLU][+dropout](x), x): the block input leaves this node twice -- normalised, and as the skip
+    tensor the block's last convolution (or its 1x1 shortcut) consumes -- so that BOTH gradients come back to ONE backward call:
+    dx = GroupNorm'(dy) + res_scale * d(x_skip) in the GroupNorm backward kernel's own pass (no scale launch, no accumulate
+    launch, three tensor passes less per residual block).  res_scale: the factor the skip's consumer left to us."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, act, drop_p, seed, res_scale):
+        x = _c(x)
+        sd = hip.SEED_DEV[0] if drop_p > 0 else None
+        out = hip.h16_groupnorm_fwd(x, gamma, beta, G, eps, act, drop_p, seed, sd)
+        ctx.h16 = out is not None
+        if out is None:
+            y32, mean, rstd = hip.groupnorm_fwd(hip.to_f32(x), gamma, beta, G, eps, act, drop_p, seed, sd)
+            out = (hip.to_bf16(y32), mean, rstd)
+        y, mean, rstd = out
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (G, act, drop_p, seed, sd, res_scale)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, act, drop_p, seed, sd, res_scale = ctx.cfg
+        dskip = _c(dskip)
+        if dy is None:   # (only the skip was used)
+            return (dskip if res_scale == 1.0 else hip.h16_scale(dskip, res_scale)), None, None, None, None, None, None, None, None
+        dy = _c(dy)
+        if ctx.h16:
+            dx, dg, db = hip.h16_groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act, drop_p, seed, sd, dskip, res_scale)
+        else:
+            dx, dg, db = hip.groupnorm_bwd(hip.to_f32(dy), hip.to_f32(x), gamma, beta, mean, rstd, G, act, drop_p, seed, sd)
+            if dskip is not None:
+                dx = dx + res_scale * hip.to_f32(dskip)
+            dx = hip.to_bf16(dx)
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def group_norm_res(x, gamma, beta, eps=1e-6, silu=False, drop_p=0.0, seed=0, res_scale=1.0):
+    """bf16 x -> (GroupNorm(x), x_skip); see _GroupNormResH16"""
+    C = x.shape[-1]
+    return _GroupNormResH16.apply(x, gamma, beta, min(C // 4, 32), eps, 1 if silu else 0, float(drop_p), int(seed), float(res_scale))
 
 
 class _AttnCoreH16(Function):
