@@ -834,6 +834,142 @@ __global__ __launch_bounds__(256, 2) void f16_wgrad_gemm_kernel(WgradGemmArgs p)
       }
 }
 
+// Round 6: the same contraction with the operands copied chunk by chunk straight into LDS (direct-to-LDS, no register
+// staging) and the fragments built by TRANSPOSING LDS reads instead of 64 two-byte LDS stores per thread and slab (those
+// stores, not the MFMAs or the bytes, bounded f16_wgrad_gemm_kernel: 404 TF-equivalent at M = 131072).
+//   * an F16 chunk (mt, nb, s) is 1 KB: lane-slot (lhi, r) holds row r's 8 columns 16 s + 8 (e >> 2) + 4 lhi + (e & 3).  The
+//     copy is lane-linear, but WHICH source slot a lane copies is free: LDS slot q <- source slot (lhi = q & 1, r = q >> 1),
+//     so a row's two halves are adjacent (32 bytes) and four consecutive rows are 128 contiguous bytes; chunks sit 1152 bytes
+//     apart (1 KB + 128: the two chunks a half-wave reads fall into complementary bank halves -> conflict-free).
+//   * ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of piece (i & 3) of row (i >> 2) and receives, for
+//     the four rows, column col(i) = {0..3, 8..11, 4..7, 12..15}[i] of the chunk -- the MFMA operand "8 consecutive rows of one
+//     column" in two reads.  The columns of a 32-column block therefore reach the MFMA in a fixed permutation, undone when the
+//     partial tile is written.
+//   * gated form: the X and G fragments are multiplied in fp32 and rounded once (the rounding of the old kernel's store).
+// Same arguments, same [split][512][512] partial slabs and reduce kernel as f16_wgrad_gemm_kernel.
+__device__ __forceinline__ int tr_col(int i) { return (i & 3) + 8 * ((i >> 2) & 1) + 4 * (i >> 3); }
+
+template <bool GATED>
+__global__ __launch_bounds__(256, 2) void f16_wgrad_tr_kernel(WgradGemmArgs p) {
+  constexpr int CH = 1152;                         // bytes per chunk slot
+  constexpr int OPB = 8 * CH;                      // one operand's 128 columns x 32 rows
+  constexpr int NOP = GATED ? 3 : 2;
+  constexpr int BUF = NOP * OPB;
+  constexpr int NBUF = GATED ? 2 : 3, D = NBUF - 1;   // (gated: three operands x three stages would leave one workgroup per CU)
+  constexpr int NDMA = 2 * NOP;                    // copies per wave and slab
+  extern __shared__ __attribute__((aligned(16))) char wt_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int tile = loc & 15, split = (loc >> 4) * 8 + xcd;
+  if (split >= p.S) return;
+  const int t1 = tile >> 2, t2 = tile & 3;
+  const int w1 = wave >> 1, w2 = wave & 1;
+  const int mt0 = split * p.per, mt1 = min(p.mts, mt0 + p.per);
+  const int nk = mt1 - mt0;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // copies: wave w stages chunks 2 w, 2 w + 1 of each operand's tile (chunk c = 2 * local column block + s)
+  const unsigned src_lane = (unsigned)((32 * (lane & 1) + (lane >> 1)) * 16);   // source slot of this lane's LDS slot
+  auto stage = [&](int buf, int mt) {
+    char* base = wt_smem + buf * BUF;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = 2 * wave + q;
+      const long cx = ((long)mt * 16 + t1 * 4 + (c >> 1)) * 2 + (c & 1), cy = ((long)mt * 16 + t2 * 4 + (c >> 1)) * 2 + (c & 1);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(lds_addr(base + c * CH)), "v"(src_lane), "s"((const char*)p.X + cx * 1024) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(lds_addr(base + OPB + c * CH)), "v"(src_lane), "s"((const char*)p.Y + cy * 1024) : "memory", "m0");
+      if constexpr (GATED)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds_addr(base + 2 * OPB + c * CH)), "v"(src_lane), "s"((const char*)p.G + cx * 1024) : "memory", "m0");
+    }
+  };
+  // transposing reads: lane (i = lane & 15, g1, lhi) supplies piece (i & 3) of row 8 lhi + (i >> 2) (+ 16 ks, + 4 h) of chunk g1
+  const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+  const unsigned rd = (unsigned)(g1 * CH + (2 * (8 * lhi + (i16 >> 2)) + ((i16 >> 1) & 1)) * 16 + (i16 & 1) * 8);
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  auto trd = [](const char* q) -> s16x4_t {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)q);
+  };
+  auto frag = [&](const char* op, int blk, int ks) -> bf16x8 {   // rows 16 ks + 8 lhi + 0 .. 7 of this lane's column in block blk
+    const char* q = op + blk * 2 * CH + rd + ks * 512;            // (16 rows = 32 slots = 512 bytes)
+    const s16x4_t lo = trd(q), hi = trd(q + 128);                 // (4 rows = 8 slots = 128 bytes)
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto wait = [](int n) {   // n = 1: the newest stage may stay in flight (three buffers only)
+    if (n == 0 || D == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  };
+  auto barrier = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  static_assert(GATED || NDMA == 4, "the counted wait above");
+  {
+    const int pre = nk < D ? nk : D;
+    for (int d = 0; d < pre; ++d) stage(d, mt0 + d);
+    wait(nk >= D ? 1 : 0);
+    barrier();
+  }
+  int buf = 0, sbuf = D;
+  for (int s = 0; s < nk; ++s) {
+    if (s + D < nk) stage(sbuf, mt0 + s + D);
+    const char* xs = wt_smem + buf * BUF;
+    const char* ys = xs + OPB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ha[2], hb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ha[i] = frag(xs, w1 * 2 + i, ks);
+        if constexpr (GATED) {
+          const bf16x8 hg = frag(xs + 2 * OPB, w1 * 2 + i, ks);
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (float)ha[i][e] * (float)hg[e];
+          ha[i] = indm_pack_bf16x8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) hb[j] = frag(ys, w2 * 2 + j, ks);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);   // D[n1][n2]
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wait(s + 2 < nk ? 1 : 0);
+    barrier();
+    buf = buf == D ? 0 : buf + 1;
+    sbuf = sbuf == D ? 0 : sbuf + 1;
+  }
+  float* out = p.part + (long)split * R_N * R_N;
+  const int n2l = 16 * (l31 >> 4) + tr_col(l31 & 15);            // the column this lane's B fragments carried
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ai = (r & 3) + 8 * (r >> 2) + 4 * lhi;         // the A-operand lane whose column this accumulator row is
+        const int n1 = t1 * 128 + (w1 * 2 + i) * 32 + 16 * (ai >> 4) + tr_col(ai & 15);
+        const int n2 = t2 * 128 + (w2 * 2 + j) * 32 + n2l;
+        out[(long)n1 * R_N + n2] = acc[i][j][r];
+      }
+}
+
 inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 }  // namespace
@@ -969,6 +1105,22 @@ INDM_API int indm_f16_wgrad_gemm(const void* X, const void* gateX, const void* Y
   WgradGemmArgs p = {(const u16*)X, (const u16*)gateX, (const u16*)Y, ws, mts, per, S};
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(((S + 7) / 8) * 8 * 16);
+  static const int use_tr = getenv("INDM_F16_WGRAD_TR") ? atoi(getenv("INDM_F16_WGRAD_TR")) : 1;
+  if (use_tr) {   // round 6: direct-to-LDS chunks + transposing reads (f16_wgrad_tr_kernel)
+    constexpr int ldsg = 2 * 3 * 8 * 1152, ldsp = 3 * 2 * 8 * 1152;
+    if (gateX) {
+      if (indm_lds_optin<f16_wgrad_tr_kernel<true>>(ldsg) != INDM_OK) return INDM_E_LAUNCH;
+      hipLaunchKernelGGL((f16_wgrad_tr_kernel<true>), grid, dim3(256), ldsg, st, p);
+    } else {
+      if (indm_lds_optin<f16_wgrad_tr_kernel<false>>(ldsp) != INDM_OK) return INDM_E_LAUNCH;
+      hipLaunchKernelGGL((f16_wgrad_tr_kernel<false>), grid, dim3(256), ldsp, st, p);
+    }
+    INDM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(f16_wgrad_reduce_kernel, dim3(cdiv((long)R_N * R_N, 256)), dim3(256), 0, st, ws, out, S, R_N, R_N, alpha,
+                       transpose, (long)R_N);
+    INDM_CHECK_LAUNCH();
+    return INDM_OK;
+  }
   constexpr int lds2 = 4 * 128 * (32 * 2 + 8) * 2, lds1 = 4 * 128 * (32 + 8) * 2;
   if (!gateX && indm_lds_optin<f16_wgrad_gemm_kernel<false, 2>>(lds2) != INDM_OK) return INDM_E_LAUNCH;   // 72 KB (the gated form: 40 KB)
   if (gateX) hipLaunchKernelGGL((f16_wgrad_gemm_kernel<true, 1>), grid, dim3(256), lds1, st, p);

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 Q="--no-cpu-baseline --no-sampling --no-extra-legs"
-INDM_BENCH_PROFILE=1 python3 $R/bench.py > $O/final_bench.json 2> $O/final_bench.err
+INDM_BENCH_PROFILE=1 python3 $R/bench.py --steps 20 --warmup 5 > $O/final_bench.json 2> $O/final_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof -- python3 $R/bench.py --steps 3 --warmup 1 $Q > $O/final_prof.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/final_fetch -- python3 $R/bench.py --steps 1 --warmup 1 $Q > $O/final_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/final_write -- python3 $R/bench.py --steps 1 --warmup 1 $Q > $O/final_write.log 2>&1
