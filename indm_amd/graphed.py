@@ -88,6 +88,8 @@ class GraphedScore:
         # stream -- an illegal dependency inside a capture (it crashed the process, tests/parity_cases.py::case_celeba_squeeze).
         aliases = {n: p.detach().requires_grad_(True) for n, p in flat.named}
         leaves = list(aliases.values())
+        for a in leaves:
+            a._indm_param_alias = True      # hip._packed_weight must not cache re-laid-out copies of these (see there)
 
         def run():
             return torch.func.functional_call(net, aliases, (self.sx, self.sl), {"rng": _SeedRng(), "nhwc": True})

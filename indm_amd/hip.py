@@ -453,7 +453,9 @@ def _packed_weight(w, kind):
     import weakref
     # never cache a Parameter: the fused optimiser rewrites parameter memory through the flat buffer, which no version
     # counter sees.  The flow's normalised weights are fresh non-parameter tensors on every flow call.
-    cacheable = not isinstance(w, torch.nn.Parameter)
+    # ... nor an ALIAS of one (graphed.py captures the score network on detached aliases of its parameters: a hit here during
+    # the capture would freeze the warm-up pass's packed copy into the graph -- the weights of every later replay)
+    cacheable = not isinstance(w, torch.nn.Parameter) and not getattr(w, "_indm_param_alias", False)
     key = (id(w), kind)
     hit = _packed.get(key) if cacheable else None
     if hit is not None and hit[0]() is w and hit[1] == w._version:

@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _mini(nf=32, dropout=0.0):
+def _mini(nf=64, dropout=0.0):
+    """nf = 64: the last convolution (64 -> 3) takes the skinny-output path with its re-laid-out weight copy, and the attention
+    block (128 channels, 64 tokens) the fused bf16 kernels -- both have to see the UPDATED weights on every replay"""
     cfg = gu.mini_config("mini_vp_nll")
     cfg.model.nf, cfg.model.dropout = nf, dropout
     cfg.device = torch.device(DEV)
@@ -97,3 +99,48 @@ def test_graphed_dropout_draws_a_fresh_mask_per_replay():
     assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().max() > 0
     assert flat.g.abs().max() > 0
     graphed.clear()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graphed_steps_equal_eager_on_the_full_size_networks(dtype):
+    """two optimisation steps of the FULL-SIZE vp/CIFAR10/indm_nll networks (batch 2), eager vs graphed score call, same init and
+    noise: identical losses and parameters -- the second step replays the graph on UPDATED weights (the skinny last convolution's
+    re-laid-out weight copy and the bf16 packs must be refreshed inside the graph, not frozen at capture time)"""
+    from indm_amd import configs
+    res = {}
+    try:
+        for mode in ("eager", "graph"):
+            graphed.enabled(mode == "graph")
+            graphed.clear()
+            cfg = configs.get_config("vp/CIFAR10/indm_nll")
+            cfg.model.dropout = 0.0
+            cfg.training.batch_size = 2
+            cfg.device = torch.device(DEV)
+            cfg.compute_dtype = dtype
+            torch.manual_seed(0)
+            score = utils.create_model(cfg, cfg.device)
+            fl = create_flow_model(cfg).to(cfg.device)
+            with torch.no_grad():
+                for p in score.parameters():
+                    if p.dim() > 1 and p.abs().max() < 1e-6:
+                        p.copy_(torch.randn_like(p) * 0.02)
+            state, fstate, _ = utils.build_states(cfg, score, fl, cfg.device)
+            step_fn = losses.get_step_fn(cfg, sde_lib.get_sde(cfg), train=True)
+            score.train(); fl.train()
+            rec = []
+            for it in range(2):
+                g = torch.Generator().manual_seed(50 + it)
+                x = (torch.rand(2, 3, 32, 32, generator=g) * 2 - 1).to(DEV)
+                ls = step_fn(state, fstate, x, rng=DeviceRng(cfg.device, seed=9 + it, poisson_seed=3 + it))
+                rec.append(([v.clone() for v in ls], state["optimizer"].flat.p.clone(), fstate["optimizer"].flat.p.clone()))
+            res[mode] = rec
+            del state, fstate, step_fn, score, fl
+    finally:
+        hip.set_compute_dtype("f32")
+        graphed.enabled(True)
+        graphed.clear()
+    for it in range(2):
+        e, g = res["eager"][it], res["graph"][it]
+        for nm, a, b in zip(("loss", "score", "flow", "logp"), e[0], g[0]):
+            assert torch.equal(a, b), (dtype, it, nm, a, b)
+        assert torch.equal(e[1], g[1]) and torch.equal(e[2], g[2]), (dtype, it)
