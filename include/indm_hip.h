@@ -252,12 +252,20 @@ int indm_f16_unpack_f32(const void* x, float* y, long M, int N, void* stream);
  * 2: out1 = (conv + bias) .* gate (F16), out2 (optional) = conv + bias.  Returns 1 if the geometry is not covered. */
 int indm_f16_thin_conv(const float* x, const float* w, const float* bias, const void* gate, void* out1, void* out2,
                        int Nimg, int H, int W, int C, int Cout, int sign, int epilogue, void* stream);
+/* The im2col image of a skinny fp32 NHWC tensor (C % 4 == 0, 9 C <= 512) as an F16 [Nimg H W, 512] operand:
+ * out[pixel][(tap, c)] = x[pixel shifted by -sign (tap - 1)][c], zero columns behind 9 C.  The 48-channel scale of the 64 x 64
+ * flows (CelebA, 9 C = 432): its 3x3 convolutions with the 512-wide side (LopConv2d, lipschitz.py:321-369) then run as
+ * indm_f16_rows modes 0 / 1 / 4 with the weight's rows zero-padded to 512, their weight gradients as indm_f16_wgrad_gemm.
+ * Returns 1 if not covered. */
+int indm_f16_tap_spread(const float* x, void* out, int Nimg, int H, int W, int C, int sign, void* stream);
 /* A workgroup owns 64 rows x 512 columns of an F16 A[M, 512] (M % 64 == 0):
  * mode 0  out1 = A Wp + bias[n] + bias2[m / rows_per_group][n]                        (F16; LopCondConv2d 1x1 lipschitz.py:429-435 and its data gradients)
  * mode 1  (out1, out2) = Sin activation of that product (a, cos)
  * mode 2  P[M, J] = ((A Wp) .* D1) Pp[:, :J]; out1 (optional) = A Wp                (the back-to-back VJP link of indm_ires_chain_*, iresblock.py:257,269)
  * mode 3  P[M, J] = A Pp[:, :J]                                                       (3x3 conv with a skinny OUTPUT before its tap gather)
- * Wp: packed [512, 512]; Pp: packed [512, 32 | 128] panel (J <= 32 | J <= 128), P fp32 row-major.  Returns 1 if not covered. */
+ * mode 4  out1 = (A Wp + bias) .* D1, out2 (optional) = A Wp + bias                   (mode 0 with the gate epilogue of indm_f16_thin_conv)
+ * Wp: packed [512, 512]; Pp: packed [512, 32 | 128 | 448] panel (J <= 32 | J <= 128 | J <= 448), P fp32 row-major.
+ * Returns 1 if not covered. */
 int indm_f16_rows(int mode, const void* A, const void* Wp, const void* D1, const void* Pp, float* P, void* out1, void* out2,
                   const float* bias, const float* bias2, int M, int J, int rows_per_group, void* stream);
 
@@ -481,7 +489,7 @@ int indm_ema_update_f32(float* s, const float* p, long n, float one_minus_decay,
  * host call per kernel.  The kernels are the ones the op-level entry points above launch; only the SEQUENCING lives
  * here, so results are bit-identical to the op-level composition.
  * Geometry covered (return 1 otherwise, nothing enqueued; the caller composes the op-level calls): C <= 3 with
- * W | 128 and H*W % 128 == 0, or C % 4 == 0 with 9C <= 128; idim == 512; N*H*W % 64 == 0 and >= 1024.
+ * W | 128 and H*W % 128 == 0, or C % 4 == 0 with 9C <= 128 (bf16 = 2: C <= 48); idim == 512; N*H*W % 64 == 0 and >= 1024.
  * All tensors NHWC fp32; weights are the Lop-NORMALISED ones (lipschitz.py:350-359), in the layouts named below.
  * `coeffs` is a HOST array.  ws: device scratch of indm_iresblock_ws_floats() floats; splitk_ws: the dense engine's
  * split-K scratch (may be shared with other calls on the same stream). */
@@ -518,7 +526,10 @@ typedef struct {
   /* bf16 = 2 only: weights in the packed bf16 fragment order (F16 section above) */
   const void* W2_bf16w;    /* W2 [idim, idim] (= [Cin, Cout]) */
   const void* panel_bf16w; /* `panel` */
-  const void* W3_bf16w;    /* W3_ci_tapco zero-padded to [idim, 32 | 128] */
+  const void* W3_bf16w;    /* W3_ci_tapco zero-padded to [idim, 32 | 128 | 448] */
+  /* bf16 = 2 and 12 < C <= 48 only (9 C > 128 taps: the convolutions run as 64-row GEMMs on the F16 im2col operand) */
+  const void* W1_bf16w;    /* W1 as [(tap,c), idim], rows zero-padded to 512, packed */
+  const void* W3t_bf16w;   /* W3_tapco_ci, rows zero-padded to 512, packed */
 } indm_iresblock_fwd_args;
 
 /* Backward of the training-mode block (replaces autograd's double backward through iresblock.py:264-273 and g's own
@@ -536,6 +547,7 @@ typedef struct {
   float* splitk_ws; long splitk_ws_floats;
   /* bf16 = 2 only (a1, d1, a2, d2, t3, t2 are F16 buffers): packed weights */
   const void *W2_bf16w, *W2T_bf16w, *panel_bf16w;
+  const void *W1_bf16w, *W3t_bf16w;   /* 12 < C <= 48 only, as in the forward block */
 } indm_iresblock_bwd_args;
 
 /* Fixed-point inverse x <- y - g(x) (iresblock.py:78-88): iterates until every element passes

@@ -121,18 +121,18 @@ __global__ __launch_bounds__(256) void f16_unpack_kernel(const u16* __restrict__
 
 // ---------------------------------------------------------------------------------------------------------------
 // f16_rows_kernel
-enum { R_GEMM = 0, R_GEMM_ACT = 1, R_CHAIN = 2, R_THINN = 3 };
+enum { R_GEMM = 0, R_GEMM_ACT = 1, R_CHAIN = 2, R_THINN = 3, R_GEMM_GATE = 4 };
 constexpr int R_TM = 64, R_N = 512, R_NW = 8;
 constexpr int R_LDS_BYTES = R_TM * R_N * 2;   // the A tile; the stage-2 reduction buffer [8][64][32] fp32 overlays it
 
 struct RowsArgs {
   const u16* A;      // F16 [M, 512]
   const u16* Bp;     // packed [32][16][64][8] (stage 1)
-  const u16* D1;     // F16 [M, 512]: gate of the chain epilogue
+  const u16* D1;     // F16 [M, 512]: gate of the chain epilogue / of GEMM_GATE
   const u16* Pp;     // packed panel [32][JB][64][8] (stage 2 / THIN_N)
   float* P;          // [M, J] fp32 row-major
-  u16* O1;           // GEMM: C; GEMM_ACT: a; CHAIN: t2 (optional)
-  u16* O2;           // GEMM_ACT: cos
+  u16* O1;           // GEMM: C; GEMM_ACT: a; CHAIN: t2 (optional); GEMM_GATE: C .* D1
+  u16* O2;           // GEMM_ACT: cos; GEMM_GATE: C (optional)
   const float* bias;   // [512] (GEMM_ACT / GEMM, optional)
   const float* bias2;  // [M / rpg][512] (optional)
   int M, J, rpg;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const l
     return ((((tile * MB + j) * 16 + 2 * wave + i) * 2 + s) * 64 + lane) * 8;   // bf16 index
   };
 
-  if constexpr (MODE == R_GEMM || MODE == R_GEMM_ACT) {
+  if constexpr (MODE == R_GEMM || MODE == R_GEMM_ACT || MODE == R_GEMM_GATE) {
     // acc[i][j][r] = C[m = m0 + 32 j + l31][n = 64 wave + 32 i + (r & 3) + 8 (r >> 2) + 4 lhi]
     const float* b2 = p.bias2 ? p.bias2 + (m0 / p.rpg) * R_N : nullptr;   // rpg % 64 == 0: one image per tile
 #pragma unroll
@@ -229,6 +229,12 @@ __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const l
 #pragma unroll
             for (int e = 0; e < 8; ++e) sin_act(v[e], v[e], w[e]);
             *(u32x4*)(p.O2 + chunk(i, j, s)) = pack8(w);
+          }
+          if constexpr (MODE == R_GEMM_GATE) {
+            if (p.O2) *(u32x4*)(p.O2 + chunk(i, j, s)) = pack8(v);
+            unpack8(*(const u32x4*)(p.D1 + chunk(i, j, s)), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= w[e];
           }
           *(u32x4*)(p.O1 + chunk(i, j, s)) = pack8(v);
         }
@@ -970,6 +976,40 @@ __global__ __launch_bounds__(256, 2) void f16_wgrad_tr_kernel(WgradGemmArgs p) {
       }
 }
 
+// f16_tap_spread_kernel: the im2col image of a skinny NHWC fp32 tensor (C % 4 == 0, 9 C <= 512) as an F16 [pixels, 512] operand:
+//   out[pixel][(tap, c)] = x[pixel shifted by -sign (tap - 1)][c], columns >= 9 C zero
+// -- the 48-channel scale of the 64 x 64 flows (9 C = 432): its 3x3 convolutions with the 512-wide side become the 64-row
+// GEMM (modes 0 / 1 / 4 of f16_rows_kernel) on this operand, its weight gradients the row contraction of two F16 tensors.
+// One thread per 16-byte group of the output (1 KB contiguous per wave); a group's two float4 halves never straddle a tap.
+__global__ __launch_bounds__(256) void f16_tap_spread_kernel(const float* __restrict__ x, u16* __restrict__ y, long M, int H,
+                                                             int W, int C, int sign) {
+  const long groups = M * 64;
+  const int K = 9 * C, HW = H * W;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long)gridDim.x * 256) {
+    const int lane = (int)(g & 63);
+    const long c = g >> 6;
+    const int s = (int)(c & 1), nb = (int)((c >> 1) & 15);
+    const long mt = c >> 5;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const long pix = mt * 32 + l31;
+    const int r = (int)(pix % HW);
+    const int h = r / W, w = r - h * W;
+    const float* base = x + pix * C;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n0 = 32 * nb + 16 * s + 8 * q + 4 * lhi;
+      const int tap = n0 / C, cc = n0 - tap * C;
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const int hh = h - sign * (kh - 1), ww = w - sign * (kw - 1);
+      const bool ok = n0 < K && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      const float4 t = *(const float4*)(base + (ok ? ((hh - h) * W + (ww - w)) * C + cc : 0));
+      v[4 * q] = ok ? t.x : 0.f; v[4 * q + 1] = ok ? t.y : 0.f; v[4 * q + 2] = ok ? t.z : 0.f; v[4 * q + 3] = ok ? t.w : 0.f;
+    }
+    *(u32x4*)(y + g * 8) = pack8(v);
+  }
+}
+
 inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 }  // namespace
@@ -1013,6 +1053,18 @@ INDM_API int indm_f16_thin_conv(const float* x, const float* w, const float* bia
   return INDM_E_ARG;
 }
 
+INDM_API int indm_f16_tap_spread(const float* x, void* out, int Nimg, int H, int W, int C, int sign, void* stream) {
+  if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0) return INDM_E_SHAPE;
+  if (Nimg == 0) return INDM_OK;
+  const long M = (long)Nimg * H * W;
+  if ((C & 3) || 9 * C > R_N || (M % 32) || M * C >= (1L << 31)) return 1;
+  if (!x || !out || !al16(x) || !al16(out)) return INDM_E_ARG;
+  hipLaunchKernelGGL(f16_tap_spread_kernel, dim3(ew_grid(M * 64, 256)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out, M, H, W,
+                     C, sign);
+  INDM_CHECK_LAUNCH();
+  return INDM_OK;
+}
+
 INDM_API int indm_f16_rows(int mode, const void* A, const void* Bp, const void* D1, const void* Pp, float* P, void* out1,
                            void* out2, const float* bias, const float* bias2, int M, int J, int rows_per_group, void* stream) {
   if (M < 0) return INDM_E_SHAPE;
@@ -1032,12 +1084,17 @@ INDM_API int indm_f16_rows(int mode, const void* A, const void* Bp, const void* 
       if (!Bp || !out1 || !out2) return INDM_E_ARG;
       if (bias2 && (a.rpg % R_TM)) return 1;
       return launch_rows<R_GEMM_ACT, 1, false>(a, st);
+    case R_GEMM_GATE:
+      if (!Bp || !D1 || !out1) return INDM_E_ARG;
+      return launch_rows<R_GEMM_GATE, 1, false>(a, st);
     case R_CHAIN:
-      if (!Bp || !D1 || !Pp || !P || J < 1 || J > 128) return INDM_E_ARG;
+      if (!Bp || !D1 || !Pp || !P || J < 1 || J > 448) return INDM_E_ARG;
       if (J <= 32) return out1 ? launch_rows<R_CHAIN, 1, true>(a, st) : launch_rows<R_CHAIN, 1, false>(a, st);
-      return out1 ? launch_rows<R_CHAIN, 4, true>(a, st) : launch_rows<R_CHAIN, 4, false>(a, st);
+      if (J <= 128) return out1 ? launch_rows<R_CHAIN, 4, true>(a, st) : launch_rows<R_CHAIN, 4, false>(a, st);
+      return out1 ? launch_rows<R_CHAIN, 14, true>(a, st) : launch_rows<R_CHAIN, 14, false>(a, st);   // 48 channels: 9 C = 432
     case R_THINN:
-      if (!Pp || !P || J < 1 || J > 128) return INDM_E_ARG;
+      if (!Pp || !P || J < 1 || J > 448) return INDM_E_ARG;
+      if (J > 128) return launch_rows<R_THINN, 14, false>(a, st);
       return J <= 32 ? launch_rows<R_THINN, 1, false>(a, st) : launch_rows<R_THINN, 4, false>(a, st);
     default:
       return INDM_E_ARG;

@@ -146,23 +146,25 @@ static int g_pass(const Ctx& c, int preact, const float* x, const float* cb, con
 }
 
 // out[b][a][c] = x[a][b][c] (+ x2[a][b][c]) (+ y[b][a][c]) : re-layout (and sum) of the small weight-gradient GEMM results
+// (ldx = row stride of x / x2 over a: B C when dense, 512 when they are the padded [512, 512] results of the F16 row contraction)
 __global__ __launch_bounds__(256) void permute021_add_kernel(const float* __restrict__ x, const float* __restrict__ x2,
                                                              const float* __restrict__ y, float* __restrict__ out, int A,
-                                                             int B, int C) {
+                                                             int B, int C, int ldx) {
   const int total = A * B * C;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int c = i % C, ab = i / C;
     const int a = ab % A, b = ab / A;        // i indexes out[b][a][c]
-    const int src = (a * B + b) * C + c;
+    const int src = a * ldx + b * C + c;
     float v = x[src];
     if (x2) v = v + x2[src];
     if (y) v = v + y[i];
     out[i] = v;
   }
 }
-static int permute021_add(const float* x, const float* x2, const float* y, float* out, int A, int B, int C, void* st) {
+static int permute021_add(const float* x, const float* x2, const float* y, float* out, int A, int B, int C, void* st, int ldx = 0) {
   const int total = A * B * C;
-  hipLaunchKernelGGL(permute021_add_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)st, x, x2, y, out, A, B, C);
+  hipLaunchKernelGGL(permute021_add_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)st, x, x2, y, out, A, B, C,
+                     ldx > 0 ? ldx : B * C);
   INDM_CHECK_LAUNCH();
   return 0;
 }
@@ -174,14 +176,15 @@ INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int
   const long red = pad64(indm_rowreduce_ws_floats(N, (long)H * W * C)) + pad64(N);
   const long nH = pad64(M * idim / 2);   // one F16 [M, idim] tensor, in floats
   switch (which) {
+    // (C > 12, the wide form: + the F16 im2col operand; the weight-gradient results are padded [512][512])
     case 16:  // forward, training, bf16 storage: u2 (F16) + Pn, g, v, wtmp + reductions
-      return nH + nP + 4 * nC + red + 64;
+      return nH + nP + 4 * nC + red + (C > 12 ? nH : 0) + 64;
     case 17:  // forward, eval, bf16 storage: + a0, d0 (fp32) and a1, d1, a2, d2 (F16) live here
-      return nH + nP + 3 * nC + red + 2 * nC + 4 * nH + 64;
+      return nH + nP + 3 * nC + red + 2 * nC + 4 * nH + (C > 12 ? nH : 0) + 64;
     case 18: {  // backward, bf16 storage: five F16 [M, idim] buffers + the fp32 skinny side
-      const long small = 6 * pad64((long)idim * 9 * C) + pad64((long)N * idim) + pad64(idim);
+      const long small = 6 * pad64((long)idim * (C > 12 ? 512 : 9 * C)) + pad64((long)N * idim) + pad64(idim);
       const long redb = pad64(indm_colreduce_ws_floats(M, C)) + pad64(indm_colreduce_ws_floats(N, idim));
-      return 5 * nH + 2 * nP + 5 * nC + small + redb + 64;
+      return 5 * nH + 2 * nP + 5 * nC + small + redb + (C > 12 ? nH : 0) + 64;
     }
     case 0:  // forward, training: p, Pn, g, v, wtmp, vj + reductions
       return nW + nP + 4 * nC + red + 64;
@@ -205,15 +208,42 @@ INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int
 // by the chain kernel on its accumulators.  Per series iteration: 134 MB written + 134 MB read by the thin convolution,
 // 268 MB read by the chain kernel at batch 128 (fp32 tensors: 268 written, 805 read).
 namespace {
-enum { F16_PLAIN = 0, F16_ACT = 1, F16_GATE = 2, F16R_GEMM = 0, F16R_GEMM_ACT = 1, F16R_CHAIN = 2, F16R_THINN = 3 };
+enum { F16_PLAIN = 0, F16_ACT = 1, F16_GATE = 2, F16R_GEMM = 0, F16R_GEMM_ACT = 1, F16R_CHAIN = 2, F16R_THINN = 3, F16R_GEMM_GATE = 4 };
 
+// 12 < C (the 48-channel scale of the 64 x 64 flows, 9 C = 432 taps): no gathering thin kernel -- the skinny side's im2col image
+// becomes an F16 [M, 512] operand (indm_f16_tap_spread into `colF`, zero columns behind 9 C) and the convolution the 64-row
+// GEMM on it with the K-padded packed weights (`wp`), epilogues unchanged; weight gradients: the row contraction of two F16
+// tensors (indm_f16_wgrad_gemm) instead of the thin form.
 struct Ctx16 {
   int N, H, W, C, Cw;
   long M;
   void* st;
   Timer* timer;
-  int thin(const float* x, const float* w2d, const float* bias, const void* gate, void* o1, void* o2, int sign, int epi) const {
-    return indm_f16_thin_conv(x, w2d, bias, gate, o1, o2, N, H, W, C, Cw, sign, epi, st);
+  void* colF;   // wide only
+  bool wide() const { return C > 12; }
+  int thin(const float* x, const float* w2d, const void* wp, const float* bias, const void* gate, void* o1, void* o2, int sign,
+           int epi) const {
+    if (!wide()) return indm_f16_thin_conv(x, w2d, bias, gate, o1, o2, N, H, W, C, Cw, sign, epi, st);
+    int r = indm_f16_tap_spread(x, colF, N, H, W, C, sign, st);
+    if (r != 0) return r;
+    const int mode = epi == F16_PLAIN ? F16R_GEMM : epi == F16_ACT ? F16R_GEMM_ACT : F16R_GEMM_GATE;
+    return indm_f16_rows(mode, colF, wp, gate, nullptr, nullptr, o1, o2, bias, nullptr, (int)M, 0, 1, st);
+  }
+  // weight gradient of a 3x3 convolution between the skinny side `xs` (fp32 NHWC, spread with `sign`) and the F16 tensor `wide16`
+  // (.* gate): tr = 1: out[n][(tap, c)] (row stride ld_out()), tr = 0: out[(tap, c)][n]
+  int ld_out() const { return wide() ? 512 : 9 * C; }
+  int wgrad(const float* xs, int sign, float* col, const void* wide16, const void* gate, float* out, int tr, float* sk,
+            long skn) const {
+    const int J = 9 * C;
+    if (!wide()) {
+      int r = indm_tap_spread_f32(xs, col, N, H, W, C, sign, 1.0f, st);
+      if (r != 0) return r;
+      return indm_f16_thin_wgrad(col, wide16, gate, out, M, J, 1.0f, tr, tr ? J : Cw, sk, skn, st);
+    }
+    int r = indm_f16_tap_spread(xs, colF, N, H, W, C, sign, st);
+    if (r != 0) return r;
+    if (tr) return indm_f16_wgrad_gemm(wide16, gate, colF, out, M, 1.0f, 0, sk, skn, st);   // [Cw][512]: columns (tap, c), zeros behind
+    return gate ? INDM_E_ARG : indm_f16_wgrad_gemm(colF, nullptr, wide16, out, M, 1.0f, 0, sk, skn, st);   // [512][Cw]: the first 9 C rows
   }
   int chain(const void* u2, const void* W2Tp, const void* d1, const void* panelp, float* P, void* t2) const {
     const int J = 9 * C;
@@ -238,12 +268,12 @@ struct Ctx16 {
 
 static bool covered16(int N, int H, int W, int C, int idim) {
   const long M = (long)N * H * W;
-  return idim == 512 && (C <= 3 || (C <= 12 && !(C & 3))) && M >= 1024 && !(M % 128) && !(((long)H * W) % 64) &&
+  return idim == 512 && (C <= 3 || (C <= 48 && !(C & 3))) && M >= 1024 && !(M % 128) && !(((long)H * W) % 64) &&
          M * 9 * C < (1L << 31);
 }
 
 // g(x, h) on F16 tensors: fills a0, d0 (preact, fp32), a1, d1, a2, d2 (F16) and g (fp32) [+ y = x + g]
-static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb, const float* W1, const void* W2p,
+static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb, const float* W1, const void* W1p, const void* W2p,
                     const void* W3p, const float* b1, const float* b2, const float* b3, float* a0, float* d0, void* a1, void* d1,
                     void* a2, void* d2, float* Pn, float* g, float* y_res) {
   const long nC = c.M * c.C;
@@ -252,7 +282,7 @@ static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb,
     TRY(indm_sincos_act_fwd_f32(x, a0, d0, nC, c.st));
     in = a0;
   }
-  TRY(c.thin(in, W1, b1, nullptr, a1, d1, -1, F16_ACT));                                     // (a1, d1) = Sin(conv(a0, W1) + b1)
+  TRY(c.thin(in, W1, W1p, b1, nullptr, a1, d1, -1, F16_ACT));                                // (a1, d1) = Sin(conv(a0, W1) + b1)
   TRY(indm_f16_rows(F16R_GEMM_ACT, a1, W2p, nullptr, nullptr, nullptr, a2, d2, b2, cb, (int)c.M, 0, c.H * c.W, c.st));   // Sin(a1 W2 + b2 + cb[n])
   TRY(indm_f16_rows(F16R_THINN, a2, nullptr, nullptr, W3p, Pn, nullptr, nullptr, nullptr, nullptr, (int)c.M, 9 * c.C, 1, c.st));
   if (y_res) TRY(indm_tap_gather_acc_f32(Pn, b3, nullptr, g, x, y_res, 1.0f, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
@@ -263,9 +293,10 @@ static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb,
 static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
   if (!covered16(a->N, a->H, a->W, a->C, a->idim) || !a->panel) return 1;
   if (!a->x || !a->cb || !a->W1 || !a->W3_tapco_ci || !a->b1 || !a->b2 || !a->b3 || !a->eps || !a->y || !a->logdet ||
-      !a->W2T_bf16w || !a->W2_bf16w || !a->panel_bf16w || !a->W3_bf16w || (a->ncoeff > 0 && !a->coeffs) || a->ncoeff < 0)
+      !a->W2T_bf16w || !a->W2_bf16w || !a->panel_bf16w || !a->W3_bf16w || (a->ncoeff > 0 && !a->coeffs) || a->ncoeff < 0 ||
+      (a->C > 12 && (!a->W1_bf16w || !a->W3t_bf16w)))
     return INDM_E_ARG;
-  Ctx16 c = {a->N, a->H, a->W, a->C, a->idim, (long)a->N * a->H * a->W, stream, (Timer*)a->timer};
+  Ctx16 c = {a->N, a->H, a->W, a->C, a->idim, (long)a->N * a->H * a->W, stream, (Timer*)a->timer, nullptr};
   const long nC = c.M * c.C, nP = c.M * 9 * c.C, nH = c.M * c.Cw / 2;
   Bump ws = {a->ws, a->ws_floats, 0};
   float *a0 = a->a0, *d0 = a->d0;
@@ -279,9 +310,12 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
   void* u2 = ws.get(nH);
   float *Pn = ws.get(nP), *g = ws.get(nC), *v = ws.get(nC);
   float* rws = ws.get(indm_rowreduce_ws_floats(c.N, (long)c.H * c.W * c.C));
-  if (!u2 || !Pn || !g || !v || !rws || (!a->training && (!a1 || !d2 || (a->preact && !d0)))) return INDM_E_ARG;
+  if (c.wide()) c.colF = ws.get(nH);
+  if (!u2 || !Pn || !g || !v || !rws || (c.wide() && !c.colF) || (!a->training && (!a1 || !d2 || (a->preact && !d0))))
+    return INDM_E_ARG;
   const int K = a->ncoeff;
-  TRY(g_pass16(c, a->preact, a->x, a->cb, a->W1, a->W2_bf16w, a->W3_bf16w, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2, Pn, g, a->y));
+  TRY(g_pass16(c, a->preact, a->x, a->cb, a->W1, a->W1_bf16w, a->W2_bf16w, a->W3_bf16w, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2,
+               Pn, g, a->y));
   const float* gate0 = a->preact ? d0 : nullptr;
   if (a->training) {
     float* wtmp = ws.get(nC);
@@ -289,7 +323,7 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
     const float *vin = a->eps, *win = a->eps;
     for (int k = 0; k < K; ++k) {
       float* wout = ((K - 1 - k) & 1) ? wtmp : a->w;
-      TRY(c.thin(vin, a->W3_tapco_ci, nullptr, d2, u2, nullptr, 1, F16_GATE));            // u2 = (C3^T v) .* d2
+      TRY(c.thin(vin, a->W3_tapco_ci, a->W3t_bf16w, nullptr, d2, u2, nullptr, 1, F16_GATE));   // u2 = (C3^T v) .* d2
       TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, nullptr));
       TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, win, wout, a->coeffs[k], c.N, c.H, c.W, c.C, -1, 1.0f, stream));
       vin = v;
@@ -297,7 +331,7 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
     }
     if (K == 0 && hipMemcpyAsync(a->w, a->eps, nC * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
       return INDM_E_LAUNCH;
-    TRY(c.thin(a->w, a->W3_tapco_ci, nullptr, d2, u2, a->t3, 1, F16_GATE));               // ... and t3 itself, saved
+    TRY(c.thin(a->w, a->W3_tapco_ci, a->W3t_bf16w, nullptr, d2, u2, a->t3, 1, F16_GATE));   // ... and t3 itself, saved
     TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, a->t2));
     if (a->preact) {
       TRY(indm_tap_gather_f32(Pn, nullptr, a->c1, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
@@ -312,7 +346,7 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
   if (!tr) return INDM_E_ARG;
   const float* vin = a->eps;
   for (int k = 0; k < K; ++k) {
-    TRY(c.thin(vin, a->W3_tapco_ci, nullptr, d2, u2, nullptr, 1, F16_GATE));
+    TRY(c.thin(vin, a->W3_tapco_ci, a->W3t_bf16w, nullptr, d2, u2, nullptr, 1, F16_GATE));
     TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, nullptr));
     TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, nullptr, nullptr, 0.0f, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
     vin = v;
@@ -410,26 +444,29 @@ static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
       !a->W3_tapco_ci || !a->W2_bf16w || !a->W2T_bf16w || !a->panel_bf16w || (a->preact && (!a->d0 || !a->c1)) || !a->dx ||
       !a->dcb || !a->dW1 || !a->dW2 || !a->dW3 || !a->dW2T || !a->db1 || !a->db2 || !a->db3 || !a->splitk_ws)
     return INDM_E_ARG;
-  Ctx16 c = {a->N, a->H, a->W, a->C, a->idim, (long)a->N * a->H * a->W, stream, nullptr};
+  Ctx16 c = {a->N, a->H, a->W, a->C, a->idim, (long)a->N * a->H * a->W, stream, nullptr, nullptr};
   const int C = c.C, Cw = c.Cw, Mi = (int)c.M, rps = c.H * c.W, J = 9 * C;
+  if (c.wide() && (!a->W1_bf16w || !a->W3t_bf16w)) return INDM_E_ARG;
   const long nC = c.M * C, nP = c.M * 9 * C, nH = c.M * Cw / 2;
+  const long nQ = (long)Cw * (c.wide() ? 512 : J);   // one weight-gradient result: [Cw][9 C], or the padded [512][512] of the row contraction
+  const int ldq = c.ld_out();
   Bump ws = {a->ws, a->ws_floats, 0};
   void *bufA = ws.get(nH), *bufB = ws.get(nH), *bufC = ws.get(nH), *bufD = ws.get(nH), *bufE = ws.get(nH);
   float *col = ws.get(nP), *Pn = ws.get(nP);
   float *dvj = ws.get(nC), *q0 = ws.get(nC), *dd0 = ws.get(nC), *da0 = ws.get(nC), *tmpc = ws.get(nC);
-  float *qa = ws.get((long)Cw * J), *qb = ws.get((long)Cw * J), *qc = ws.get((long)Cw * J), *qd = ws.get((long)Cw * J);
+  float *qa = ws.get(nQ), *qb = ws.get(nQ), *qc = ws.get(nQ), *qd = ws.get(nQ);
   float* seg1 = ws.get((long)c.N * Cw);
   float *cr_c = ws.get(indm_colreduce_ws_floats(c.M, C)), *cr_n = ws.get(indm_colreduce_ws_floats(c.N, Cw));
+  if (c.wide()) c.colF = ws.get(nH);
   if (!bufA || !bufB || !bufC || !bufD || !bufE || !col || !Pn || !dvj || !q0 || !dd0 || !da0 || !tmpc || !qa || !qb || !qc ||
-      !qd || !seg1 || !cr_c || !cr_n)
+      !qd || !seg1 || !cr_c || !cr_n || (c.wide() && !c.colF))
     return INDM_E_ARG;
   float* sk = a->splitk_ws;
   const long skn = a->splitk_ws_floats;
   // ---- g path, level 3:  g = conv(a2, W3) + b3 ----
   void* da2 = bufA;
-  TRY(c.thin(a->gy, a->W3_tapco_ci, nullptr, nullptr, da2, nullptr, 1, F16_PLAIN));                       // da2 = C3^T gy
-  TRY(indm_tap_spread_f32(a->gy, col, c.N, c.H, c.W, C, 1, 1.0f, stream));
-  TRY(indm_f16_thin_wgrad(col, a->a2, nullptr, qa, c.M, J, 1.0f, 1, J, sk, skn, stream));                   // a2^T spread(gy): [Cw, 9C]
+  TRY(c.thin(a->gy, a->W3_tapco_ci, a->W3t_bf16w, nullptr, nullptr, da2, nullptr, 1, F16_PLAIN));          // da2 = C3^T gy
+  TRY(c.wgrad(a->gy, 1, col, a->a2, nullptr, qa, 1, sk, skn));                                             // a2^T spread(gy): [Cw, 9C]
   TRY(indm_colreduce_f32(a->gy, nullptr, a->db3, c.M, C, 0, 1.0f, 0.0f, cr_c, stream));
   // ---- reverse sweep of the last VJP chain ----
   TRY(indm_scale_rows_f32(a->eps, a->gld, dvj, c.N, (long)rps * C, stream));
@@ -439,14 +476,12 @@ static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
     q0p = q0;
   }
   void *q1 = bufB, *q1g = bufC;
-  TRY(c.thin(q0p, a->W1, nullptr, a->d1, q1g, q1, -1, F16_GATE));                                          // q1 = conv(q0, W1); q1g = q1 .* d1 (= dt2)
-  TRY(indm_tap_spread_f32(q0p, col, c.N, c.H, c.W, C, -1, 1.0f, stream));
-  TRY(indm_f16_thin_wgrad(col, a->t2, a->d1, qb, c.M, J, 1.0f, 1, J, sk, skn, stream));                     // (t2 .* d1)^T spread(q0)
+  TRY(c.thin(q0p, a->W1, a->W1_bf16w, nullptr, a->d1, q1g, q1, -1, F16_GATE));                             // q1 = conv(q0, W1); q1g = q1 .* d1 (= dt2)
+  TRY(c.wgrad(q0p, -1, col, a->t2, a->d1, qb, 1, sk, skn));                                                // (t2 .* d1)^T spread(q0)
   void* du2 = bufD;
   TRY(indm_f16_rows(F16R_GEMM, q1g, a->W2_bf16w, nullptr, nullptr, nullptr, du2, nullptr, nullptr, nullptr, Mi, 0, 1, stream));   // du2 = (q1 .* d1) W2
-  TRY(indm_tap_spread_f32(a->w, col, c.N, c.H, c.W, C, 1, 1.0f, stream));
-  TRY(indm_f16_thin_wgrad(col, du2, a->d2, qc, c.M, J, 1.0f, 1, J, sk, skn, stream));                       // (du2 .* d2)^T spread(w)
-  TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream));
+  TRY(c.wgrad(a->w, 1, col, du2, a->d2, qc, 1, sk, skn));                                                  // (du2 .* d2)^T spread(w)
+  TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream, ldq));
   void* dp2 = bufE;
   TRY(indm_f16_bwd_act(da2, du2, a->d2, a->a2, a->t3, dp2, a->dcb, c.M, rps, stream));
   TRY(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
@@ -461,9 +496,8 @@ static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
   // ---- level 1:  p1 = conv(a0, W1) + b1 ----
   TRY(indm_f16_rows(F16R_THINN, dp1, nullptr, nullptr, a->panel_bf16w, Pn, nullptr, nullptr, nullptr, nullptr, Mi, J, 1, stream));
   TRY(indm_tap_gather_f32(Pn, nullptr, da0, c.N, c.H, c.W, C, -1, 1.0f, stream));
-  TRY(indm_tap_spread_f32(a->a0, col, c.N, c.H, c.W, C, -1, 1.0f, stream));
-  TRY(indm_f16_thin_wgrad(col, dp1, nullptr, qd, c.M, J, 1.0f, 0, Cw, sk, skn, stream));                    // spread(a0)^T dp1: [9C, Cw]
-  TRY(permute021_add(qb, nullptr, qd, a->dW1, Cw, J, 1, stream));
+  TRY(c.wgrad(a->a0, -1, col, dp1, nullptr, qd, 0, sk, skn));                                              // spread(a0)^T dp1: [9C, Cw]
+  TRY(permute021_add(qb, nullptr, qd, a->dW1, Cw, J, 1, stream, ldq));
   if (a->preact) {
     TRY(indm_sincos_act_bwd_f32(da0, dd0, a->a0, a->d0, tmpc, nC, stream));
     TRY(indm_axpby_f32(a->gy, tmpc, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));

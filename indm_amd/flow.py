@@ -436,6 +436,19 @@ class ResidualFlow(nn.Module):
                     if hip.storage_dtype() == "bf16":   # the thin-N panels of the F16 kernels: W1^T and W3 as [idim, 9C]
                         hip.pack_w2t_bf16(list(qs))
                         hip.pack_w2t_bf16([hip._packed_weight(Ws[blks.index(b)][2], "ci_tapco") for b in sc])
+                elif hip.storage_dtype() == "bf16" and hip.f16_wide(C_) and I_ == 512:
+                    # the 48-channel scale of the 64 x 64 flows on the F16 drivers (round 6): panels [idim, 9C -> 448] for the chain /
+                    # thin-N stages, W1 and W3^T as K-padded GEMM operands for the convolutions on the im2col operand
+                    w3s = [Ws[blks.index(b)][2] for b in sc]
+                    hip.prepack_weights(w3s)
+                    pn = torch.nn.functional.pad(w1.reshape(nb_, 9 * C_, I_).transpose(1, 2), (0, -(9 * C_) % 32)).contiguous()
+                    qs = pn.unbind(0)
+                    for b, q in zip(sc, qs):
+                        panels[b] = q
+                    hip.pack_w2t_bf16(list(qs))
+                    hip.pack_w2t_bf16([hip._packed_weight(w, "ci_tapco") for w in w3s])
+                    hip.pack_kpad_bf16([Ws[blks.index(b)][0] for b in sc], "w1")
+                    hip.pack_kpad_bf16(w3s, "w3t")
         return {b: (list(W) + [w2ts[i], panels.get(b)], cbs[i]) for i, (b, W) in enumerate(zip(blks, Ws))}
 
     def fwdpass(self, x, h, eval_logdet, rng, stats=None):

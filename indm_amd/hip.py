@@ -131,6 +131,7 @@ _SIGS = {
     "indm_f16_pack_f32": [c_p, c_p, c_l, c_i, c_p],
     "indm_f16_unpack_f32": [c_p, c_p, c_l, c_i, c_p],
     "indm_f16_thin_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "indm_f16_tap_spread": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "indm_f16_bwd_act_ok": [c_l, c_l],
     "indm_f16_bwd_act": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
@@ -1457,7 +1458,7 @@ def pack_weight_bf16(w):
 
 
 F16_PLAIN, F16_ACT, F16_GATE = 0, 1, 2
-F16_GEMM, F16_GEMM_ACT, F16_CHAIN, F16_THINN = 0, 1, 2, 3
+F16_GEMM, F16_GEMM_ACT, F16_CHAIN, F16_THINN, F16_GEMM_GATE = 0, 1, 2, 3, 4
 
 
 def f16_thin_conv(x, w2d, sign, epilogue=F16_PLAIN, bias=None, gate=None, want_raw=False):
@@ -1477,11 +1478,12 @@ def f16_thin_conv(x, w2d, sign, epilogue=F16_PLAIN, bias=None, gate=None, want_r
 
 
 def f16_rows(mode, A, M, Wp=None, D1=None, Pp=None, J=0, bias=None, bias2=None, rows_per_group=1, want_t2=False):
-    """indm_f16_rows: mode F16_GEMM -> C; F16_GEMM_ACT -> (a, cos); F16_CHAIN -> (P, t2 or None); F16_THINN -> P.  None if not covered."""
+    """indm_f16_rows: mode F16_GEMM -> C; F16_GEMM_ACT -> (a, cos); F16_CHAIN -> (P, t2 or None); F16_THINN -> P;
+    F16_GEMM_GATE -> (C .* D1, C).  None if not covered."""
     dev = A.device
     new16 = lambda: torch.empty(M * 512, dtype=torch.bfloat16, device=dev)  # noqa: E731
-    o1 = new16() if (mode in (F16_GEMM, F16_GEMM_ACT) or (mode == F16_CHAIN and want_t2)) else None
-    o2 = new16() if mode == F16_GEMM_ACT else None
+    o1 = new16() if (mode in (F16_GEMM, F16_GEMM_ACT, F16_GEMM_GATE) or (mode == F16_CHAIN and want_t2)) else None
+    o2 = new16() if mode in (F16_GEMM_ACT, F16_GEMM_GATE) else None
     P = torch.empty((M, J), dtype=torch.float32, device=dev) if mode in (F16_CHAIN, F16_THINN) else None
     st = lib().indm_f16_rows(mode, _ptr16(A), _ptr16(Wp), _ptr16(D1), _ptr16(Pp), _ptr(P),
                              o1.data_ptr() if o1 is not None else None, o2.data_ptr() if o2 is not None else None,
@@ -1491,11 +1493,22 @@ def f16_rows(mode, A, M, Wp=None, D1=None, Pp=None, J=0, bias=None, bias2=None, 
     _chk(st, "indm_f16_rows")
     if mode == F16_GEMM:
         return o1
-    if mode == F16_GEMM_ACT:
+    if mode in (F16_GEMM_ACT, F16_GEMM_GATE):
         return o1, o2
     if mode == F16_CHAIN:
         return P, o1
     return P
+
+
+def f16_tap_spread(x, sign):
+    """indm_f16_tap_spread: NHWC fp32 x [N,H,W,C] -> F16 [N H W, 512] im2col operand (None if not covered)"""
+    N, H, W, C = x.shape
+    out = torch.empty(N * H * W * 512, dtype=torch.bfloat16, device=x.device)
+    st = lib().indm_f16_tap_spread(_ptr(x), out.data_ptr(), N, H, W, C, sign, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_tap_spread")
+    return out
 
 
 def f16_bwd_act(da, du, d, a, t, R, rows_per_seg=None):
@@ -1808,7 +1821,7 @@ class _IResFwdArgs(ctypes.Structure):
                 + [("ncoeff", c_i)]
                 + [(n, c_p) for n in ("y", "logdet", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w")]
                 + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("timer", c_p)]
-                + [(n, c_p) for n in ("W2_bf16w", "panel_bf16w", "W3_bf16w")])
+                + [(n, c_p) for n in ("W2_bf16w", "panel_bf16w", "W3_bf16w", "W1_bf16w", "W3t_bf16w")])
 
 
 class _IResBwdArgs(ctypes.Structure):
@@ -1817,7 +1830,7 @@ class _IResBwdArgs(ctypes.Structure):
                 + [(n, c_p) for n in ("gy", "gld", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w", "eps", "W1", "W2",
                                       "W2T", "W3_tapco_ci", "dx", "dcb", "dW1", "dW2", "dW3", "dW2T", "db1", "db2", "db3")]
                 + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l)]
-                + [(n, c_p) for n in ("W2_bf16w", "W2T_bf16w", "panel_bf16w")])
+                + [(n, c_p) for n in ("W2_bf16w", "W2T_bf16w", "panel_bf16w", "W1_bf16w", "W3t_bf16w")])
 
 
 BLOCK_DRIVERS = {"on": os.environ.get("INDM_BLOCK_DRIVERS", "1") != "0"}   # tools / tests switch to the op-level composition
@@ -1887,8 +1900,42 @@ def _w2t_bf16w(w2t):
 
 def _f16_geometry(N, H, W, C, idim):
     M = N * H * W
-    return (idim == 512 and (C <= 3 or (C <= 12 and C % 4 == 0)) and M >= 1024 and M % 128 == 0 and (H * W) % 64 == 0
+    return (idim == 512 and (C <= 3 or (C <= 48 and C % 4 == 0)) and M >= 1024 and M % 128 == 0 and (H * W) % 64 == 0
             and M * 9 * C < (1 << 31))
+
+
+def f16_wide(C):
+    """12 < C <= 48 (C % 4 == 0): a flow scale the F16 drivers run on the im2col operand (indm_f16_tap_spread) instead of the
+    gathering thin kernels -- the 48-channel scale of the 64 x 64 flows"""
+    return 12 < C <= 48 and C % 4 == 0
+
+
+_kpad_packed = {}  # (id(w), kind) -> (weakref, version, packed bf16 copy of w as [9C -> 512, idim])
+
+
+def pack_kpad_bf16(ws, kind):
+    """F16 wide scales: the skinny 3x3 weights of a whole scale as K-padded packed GEMM operands, registered per weight object.
+    kind 'w1': w [3,3,C,idim] -> [(tap,c), idim]; 'w3t': w [3,3,idim,C] -> [(tap,co), ci].  Rows zero-padded to 512."""
+    import weakref
+    with torch.no_grad():
+        st = torch.stack([w.detach() for w in ws])
+        n, KH, KW, A, B = st.shape
+        m = st.reshape(n, KH * KW * A, B) if kind == "w1" else st.permute(0, 1, 2, 4, 3).reshape(n, KH * KW * B, A)
+        m = torch.nn.functional.pad(m, (0, 0, 0, 512 - m.shape[1]))
+    pk = pack_w2t_bf16(list(m.unbind(0)))
+    for k in [k for k, v in _kpad_packed.items() if v[0]() is None]:
+        del _kpad_packed[k]
+    for i, w in enumerate(ws):
+        if not isinstance(w, torch.nn.Parameter):
+            _kpad_packed[(id(w), kind)] = (weakref.ref(w), w._version, pk[i])
+    return pk
+
+
+def packed_kpad_bf16(w, kind):
+    hit = _kpad_packed.get((id(w), kind))
+    if hit is None or hit[0]() is not w or hit[1] != w._version:
+        return pack_kpad_bf16([w], kind)[0]
+    return hit[2]
 
 
 _F16_STATS = {}
@@ -1926,6 +1973,9 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     if f16:
         keep = [packed_bf16(W2T), packed_bf16(W2), packed_bf16(panel), packed_bf16(w3ct)]   # alive until the call returns
         a.W2T_bf16w, a.W2_bf16w, a.panel_bf16w, a.W3_bf16w = (t.data_ptr() for t in keep)
+        if f16_wide(C):
+            keep += [packed_kpad_bf16(W1, "w1"), packed_kpad_bf16(W3, "w3t")]
+            a.W1_bf16w, a.W3t_bf16w = keep[-2].data_ptr(), keep[-1].data_ptr()
     a.panel, a.b1, a.b2, a.b3, a.eps = _ptr(panel), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(eps)
     cf = (ctypes.c_float * max(1, len(coeffs)))(*coeffs)
     a.coeffs, a.ncoeff = ctypes.cast(cf, c_p), len(coeffs)
@@ -1978,6 +2028,9 @@ def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact, panel=None):
             return None
         keep = [packed_bf16(W2), packed_bf16(W2T), packed_bf16(panel)]
         a.W2_bf16w, a.W2T_bf16w, a.panel_bf16w = (t.data_ptr() for t in keep)
+        if f16_wide(C):
+            keep += [packed_kpad_bf16(W1, "w1"), packed_kpad_bf16(W3, "w3t")]
+            a.W1_bf16w, a.W3t_bf16w = keep[-2].data_ptr(), keep[-1].data_ptr()
     else:
         a.a1, a.d1, a.a2, a.d2, a.t3, a.t2, a.w, a.eps = (_ptr(t) for t in (a1, d1, a2, d2, t3, t2, w, eps))
     a.W1, a.W2, a.W2T, a.W3_tapco_ci = _ptr(W1), _ptr(W2), _ptr(W2T), _ptr(_packed_weight(W3, "tapco_ci"))

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _flow(seed=3):
-    cfg = configs.get_config("vp/CIFAR10/indm_nll")
+def _flow(seed=3, name="vp/CIFAR10/indm_nll"):
+    cfg = configs.get_config(name)
     cfg.device = torch.device(DEV)
     torch.manual_seed(seed)
     return cfg, create_flow_model(cfg).to(DEV)
@@ -106,19 +106,25 @@ def _rel(a, b):
     return (a - b).norm().item() / (b.norm().item() + 1e-30)
 
 
-@pytest.mark.parametrize("B", [4, 16])
-def test_bf16_storage_block_tracks_bf16_compute_on_fp32_tensors(drivers, B):
+@pytest.mark.parametrize("B,name", [(4, "vp/CIFAR10/indm_nll"), (16, "vp/CIFAR10/indm_nll"), (4, "vp/CELEBA/indm_fid")])
+def test_bf16_storage_block_tracks_bf16_compute_on_fp32_tensors(drivers, B, name):
     """bf16 STORAGE of the flow's 512-wide tensors (F16 fragment order, csrc/flow_f16.hip: activations rounded to bf16
     once more than the compute-only mode, hardware sine / cosine, gates applied at other points of the chain) against the
     bf16-compute / fp32-tensor drivers and the fp32 drivers on the same weights and noise: outputs, log-dets and every
-    parameter gradient."""
-    cfg, fl = _flow()
-    x = torch.rand(B, 3, 32, 32, device=DEV) * 2 - 1
+    parameter gradient.  CelebA: the 12-channel scale at 32 x 32 and the 48-channel scale at 16 x 16 (round 6: the wide form of
+    the F16 drivers -- im2col operand + 64-row GEMMs; before, that scale ran the op-level composition on fp32 tensors)."""
+    cfg, fl = _flow(name=name)
+    S = cfg.data.image_size
+    x = torch.rand(B, 3, S, S, device=DEV) * 2 - 1
     try:
         hip.set_compute_dtype("bf16")
         hip.f16_storage(True)
         assert hip.storage_dtype() == "bf16"
+        hip.f16_stats(reset=True)
         z2, ld2, g2 = _train_pass(cfg, fl, x, True)
+        stats = hip.f16_stats(reset=True)
+        want = {(3, 32, 32), (12, 16, 16)} if S == 32 else {(12, 32, 32), (48, 16, 16)}
+        assert set(stats) == want and all(v[0] > 0 and v[1] == 0 for v in stats.values()), stats
         hip.f16_storage(False)
         z1, ld1, g1 = _train_pass(cfg, fl, x, True)
         hip.set_compute_dtype("f32")

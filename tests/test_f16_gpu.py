@@ -80,6 +80,36 @@ def test_thin_conv(N, H, W, C, sign):
     close16(hip.f16_unpack(u2, M, Co), (ref - b.double()) * r16(g).double(), "thin conv gated, no bias", ulps=1.5)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(4, 16, 16, 48), (32, 16, 16, 48), (2, 32, 32, 16)])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_wide_conv_on_the_im2col_operand(N, H, W, C, sign):
+    """12 < C <= 48 (CelebA's 48-channel flow scale, 9 C = 432 taps): indm_f16_tap_spread + the 64-row GEMM with its three
+    epilogues = the convolution the thin kernel computes at C <= 12 (same fp64 statement, same tolerances)."""
+    Co, M, K = 512, N * H * W, 9 * C
+    x, w, b = rnd(N, H, W, C), rnd(K, Co, seed=1, scale=0.1), rnd(Co, seed=2)
+    col = hip.f16_tap_spread(x.to(DEV), sign)
+    assert col is not None
+    # the operand is exactly the fp32 spread, zero-padded to 512 columns and rounded to bf16
+    want = hip.f16_pack(torch.nn.functional.pad(hip.tap_spread(x.to(DEV), sign).view(M, K), (0, 512 - K)))
+    assert torch.equal(col.view(torch.int16), want.view(torch.int16))
+    Wp = hip.pack_weight_bf16(torch.nn.functional.pad(w, (0, 0, 0, 512 - K)).to(DEV))
+    ref = _emu.conv3x3_thin(r16(x).double(), r16(w).double(), sign).reshape(M, Co) + b.double()
+    out = hip.f16_rows(hip.F16_GEMM, col, M, Wp=Wp, bias=b.to(DEV))
+    close16(hip.f16_unpack(out, M, Co), ref, "wide conv", atol=1e-5)
+    a, d = hip.f16_rows(hip.F16_GEMM_ACT, col, M, Wp=Wp, bias=b.to(DEV))
+    close16(hip.f16_unpack(a, M, Co), torch.sin(2 * math.pi * ref) / (2 * math.pi), "wide conv sin", atol=3e-5)
+    close16(hip.f16_unpack(d, M, Co), torch.cos(2 * math.pi * ref), "wide conv cos", atol=2e-4)
+    g = rnd(M, Co, seed=5)
+    u, raw = hip.f16_rows(hip.F16_GEMM_GATE, col, M, Wp=Wp, D1=hip.f16_pack(g.to(DEV)), bias=b.to(DEV))
+    close16(hip.f16_unpack(raw, M, Co), ref, "wide conv raw", atol=1e-5)
+    close16(hip.f16_unpack(u, M, Co), ref * r16(g).double(), "wide conv gated", ulps=1.5, atol=1e-5)
+
+
+def test_tap_spread_declines_uncovered_geometry():
+    assert hip.f16_tap_spread(rnd(2, 16, 16, 6).to(DEV), -1) is None       # C % 4
+    assert hip.f16_tap_spread(rnd(2, 16, 16, 64).to(DEV), -1) is None      # 9 C > 512
+
+
 def test_thin_conv_declines_uncovered_geometry():
     assert hip.f16_thin_conv(rnd(2, 32, 32, 5).to(DEV), rnd(45, 512).to(DEV), -1) is None
     assert hip.f16_thin_conv(rnd(1, 8, 8, 3).to(DEV), rnd(27, 512).to(DEV), -1) is None      # 64 pixels: M % 128
@@ -102,13 +132,13 @@ def test_rows_gemm_and_activation(M):
     close16(hip.f16_unpack(d, M, N)[idx.to(DEV)], torch.cos(2 * math.pi * refb), "rows act cos", atol=2e-4)
 
 
-@pytest.mark.parametrize("M,J", [(64, 27), (4096, 27), (8192, 108), (131072, 27), (32768, 108)])
+@pytest.mark.parametrize("M,J", [(64, 27), (4096, 27), (8192, 108), (131072, 27), (32768, 108), (1024, 432), (8192, 432), (65536, 144)])
 def test_rows_chain_and_thin_n(M, J):
     K = N = 512
     A, Wm, D1 = rnd(M, K), rnd(K, N, seed=1, scale=0.05), rnd(M, N, seed=4)
     panel = rnd(N, J, seed=6, scale=0.1)
     A16, D16 = hip.f16_pack(A.to(DEV)), hip.f16_pack(D1.to(DEV))
-    Wp, Pp = hip.pack_weight_bf16(Wm.to(DEV)), hip.pack_weight_bf16(torch.nn.functional.pad(panel, (0, (32 if J <= 32 else 128) - J)).to(DEV))
+    Wp, Pp = hip.pack_weight_bf16(Wm.to(DEV)), hip.pack_weight_bf16(torch.nn.functional.pad(panel, (0, (32 if J <= 32 else 128 if J <= 128 else 448) - J)).to(DEV))
     idx = torch.cat([torch.arange(0, M, max(1, M // 256)), torch.arange(max(0, M - 70), M)]).unique()
     t2 = r16(A)[idx].double() @ r16(Wm).double()
     u1 = r16((t2 * r16(D1)[idx].double()).float()).double()       # the gated intermediate is rounded to bf16 for the second MFMA

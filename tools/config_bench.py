@@ -20,6 +20,8 @@ only = sys.argv[1:]
 for name, cname, B, dtype, model_kw in CASES:
     if only and not any(o in name for o in only):
         continue
+    if os.environ.get("INDM_CB_DTYPE", dtype) != dtype:
+        continue
     cfg = configs.get_config(cname)
     cfg.device = dev
     cfg.training.batch_size = B

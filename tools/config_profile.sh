@@ -1,17 +1,10 @@
-# rocprofv3 kernel statistics of one BASELINE configuration's per-rank-shard step (run through gpurun):
-# usage: config_profile.sh "#3" | "#4" | "#5"   (tools/config_bench.py runs the fp32 and the bf16 case of that configuration)
+# rocprofv3 kernel statistics of one BASELINE configuration's per-rank training step: usage config_profile.sh '#4' [f32|bf16]
+# (9 steps per process; the score network's graph warm-up adds two eager passes of the network to the totals)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=$(echo "$1" | tr -d '#')
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/config_prof_$TAG -- python3 $R/tools/config_bench.py "$1" > $R/gpurun_out/config_prof_$TAG.log 2>&1
-find $R/gpurun_out/config_prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/gpurun_out/config_${TAG}_kernel_stats.csv
-grep "^#" $R/gpurun_out/config_prof_$TAG.log
-python3 - <<PY
-import csv
-rows = list(csv.DictReader(open("$R/gpurun_out/config_${TAG}_kernel_stats.csv")))
-tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
-print(f"kernel time {tot:.0f} ms over both runs (2 x 9 steps); top 40 by time:")
-rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:40]:
-    print(f"{float(r['TotalDurationNs'])/1e6:8.1f} ms {float(r['Percentage']):5.2f}%  {int(r['Calls']):6d} calls  avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:120]}")
-PY
+C=${1:-#4}; D=${2:-f32}; T=$(echo $C | tr -d '#')
+export INDM_CB_DTYPE=$D
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/cfg_prof_${T}_$D -- python3 $R/tools/config_bench.py "$C" > $R/gpurun_out/cfg_prof_${T}_$D.log 2>&1
+find $R/gpurun_out/cfg_prof_${T}_$D -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/gpurun_out/cfg_${T}_${D}_kernel_stats.csv
+grep "ms/step" $R/gpurun_out/cfg_prof_${T}_$D.log
+python3 $R/tools/kernel_classes.py $R/gpurun_out/cfg_${T}_${D}_kernel_stats.csv 9
