@@ -548,6 +548,11 @@ typedef struct {
   /* bf16 = 2 only (a1, d1, a2, d2, t3, t2 are F16 buffers): packed weights */
   const void *W2_bf16w, *W2T_bf16w, *panel_bf16w;
   const void *W1_bf16w, *W3t_bf16w;   /* 12 < C <= 48 only, as in the forward block */
+  /* optional (bf16 = 0 / 1): a second stream for the block's weight / bias gradients, which do not feed its data path, with a
+   * split-K scratch of its own; the driver orders the two streams with events and joins them before it returns.  NULL: one
+   * stream, the launch order of rounds 3 - 5.  Same kernels and results either way. */
+  void* side_stream;
+  float* side_splitk_ws; long side_splitk_ws_floats;
 } indm_iresblock_bwd_args;
 
 /* Fixed-point inverse x <- y - g(x) (iresblock.py:78-88): iterates until every element passes

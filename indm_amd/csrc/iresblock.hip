@@ -194,7 +194,7 @@ INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int
       const long small = 6 * pad64((long)idim * 9 * C) + pad64((long)N * idim) + pad64(idim);
       const long redb = pad64(indm_colreduce_ws_floats(M, idim)) + pad64(indm_ires_bwd_act_ws_floats(M, idim)) +
                         pad64(indm_colreduce_ws_floats(M, C)) + pad64(indm_colreduce_ws_floats(N, idim));
-      return 4 * nW + 2 * nP + 5 * nC + small + redb + 64;
+      return 6 * nW + 2 * nP + 5 * nC + small + redb + 64;   // (two more [M, idim] buffers: the two-stream form keeps du2 / dp2 alive)
     }
     default:  // inverse: a0, a1, a2, p, Pn, g, x ping-pong, check scalar
       return 3 * nW + nP + 4 * nC + 128;
@@ -508,6 +508,27 @@ static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
 }
 }  // namespace
 
+namespace {
+// Round 6, the "two-stream" form of the fp32 backward: the block's weight / bias gradients do not feed its data path, so they
+// are enqueued on a SIDE stream (args.side_stream, with its own split-K scratch) behind events recorded where their operands are
+// complete -- the HBM-bound thin weight gradients then run next to the MFMA-bound fused GEMMs of the data path, and the
+// MFMA-bound [512, 512] weight gradients next to the HBM-bound thin convolutions (fp32 MFMAs and memory streaming use
+// different parts of the CU; inside ONE stream every kernel waits for the previous one).  Same kernels, same arguments, same
+// results; the main stream waits for the side stream before the call returns (the scratch is the caller's).
+struct SideEvents {
+  hipEvent_t ev[5];
+  bool ok = false;
+  SideEvents() {
+    ok = true;
+    for (auto& e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  }
+};
+static SideEvents* side_events() {
+  static SideEvents* s = new SideEvents();   // (never destroyed: the HIP runtime may be gone at static-destructor time)
+  return s->ok ? s : nullptr;
+}
+}  // namespace
+
 INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) {
   if (!a) return INDM_E_ARG;
   if (a->N <= 0) return INDM_OK;
@@ -522,7 +543,7 @@ INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) 
   const int C = c.C, Cw = c.Cw, Mi = (int)c.M, rps = c.H * c.W;
   const long nC = c.M * C, nW = c.M * Cw, nP = c.M * 9 * C;
   Bump ws = {a->ws, a->ws_floats, 0};
-  float *bufA = ws.get(nW), *bufB = ws.get(nW), *bufC = ws.get(nW), *bufD = ws.get(nW);
+  float *bufA = ws.get(nW), *bufB = ws.get(nW), *bufC = ws.get(nW), *bufD = ws.get(nW), *bufE = ws.get(nW), *bufF = ws.get(nW);
   float *col = ws.get(nP), *Pn = ws.get(nP);
   float *dvj = ws.get(nC), *q0 = ws.get(nC), *dd0 = ws.get(nC), *da0 = ws.get(nC), *tmpc = ws.get(nC);
   float *qa = ws.get((long)Cw * 9 * C), *qb = ws.get((long)Cw * 9 * C), *qc = ws.get((long)Cw * 9 * C),
@@ -530,27 +551,61 @@ INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) 
   float *seg1 = ws.get((long)c.N * Cw);
   float *cr_w = ws.get(indm_colreduce_ws_floats(c.M, Cw)), *act_w = ws.get(indm_ires_bwd_act_ws_floats(c.M, Cw)),
         *cr_c = ws.get(indm_colreduce_ws_floats(c.M, C)), *cr_n = ws.get(indm_colreduce_ws_floats(c.N, Cw));
-  if (!bufA || !bufB || !bufC || !bufD || !col || !Pn || !dvj || !q0 || !dd0 || !da0 || !tmpc || !qa || !qb || !qc || !qd ||
-      !seg1 || !cr_w || !act_w || !cr_c || !cr_n)
+  if (!bufA || !bufB || !bufC || !bufD || !bufE || !bufF || !col || !Pn || !dvj || !q0 || !dd0 || !da0 || !tmpc || !qa || !qb ||
+      !qc || !qd || !seg1 || !cr_w || !act_w || !cr_c || !cr_n)
     return INDM_E_ARG;
 
+  // ---- the side stream of the weight / bias gradients (see SideEvents above); without one, `w` IS the main context and the
+  // launches below run in the order of rounds 3 - 5
+  SideEvents* se = (a->side_stream && a->side_splitk_ws && a->side_stream != stream) ? side_events() : nullptr;
+  Ctx w = c;
+  hipStream_t ms = (hipStream_t)stream, ss = ms;
+  if (se) {
+    w.st = a->side_stream;
+    w.sk = a->side_splitk_ws;
+    w.sk_floats = a->side_splitk_ws_floats;
+    ss = (hipStream_t)a->side_stream;
+  }
+  // side waits for what the main stream has done up to here (event i) / main waits for the side stream's last launch
+  auto fork = [&](int i) -> int {
+    if (!se) return 0;
+    if (hipEventRecord(se->ev[i], ms) != hipSuccess || hipStreamWaitEvent(ss, se->ev[i], 0) != hipSuccess) return INDM_E_LAUNCH;
+    return 0;
+  };
+  auto join = [&]() -> int {
+    if (!se) return 0;
+    if (hipEventRecord(se->ev[4], ss) != hipSuccess || hipStreamWaitEvent(ms, se->ev[4], 0) != hipSuccess) return INDM_E_LAUNCH;
+    return 0;
+  };
+  // any error return below leaves the side stream un-joined: join first, then report
+#define TRYJ(call)                                              \
+  do {                                                          \
+    int st_ = (call);                                           \
+    if (st_ != 0) {                                             \
+      (void)join();                                             \
+      return st_ < 0 ? st_ : INDM_E_SHAPE;                      \
+    }                                                           \
+  } while (0)
+
+  TRYJ(fork(0));   // the inputs of this call (gy, the saved tensors) are complete on the main stream
   // ---- g path, level 3:  g = conv(a2, W3) + b3 ----
   float* da2 = bufA;
-  TRY(c.thin(a->gy, a->W3_tapco_ci, da2, 1, nullptr));                                           // da2 = C3^T gy
-  TRY(indm_tap_spread_f32(a->gy, col, c.N, c.H, c.W, C, 1, 1.0f, stream));                      // dW3 (g part) = a2^T spread(gy)
-  TRY(c.gemm(a->a2, nullptr, col, qa, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
-  TRY(indm_colreduce_f32(a->gy, nullptr, a->db3, c.M, C, 0, 1.0f, 0.0f, cr_c, stream));
+  TRYJ(c.thin(a->gy, a->W3_tapco_ci, da2, 1, nullptr));                                          // da2 = C3^T gy
+  TRYJ(indm_tap_spread_f32(a->gy, col, c.N, c.H, c.W, C, 1, 1.0f, w.st));                       // dW3 (g part) = a2^T spread(gy)
+  TRYJ(w.gemm(a->a2, nullptr, col, qa, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
+  TRYJ(indm_colreduce_f32(a->gy, nullptr, a->db3, c.M, C, 0, 1.0f, 0.0f, cr_c, w.st));
   // ---- reverse sweep of the last VJP chain: logdet = <d0 .* C1^T(d1 .* t2), eps>, t2 = (t3 .* d2) W2^T, t3 = C3^T w ----
-  TRY(indm_scale_rows_f32(a->eps, a->gld, dvj, c.N, (long)rps * C, stream));
+  TRYJ(indm_scale_rows_f32(a->eps, a->gld, dvj, c.N, (long)rps * C, stream));
   const float* q0p = dvj;
   if (a->preact) {
-    TRY(indm_mul2_f32(dvj, a->d0, a->c1, q0, dd0, nC, stream));
+    TRYJ(indm_mul2_f32(dvj, a->d0, a->c1, q0, dd0, nC, stream));
     q0p = q0;
   }
+  TRYJ(fork(1));   // q0
   float* q1 = bufB;
-  TRY(c.thin(q0p, a->W1, q1, -1, nullptr));                                                      // q1 = conv(q0, W1) = dL/d(t2 .* d1)
-  TRY(indm_tap_spread_f32(q0p, col, c.N, c.H, c.W, C, -1, 1.0f, stream));                        // dW1 (chain part)^T = (t2 .* d1)^T spread(q0)
-  TRY(c.gemm(a->t2, a->d1, col, qb, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
+  TRYJ(c.thin(q0p, a->W1, q1, -1, nullptr));                                                     // q1 = conv(q0, W1) = dL/d(t2 .* d1)
+  TRYJ(indm_tap_spread_f32(q0p, col, c.N, c.H, c.W, C, -1, 1.0f, w.st));                        // dW1 (chain part)^T = (t2 .* d1)^T spread(q0)
+  TRYJ(w.gemm(a->t2, a->d1, col, qb, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
   // du2 = (q1 .* d1) W2 = dL/d(t3 .* d2), and -- where the gated direct-to-LDS kernel takes the GEMM (fp32) -- the Sin level that
   // du2 feeds as the same launch's epilogue: dp2 = da2 d2 - 4 pi^2 a2 (du2 t3) and its per-image sums dcb
   float *du2 = bufC, *dp2 = bufD;
@@ -558,44 +613,49 @@ INDM_API int indm_iresblock_bwd(const indm_iresblock_bwd_args* a, void* stream) 
   if (!c.bf16 && (gpass_fused() & 8))
     fusedc = indm_gemm_gated_ires_bwd_act_f32(q1, a->d1, a->W2, da2, a->d2, a->a2, a->t3, du2, dp2, a->dcb, Mi, Cw, Cw, Cw, Cw, rps,
                                               act_w, stream);
-  if (fusedc < 0) return fusedc;
-  if (fusedc == 1) TRY(c.gemm(q1, a->d1, a->W2, du2, Mi, Cw, Cw, 0, 0, Cw, Cw, nullptr, nullptr, 1));
-  TRY(indm_tap_spread_f32(a->w, col, c.N, c.H, c.W, C, 1, 1.0f, stream));                        // dW3 (chain part) = (du2 .* d2)^T spread(w)
-  TRY(c.gemm(du2, a->d2, col, qc, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
-  TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream));                                // [Cw, tap, c] -> [tap, Cw, c], both parts summed
-  if (fusedc == 1) TRY(indm_ires_bwd_act_f32(da2, du2, a->d2, a->a2, a->t3, dp2, nullptr, a->dcb, c.M, Cw, rps, act_w, stream));
-  TRY(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  if (fusedc < 0) { (void)join(); return fusedc; }
+  if (fusedc == 1) {
+    TRYJ(c.gemm(q1, a->d1, a->W2, du2, Mi, Cw, Cw, 0, 0, Cw, Cw, nullptr, nullptr, 1));
+    TRYJ(indm_ires_bwd_act_f32(da2, du2, a->d2, a->a2, a->t3, dp2, nullptr, a->dcb, c.M, Cw, rps, act_w, stream));
+  }
+  TRYJ(fork(2));   // du2, dp2, dcb
+  TRYJ(indm_tap_spread_f32(a->w, col, c.N, c.H, c.W, C, 1, 1.0f, w.st));                        // dW3 (chain part) = (du2 .* d2)^T spread(w)
+  TRYJ(w.gemm(du2, a->d2, col, qc, Cw, 9 * C, Mi, 1, 0, Cw, 9 * C, nullptr, nullptr, 1));
+  TRYJ(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, w.st));                                // [Cw, tap, c] -> [tap, Cw, c], both parts summed
+  TRYJ(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, w.st));
+  TRYJ(w.gemm(a->a1, nullptr, dp2, a->dW2, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));     // dW2 = a1^T dp2
   // ---- level 2:  p2 = a1 W2 + b2 + cb[image] ----
   // da1 = dp2 W2^T and the Sin level it feeds -- dp1 = da1 d1 - 4 pi^2 a1 (q1 t2), dt2 = q1 d1, per-image sums of dp1 -- as ONE
   // launch where the direct-to-LDS kernel takes the GEMM (fp32): da1 is never written, and the pass's 1.6 GB of HBM traffic
-  // runs under the other workgroup's MFMAs.  dt2 then lives in da1's slot (dp2 = bufD is still being read by other tiles).
-  float *dp1 = bufC, *dt2 = bufA;                                                                  // du2, da2 are dead
+  // runs under the other workgroup's MFMAs.  (dp1, dt2 in buffers of their own: du2 and dp2 are still being read by the
+  // weight gradients above when those run on the side stream.)
+  float *dp1 = bufE, *dt2 = bufF;
   int fusedb = 1;
   if (!c.bf16 && (gpass_fused() & 4))
     fusedb = indm_gemm_ires_bwd_act_f32(dp2, a->W2, q1, a->d1, a->a1, a->t2, dp1, dt2, seg1, Mi, Cw, Cw, Cw, Cw, rps, act_w, stream);
-  if (fusedb < 0) return fusedb;
-  float* da1 = bufA;
-  if (fusedb == 1) TRY(c.gemm(dp2, nullptr, a->W2, da1, Mi, Cw, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));         // da1 = dp2 W2^T
-  TRY(c.gemm(a->a1, nullptr, dp2, a->dW2, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));       // dW2 = a1^T dp2
+  if (fusedb < 0) { (void)join(); return fusedb; }
   if (fusedb == 1) {
-    dt2 = bufD;                                                                                    // dp2 is dead
-    TRY(indm_ires_bwd_act_f32(da1, q1, a->d1, a->a1, a->t2, dp1, dt2, seg1, c.M, Cw, rps, act_w, stream));
+    float* da1 = bufA;                                                                             // da2 is dead
+    TRYJ(c.gemm(dp2, nullptr, a->W2, da1, Mi, Cw, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));      // da1 = dp2 W2^T
+    TRYJ(indm_ires_bwd_act_f32(da1, q1, a->d1, a->a1, a->t2, dp1, dt2, seg1, c.M, Cw, rps, act_w, stream));
   }
-  TRY(c.gemm(a->t3, a->d2, dt2, a->dW2T, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));        // dW2T = (t3 .* d2)^T (q1 .* d1)
-  TRY(indm_colreduce_f32(seg1, nullptr, a->db1, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  TRYJ(fork(3));   // dp1, dt2, seg1
+  TRYJ(w.gemm(a->t3, a->d2, dt2, a->dW2T, Cw, Cw, Mi, 1, 0, Cw, Cw, nullptr, nullptr, 1));      // dW2T = (t3 .* d2)^T (q1 .* d1)
+  TRYJ(indm_colreduce_f32(seg1, nullptr, a->db1, c.N, Cw, 0, 1.0f, 0.0f, cr_n, w.st));
   // ---- level 1:  p1 = conv(a0, W1) + b1 ----
-  TRY(c.gemm(dp1, nullptr, a->W1, Pn, Mi, 9 * C, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));         // da0 = C1^T dp1: GEMM + gather
-  TRY(indm_tap_gather_f32(Pn, nullptr, da0, c.N, c.H, c.W, C, -1, 1.0f, stream));
-  TRY(indm_tap_spread_f32(a->a0, col, c.N, c.H, c.W, C, -1, 1.0f, stream));                      // dW1 (g part) = spread(a0)^T dp1
-  TRY(c.gemm(col, nullptr, dp1, qd, 9 * C, Cw, Mi, 1, 0, 9 * C, Cw, nullptr, nullptr, 1));
-  TRY(permute021_add(qb, nullptr, qd, a->dW1, Cw, 9 * C, 1, stream));                             // qb^T + qd
+  TRYJ(c.gemm(dp1, nullptr, a->W1, Pn, Mi, 9 * C, Cw, 0, 1, Cw, Cw, nullptr, nullptr, 1));       // da0 = C1^T dp1: GEMM + gather
+  TRYJ(indm_tap_gather_f32(Pn, nullptr, da0, c.N, c.H, c.W, C, -1, 1.0f, stream));
+  TRYJ(indm_tap_spread_f32(a->a0, col, c.N, c.H, c.W, C, -1, 1.0f, w.st));                      // dW1 (g part) = spread(a0)^T dp1
+  TRYJ(w.gemm(col, nullptr, dp1, qd, 9 * C, Cw, Mi, 1, 0, 9 * C, Cw, nullptr, nullptr, 1));
+  TRYJ(permute021_add(qb, nullptr, qd, a->dW1, Cw, 9 * C, 1, w.st));                             // qb^T + qd
   if (a->preact) {
-    TRY(indm_sincos_act_bwd_f32(da0, dd0, a->a0, a->d0, tmpc, nC, stream));
-    TRY(indm_axpby_f32(a->gy, tmpc, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+    TRYJ(indm_sincos_act_bwd_f32(da0, dd0, a->a0, a->d0, tmpc, nC, stream));
+    TRYJ(indm_axpby_f32(a->gy, tmpc, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
   } else {
-    TRY(indm_axpby_f32(a->gy, da0, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+    TRYJ(indm_axpby_f32(a->gy, da0, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
   }
-  return INDM_OK;
+#undef TRYJ
+  return join() == 0 ? INDM_OK : INDM_E_LAUNCH;
 }
 
 INDM_API int indm_iresblock_inverse(const indm_iresblock_fwd_args* a, float atol, float rtol, int* iterations,

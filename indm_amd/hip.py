@@ -1830,7 +1830,8 @@ class _IResBwdArgs(ctypes.Structure):
                 + [(n, c_p) for n in ("gy", "gld", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w", "eps", "W1", "W2",
                                       "W2T", "W3_tapco_ci", "dx", "dcb", "dW1", "dW2", "dW3", "dW2T", "db1", "db2", "db3")]
                 + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l)]
-                + [(n, c_p) for n in ("W2_bf16w", "W2T_bf16w", "panel_bf16w", "W1_bf16w", "W3t_bf16w")])
+                + [(n, c_p) for n in ("W2_bf16w", "W2T_bf16w", "panel_bf16w", "W1_bf16w", "W3t_bf16w")]
+                + [("side_stream", c_p), ("side_splitk_ws", c_p), ("side_splitk_ws_floats", c_l)])
 
 
 BLOCK_DRIVERS = {"on": os.environ.get("INDM_BLOCK_DRIVERS", "1") != "0"}   # tools / tests switch to the op-level composition
@@ -2007,6 +2008,26 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     return y, logdet, saved
 
 
+# the fp32 / bf16-compute backward driver enqueues the block's weight gradients on a second stream (include/indm_hip.h,
+# indm_iresblock_bwd_args.side_stream); INDM_BWD_STREAMS=0: one stream
+BWD_STREAMS = {"on": os.environ.get("INDM_BWD_STREAMS", "1") != "0"}
+_side = {}
+
+
+def bwd_streams(on=None):
+    if on is not None:
+        BWD_STREAMS["on"] = bool(on)
+    return BWD_STREAMS["on"]
+
+
+def _side_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    hit = _side.get(key)
+    if hit is None:
+        hit = _side[key] = (torch.cuda.Stream(device=dev), torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device=dev))
+    return hit
+
+
 def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact, panel=None):
     """Backward of the training-mode block through indm_iresblock_bwd -> (dx, dcb, dW1, dW2, dW3, dW2T, db1, db2, db3)
     or None if not covered."""
@@ -2041,6 +2062,9 @@ def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact, panel=None):
     a.ws, a.ws_floats = ws.data_ptr(), n
     sk = _ws(SPLITK_WS_FLOATS, dev)
     a.splitk_ws, a.splitk_ws_floats = sk.data_ptr(), SPLITK_WS_FLOATS
+    if BWD_STREAMS["on"] and not f16 and not torch.cuda.is_current_stream_capturing():
+        side = _side_stream(dev)
+        a.side_stream, a.side_splitk_ws, a.side_splitk_ws_floats = side[0].cuda_stream, side[1].data_ptr(), SPLITK_WS_FLOATS
     st = lib().indm_iresblock_bwd(ctypes.byref(a), _stream())
     if st == 1:
         return None
