@@ -2008,9 +2008,11 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
     return y, logdet, saved
 
 
-# the fp32 / bf16-compute backward driver enqueues the block's weight gradients on a second stream (include/indm_hip.h,
-# indm_iresblock_bwd_args.side_stream); INDM_BWD_STREAMS=0: one stream
-BWD_STREAMS = {"on": os.environ.get("INDM_BWD_STREAMS", "1") != "0"}
+# INDM_BWD_STREAMS=1: the fp32 / bf16-compute backward driver enqueues the block's weight gradients on a second stream
+# (include/indm_hip.h, indm_iresblock_bwd_args.side_stream).  OFF by default: measured (round 6, profiles/r06_two_stream_ab.txt)
+# 35 ms of the step's kernels do run concurrently and the step is 0.3 % SLOWER -- 85 % of the data path are MFMA-bound GEMMs, so
+# the side stream's GEMMs mostly share the MFMA pipe with them, and its HBM-bound launches take LDS / CU slots from them.
+BWD_STREAMS = {"on": os.environ.get("INDM_BWD_STREAMS", "0") == "1"}
 _side = {}
 
 

@@ -102,6 +102,25 @@ def test_eval_logdet_and_inverse_drivers_match_op_level(drivers):
     assert (x1 - x0).abs().max().item() <= 1e-5
 
 
+def test_two_stream_backward_is_bit_identical(drivers):
+    """indm_iresblock_bwd_args.side_stream (weight / bias gradients on a second stream, ordered by events): same kernels and
+    arguments -> the same bits as the one-stream order, repeatedly (a missing event would show up as a run-to-run difference)."""
+    cfg, fl = _flow()
+    x = torch.rand(16, 3, 32, 32, device=DEV) * 2 - 1
+    was = hip.bwd_streams()
+    try:
+        hip.bwd_streams(False)
+        z0, ld0, g0 = _train_pass(cfg, fl, x, True)
+        hip.bwd_streams(True)
+        for _ in range(3):
+            z1, ld1, g1 = _train_pass(cfg, fl, x, True)
+            assert torch.equal(z1, z0) and torch.equal(ld1, ld0) and set(g1) == set(g0)
+            for n in g0:
+                assert torch.equal(g1[n], g0[n]), (n, (g1[n] - g0[n]).abs().max().item())
+    finally:
+        hip.bwd_streams(was)
+
+
 def _rel(a, b):
     return (a - b).norm().item() / (b.norm().item() + 1e-30)
 
