@@ -86,6 +86,30 @@ __global__ __launch_bounds__(256) void mfma_bf16_loop(float* out, int iters, flo
   if (s == 123.456f) out[0] = s;
 }
 
+// round 6: the SHAPE of f16_rows_kernel's launch without any of its memory traffic -- 2048 workgroups of 512 threads with 64 KB of
+// dynamic LDS each (two per CU), 128 MFMAs on four accumulators per wave: what workgroup granularity alone costs
+__global__ __launch_bounds__(512, 4) void mfma_bf16_tile(float* out, int mfmas, float a0) {
+  extern __shared__ char smem[];
+  f16v acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  bf8v a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(a0 + j + threadIdx.x * 1e-3f); b[j] = (__bf16)(0.5f + j); }
+  for (int it = 0; it < mfmas / 4; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += acc[i][j];
+  if (s == 123.456f) { out[0] = s; smem[threadIdx.x] = 1; }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <typename F>
@@ -125,6 +149,14 @@ int main(int argc, char** argv) {
       run(nm, [&] { mfma_f32_loop_rnd<4><<<blocks, 256>>>(out, iters, 12345u); }, mf * 2.0 * 32 * 32 * 2, reps);
       snprintf(nm, sizeof nm, "bf16 32x32x16 %d wave/SIMD %6d iters", wpc, iters);
       run(nm, [&] { mfma_bf16_loop<4><<<blocks, 256>>>(out, iters, 1.0f); }, mf * 2.0 * 32 * 32 * 16, reps);
+    }
+  }
+  CK(hipFuncSetAttribute((const void*)mfma_bf16_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+  for (int wgs : {2048, 512}) {
+    for (int mf : {128, 512, 2048}) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "bf16 tile-shaped: %4d WGs x 512 thr, %4d MFMA/wave", wgs, mf);
+      run(nm, [&] { mfma_bf16_tile<<<wgs, 512, 65536>>>(out, mf, 1.0f); }, (double)wgs * 8 * mf * 2.0 * 32 * 32 * 16, reps);
     }
   }
   CK(hipFree(out));
