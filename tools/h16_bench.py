@@ -1,10 +1,11 @@
 """Time the H16 (bf16 storage) convolution kernels against the bf16-compute / fp32-storage kernels of rounds 2-5 at the score
 network's shapes.  usage: python tools/h16_bench.py [batch]   (env INDM_H16_* tune the tile / split rules)"""
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from indm_amd import hip  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128

@@ -1,8 +1,9 @@
 """GroupNorm (+SiLU) forward / backward on bf16 activations vs the fp32 kernels at the score network's shapes (batch 128):
 us per launch and effective TB/s (forward: read + write; backward: 2 reads + 1 write).  INDM_H16_GNB_CH / _BS tune the backward."""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from indm_amd import hip  # noqa: E402
 
 DROP = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1

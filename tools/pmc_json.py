@@ -8,17 +8,32 @@ import json
 import sys
 
 base = sys.argv[1]
+
+
+def kname(n):   # "void (anonymous namespace)::k<...>(args)" -> "k<...>"
+    n = n.replace("(anonymous namespace)::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    depth = 0
+    for i, ch in enumerate(n):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return n[:i]
+    return n
+
+
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for i in (1, 2, 3):
     for f in glob.glob(f"{base}_{i}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            key = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size"]))
+            key = (kname(r["Kernel_Name"]), int(r["Grid_Size"]))
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for f in glob.glob(f"{base}_{i}/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-            dur[(r["Kernel_Name"].split("(")[0], g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            dur[(kname(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 largest = {}
 for (name, grid) in acc:
     if name not in largest or grid > largest[name]:
@@ -31,7 +46,7 @@ for name, grid in sorted(largest.items()):
         continue
     c = {k: sum(v) / len(v) for k, v in acc[(name, grid)].items()}
     d = dur.get((name, grid), [])
-    e = {"kernel": name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""), "grid_size": grid,
+    e = {"kernel": name, "grid_size": grid,
          "launches": len(next(iter(acc[(name, grid)].values()))), "us": round(sum(d) / len(d) / 1e3, 1) if d else None, "per_launch": c}
     der = {}
     g = lambda k: c.get(k, 0.0)  # noqa: E731

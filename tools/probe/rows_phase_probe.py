@@ -1,7 +1,8 @@
 """Which phase bounds f16_rows_kernel's GEMM mode at M = 131072: debug bits passed through the (unused) J argument of a PROBE build
 (bit 0: no stores, bit 1: weight fragments fetched once, bit 2: no A copies, bit 3: no LDS reads).  Not part of the library's contract."""
+import os
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from indm_amd import hip
 M = 131072
 dev = "cuda"
