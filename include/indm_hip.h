@@ -269,6 +269,16 @@ int indm_f16_tap_spread(const float* x, void* out, int Nimg, int H, int W, int C
 int indm_f16_rows(int mode, const void* A, const void* Wp, const void* D1, const void* Pp, float* P, void* out1, void* out2,
                   const float* bias, const float* bias2, int M, int J, int rows_per_group, void* stream);
 
+/* One series iteration of the log-det estimators (iresblock.py:257, 269-271: v -> v^T dg/dx up to the skinny tail) as ONE launch:
+ *   P[M, J] = (((C3^T x) .* gate) W2Tp .* D1) Pp[:, :J],  M = Nimg H W, J = 9 C
+ * = indm_f16_thin_conv(x, ., gate, epilogue 2) followed by indm_f16_rows mode 2 without the F16 [M, 512] tensor between them: the
+ * workgroup builds its A tile from x and the d2 gate itself (bit-identical to the two launches).  x: fp32 NHWC [Nimg,H,W,C] with
+ * C <= 3 or C in {4, 8, 12}; Wc: the transposed convolution's weight w[(tap, co), ci] (rows zero-padded to 16 S, S = ceil(9 C / 16))
+ * packed as Wc[s][nb][lane][e] = bf16(w[16 s + 8 (lane >> 5) + e][32 nb + (lane & 31)]); gate, D1: F16 [M, 512]; W2Tp, Pp: as for
+ * indm_f16_rows.  Returns 1 if not covered. */
+int indm_f16_chain_conv(const float* x, const void* Wc, const void* gate, const void* W2Tp, const void* D1, const void* Pp, float* P,
+                        int Nimg, int H, int W, int C, int sign, int J, void* stream);
+
 /* One Sin level of the hand-written iResBlock backward on F16 tensors (the F16 form of indm_ires_bwd_act_f32; replaces
  * autograd over iresblock.py:253-273's double backward): dp = da .* d - 4 pi^2 a .* (du .* t); seg (optional, fp32
  * [R / rows_per_seg][512]) = per-image column sums of dp.  rows_per_seg % 128 == 0 (indm_f16_bwd_act_ok), else returns 1. */
@@ -530,6 +540,8 @@ typedef struct {
   /* bf16 = 2 and 12 < C <= 48 only (9 C > 128 taps: the convolutions run as 64-row GEMMs on the F16 im2col operand) */
   const void* W1_bf16w;    /* W1 as [(tap,c), idim], rows zero-padded to 512, packed */
   const void* W3t_bf16w;   /* W3_tapco_ci, rows zero-padded to 512, packed */
+  /* bf16 = 2 and C <= 12, optional: W3_tapco_ci in indm_f16_chain_conv's Wc form -- the series iterations then run as one launch each */
+  const void* W3t_thin_bf16w;
 } indm_iresblock_fwd_args;
 
 /* Backward of the training-mode block (replaces autograd's double backward through iresblock.py:264-273 and g's own

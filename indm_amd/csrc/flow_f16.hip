@@ -524,6 +524,134 @@ int launch_thin_conv_e(const ThinConvArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// f16_chain_conv_kernel (round 6): one series iteration of the log-det estimators as ONE launch --
+//   P[M, J] = ((( C3^T v ) .* d2) W2T .* d1) panel        (iresblock.py:257, 269-271: the vector-Jacobian product of g)
+// i.e. f16_thin_conv_kernel's gate epilogue + f16_rows_kernel's chain mode without the [M, 512] tensor u2 = (C3^T v) .* d2 between
+// them (134 MB written and read back per iteration at batch 128; 54 + 57 thin-convolution launches per training step).  The
+// workgroup builds its 64-row A tile itself: (0) the tile's im2col image [64 px][16 S k] is gathered ONCE into LDS as bf16 in
+// fragment order (512 threads, 8 k-values each -- the thin kernel gathers per wave); (1) every wave multiplies it by its two
+// 32-column blocks of the packed transposed-convolution weight (2 S MFMAs per 32 x 32 block, the thin kernel's k order and
+// summation order: the tile is bit-identical to the u2 that kernel stores); (2) the accumulators are gated by d2 (chunks requested
+// at kernel start), rounded to bf16 and written into the A tile at their chunk positions -- the accumulator layout IS the
+// operand-fragment layout; then rows_tile<R_CHAIN> runs unchanged.  Same HBM bytes per tile as the chain kernel alone (the d2
+// chunks instead of the u2 chunks).
+struct ChainConvArgs {
+  RowsArgs r;
+  const float* X;    // [Nimg, H, W, C] fp32
+  const u16* Wc;     // packed [S][16][64][8]: Wc[s][nb][lane][e] = bf16(w[16 s + 8 (lane >> 5) + e][32 nb + (lane & 31)]), rows >= 9 C zero
+  const u16* G;      // F16 [M, 512]: d2
+  int H, W, C, sign, S;
+};
+
+template <int JB, int TMV, int SMAX, bool VEC4>
+__global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvArgs a) {
+  constexpr int MB = TMV / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* im = smem + TMV * R_N * 2;                    // [MB][SMAX] chunks of 1 KB: the im2col fragments
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const long tile = blockIdx.x;
+  const int C = a.C, K = 9 * C, HW = a.H * a.W;
+  auto chunk = [&](int i, int j, int s) -> long {
+    return ((((tile * MB + j) * 16 + 2 * wave + i) * 2 + s) * 64 + lane) * 8;   // bf16 index
+  };
+  // ---- (0) the im2col image of the tile's TMV pixels: one 16-byte group (pixel, 8 consecutive k) per thread and round
+  for (int u = tid; u < MB * SMAX * 64; u += R_NW * 64) {
+    const int ln = u & 63, sj = u >> 6;
+    const int sidx = sj % SMAX, j = sj / SMAX;
+    const long pix = tile * TMV + j * 32 + (ln & 31);
+    const int r = (int)(pix % HW);
+    const int h = r / a.W, w = r - h * a.W;
+    const float* base = a.X + pix * C;
+    float gv[8];
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = 16 * sidx + 8 * (ln >> 5) + 4 * q;
+        const int tap = k / C, c = k - tap * C;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int hh = h - a.sign * (kh - 1), ww = w - a.sign * (kw - 1);
+        const bool ok = k < K && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
+        const float4 v = *(const float4*)(base + (ok ? ((hh - h) * a.W + (ww - w)) * C + c : 0));
+        gv[4 * q] = ok ? v.x : 0.f; gv[4 * q + 1] = ok ? v.y : 0.f; gv[4 * q + 2] = ok ? v.z : 0.f; gv[4 * q + 3] = ok ? v.w : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * sidx + 8 * (ln >> 5) + e;
+        const int tap = k / C, c = k - tap * C;
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int hh = h - a.sign * (kh - 1), ww = w - a.sign * (kw - 1);
+        const bool ok = k < K && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
+        const float t = base[ok ? ((hh - h) * a.W + (ww - w)) * C + c : 0];
+        gv[e] = ok ? t : 0.f;
+      }
+    }
+    *(u32x4*)(im + (long)u * 16) = pack8(gv);
+  }
+  // the d2 chunks of this wave's accumulators (HBM): requested behind the gathers, they fly under the convolution's MFMAs
+  u32x4 gq[2][MB][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) gq[i][j][s] = *(const u32x4*)(a.G + chunk(i, j, s));
+  __syncthreads();
+  // ---- (1) the tile of C3^T v: acc[i][j] = D[co = 32 (2 wave + i) + ..][pixel = 32 j + l31]
+  f32x16 acc[2][MB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  {
+    const u32x4* wc = (const u32x4*)a.Wc + (long)(2 * wave) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      if (s < a.S) {
+        bf16x8 hx[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) hx[j] = *(const bf16x8*)(im + ((j * SMAX + s) * 64 + lane) * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 hw = __builtin_bit_cast(bf16x8, wc[(long)s * 1024 + i * 64]);
+#pragma unroll
+          for (int j = 0; j < MB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw, hx[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- (2) gate, round, store as operand fragments: chunk (m-block j, k-step 2 (2 wave + i) + s) of the A tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8], g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * s + e];
+        unpack8(gq[i][j][s], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g[e];
+        *(u32x4*)(smem + (j * 32 + 2 * (2 * wave + i) + s) * 1024 + lane * 16) = pack8(v);
+      }
+  __syncthreads();
+  rows_tile<R_CHAIN, JB, false, TMV, 4>(a.r, smem, tile, tid, lane, wave, l31, lhi);
+}
+
+template <int JB, int TMV, int SMAX, bool VEC4>
+int launch_chain_conv(const ChainConvArgs& a, hipStream_t st) {
+  constexpr int bytes = TMV * R_N * 2 + (TMV / 32) * SMAX * 1024;
+  if (indm_lds_optin<f16_chain_conv_kernel<JB, TMV, SMAX, VEC4>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+  hipLaunchKernelGGL((f16_chain_conv_kernel<JB, TMV, SMAX, VEC4>), dim3(a.r.M / TMV), dim3(R_NW * 64), bytes, st, a);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // f16_bwd_act_kernel: one Sin level of the iResBlock's hand-written backward on F16 tensors (the F16 form of
 // indm_ires_bwd_act_f32):  dp = da .* d - 4 pi^2 a .* (du .* t), seg[img][n] = sum over the rows of image img of dp.
 // All five inputs and dp share the F16 layout, so the kernel walks 16-byte groups; a workgroup owns (image, column block,
@@ -1099,6 +1227,22 @@ INDM_API int indm_f16_rows(int mode, const void* A, const void* Bp, const void* 
     default:
       return INDM_E_ARG;
   }
+}
+
+INDM_API int indm_f16_chain_conv(const float* x, const void* Wc, const void* gate, const void* W2Tp, const void* D1,
+                                 const void* Pp, float* P, int Nimg, int H, int W, int C, int sign, int J, void* stream) {
+  if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0) return INDM_E_SHAPE;
+  if (Nimg == 0) return INDM_OK;
+  const long M = (long)Nimg * H * W;
+  if (!(C <= 3 || (C <= 12 && !(C & 3))) || (M % R_TM) || M * C >= (1L << 31) || M >= (1L << 31) || J != 9 * C) return 1;
+  if (!x || !Wc || !gate || !W2Tp || !D1 || !Pp || !P) return INDM_E_ARG;
+  if (!al16(x) || !al16(Wc) || !al16(gate) || !al16(W2Tp) || !al16(D1) || !al16(Pp)) return INDM_E_ARG;
+  ChainConvArgs a = {{nullptr, (const u16*)W2Tp, (const u16*)D1, (const u16*)Pp, P, nullptr, nullptr, nullptr, nullptr, (int)M, J, 1},
+                     x, (const u16*)Wc, (const u16*)gate, H, W, C, sign, (9 * C + 15) >> 4};
+  hipStream_t st = (hipStream_t)stream;
+  const bool small = M / R_TM < 512;   // the tile rule of launch_rows
+  if (C <= 3) return small ? launch_chain_conv<1, 32, 2, false>(a, st) : launch_chain_conv<1, 64, 2, false>(a, st);
+  return small ? launch_chain_conv<4, 32, 7, true>(a, st) : launch_chain_conv<4, 64, 7, true>(a, st);
 }
 
 INDM_API long indm_f16_bwd_act_ok(long R, long rows_per_seg) {

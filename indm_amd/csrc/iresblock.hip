@@ -245,6 +245,36 @@ struct Ctx16 {
     if (tr) return indm_f16_wgrad_gemm(wide16, gate, colF, out, M, 1.0f, 0, sk, skn, st);   // [Cw][512]: columns (tap, c), zeros behind
     return gate ? INDM_E_ARG : indm_f16_wgrad_gemm(colF, nullptr, wide16, out, M, 1.0f, 0, sk, skn, st);   // [512][Cw]: the first 9 C rows
   }
+  // one series iteration: u2 = (C3^T v) .* d2, P = ((u2 W2T) .* d1) panel -- ONE launch (indm_f16_chain_conv) when the thin-order
+  // pack of W3^T is given (C <= 12), else the thin convolution + the chain link
+  int series(const float* vin, const float* w3t, const void* w3t_wide, const void* w3t_thin, const void* d2, void* u2,
+             const void* W2Tp, const void* d1, const void* panelp, float* P) const {
+    static const int fused = getenv("INDM_F16_CHAIN_CONV") ? atoi(getenv("INDM_F16_CHAIN_CONV")) : 1;
+    if (fused && w3t_thin && !wide()) {
+      const int J = 9 * C;
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (timer) {
+        const int cls = (J <= 32 ? 0 : 2);
+        if (((timer->mask >> cls) & 1) && timer->used + 2 <= (int)timer->ev.size()) {
+          e0 = timer->ev[timer->used];
+          e1 = timer->ev[timer->used + 1];
+        }
+      }
+      if (e0) (void)hipEventRecord(e0, (hipStream_t)st);
+      const int r = indm_f16_chain_conv(vin, w3t_thin, d2, W2Tp, d1, panelp, P, N, H, W, C, 1, J, st);
+      if (r != 1) {
+        if (e0) {
+          (void)hipEventRecord(e1, (hipStream_t)st);
+          timer->used += 2;
+          timer->flops += 2.0 * (double)M * Cw * (Cw + 2 * J);
+        }
+        return r;
+      }
+    }
+    int r = thin(vin, w3t, w3t_wide, nullptr, d2, u2, nullptr, 1, F16_GATE);
+    if (r != 0) return r;
+    return chain(u2, W2Tp, d1, panelp, P, nullptr);
+  }
   int chain(const void* u2, const void* W2Tp, const void* d1, const void* panelp, float* P, void* t2) const {
     const int J = 9 * C;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -323,8 +353,7 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
     const float *vin = a->eps, *win = a->eps;
     for (int k = 0; k < K; ++k) {
       float* wout = ((K - 1 - k) & 1) ? wtmp : a->w;
-      TRY(c.thin(vin, a->W3_tapco_ci, a->W3t_bf16w, nullptr, d2, u2, nullptr, 1, F16_GATE));   // u2 = (C3^T v) .* d2
-      TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, nullptr));
+      TRY(c.series(vin, a->W3_tapco_ci, a->W3t_bf16w, a->W3t_thin_bf16w, d2, u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn));   // u2 = (C3^T v) .* d2; the chain link
       TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, win, wout, a->coeffs[k], c.N, c.H, c.W, c.C, -1, 1.0f, stream));
       vin = v;
       win = wout;
@@ -346,8 +375,7 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
   if (!tr) return INDM_E_ARG;
   const float* vin = a->eps;
   for (int k = 0; k < K; ++k) {
-    TRY(c.thin(vin, a->W3_tapco_ci, a->W3t_bf16w, nullptr, d2, u2, nullptr, 1, F16_GATE));
-    TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, nullptr));
+    TRY(c.series(vin, a->W3_tapco_ci, a->W3t_bf16w, a->W3t_thin_bf16w, d2, u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn));
     TRY(indm_tap_gather_acc_f32(Pn, nullptr, gate0, v, nullptr, nullptr, 0.0f, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
     vin = v;
     TRY(indm_rowreduce_f32(v, a->eps, k == 0 ? a->logdet : tr, c.N, (long)c.H * c.W * c.C, 0, a->coeffs[k], rws, stream));

@@ -132,6 +132,7 @@ _SIGS = {
     "indm_f16_unpack_f32": [c_p, c_p, c_l, c_i, c_p],
     "indm_f16_thin_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_tap_spread": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "indm_f16_chain_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "indm_f16_bwd_act_ok": [c_l, c_l],
     "indm_f16_bwd_act": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
@@ -1500,6 +1501,26 @@ def f16_rows(mode, A, M, Wp=None, D1=None, Pp=None, J=0, bias=None, bias2=None, 
     return P
 
 
+def pack_thin_conv_bf16(w2d):
+    """[9C, 512] fp32 -> indm_f16_chain_conv's Wc (rows zero-padded to 16 S; k = 16 s + 8 (lane >> 5) + e)"""
+    K, N = w2d.shape
+    S = (K + 15) // 16
+    m = torch.nn.functional.pad(w2d, (0, 0, 0, 16 * S - K)).to(torch.bfloat16)
+    return m.view(S, 2, 8, N // 32, 32).permute(0, 3, 1, 4, 2).contiguous()
+
+
+def f16_chain_conv(x, Wc, gate, W2Tp, D1, Pp, sign=1):
+    """indm_f16_chain_conv -> P fp32 [N H W, 9 C] (None if not covered)"""
+    N, H, W, C = x.shape
+    P = torch.empty((N * H * W, 9 * C), dtype=torch.float32, device=x.device)
+    st = lib().indm_f16_chain_conv(_ptr(x), _ptr16(Wc), _ptr16(gate), _ptr16(W2Tp), _ptr16(D1), _ptr16(Pp), _ptr(P), N, H, W, C, sign,
+                                   9 * C, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_chain_conv")
+    return P
+
+
 def f16_tap_spread(x, sign):
     """indm_f16_tap_spread: NHWC fp32 x [N,H,W,C] -> F16 [N H W, 512] im2col operand (None if not covered)"""
     N, H, W, C = x.shape
@@ -1821,7 +1842,7 @@ class _IResFwdArgs(ctypes.Structure):
                 + [("ncoeff", c_i)]
                 + [(n, c_p) for n in ("y", "logdet", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w")]
                 + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("timer", c_p)]
-                + [(n, c_p) for n in ("W2_bf16w", "panel_bf16w", "W3_bf16w", "W1_bf16w", "W3t_bf16w")])
+                + [(n, c_p) for n in ("W2_bf16w", "panel_bf16w", "W3_bf16w", "W1_bf16w", "W3t_bf16w", "W3t_thin_bf16w")])
 
 
 class _IResBwdArgs(ctypes.Structure):
@@ -1911,19 +1932,29 @@ def f16_wide(C):
     return 12 < C <= 48 and C % 4 == 0
 
 
+# the series iterations of the F16 forward driver as one launch each (indm_f16_chain_conv); INDM_F16_CHAIN_CONV=0: thin conv + chain
+CHAIN_CONV = {"on": os.environ.get("INDM_F16_CHAIN_CONV", "1") != "0"}
 _kpad_packed = {}  # (id(w), kind) -> (weakref, version, packed bf16 copy of w as [9C -> 512, idim])
 
 
 def pack_kpad_bf16(ws, kind):
     """F16 wide scales: the skinny 3x3 weights of a whole scale as K-padded packed GEMM operands, registered per weight object.
-    kind 'w1': w [3,3,C,idim] -> [(tap,c), idim]; 'w3t': w [3,3,idim,C] -> [(tap,co), ci].  Rows zero-padded to 512."""
+    kind 'w1': w [3,3,C,idim] -> [(tap,c), idim]; 'w3t': w [3,3,idim,C] -> [(tap,co), ci].  Rows zero-padded to 512.
+    kind 'w3t_thin' (C <= 12): the 'w3t' matrix with its rows padded to 16 S only, in indm_f16_chain_conv's Wc order
+    (k = 16 s + 8 (lane >> 5) + e: the thin convolution kernel's own fragment order)."""
     import weakref
     with torch.no_grad():
         st = torch.stack([w.detach() for w in ws])
         n, KH, KW, A, B = st.shape
         m = st.reshape(n, KH * KW * A, B) if kind == "w1" else st.permute(0, 1, 2, 4, 3).reshape(n, KH * KW * B, A)
-        m = torch.nn.functional.pad(m, (0, 0, 0, 512 - m.shape[1]))
-    pk = pack_w2t_bf16(list(m.unbind(0)))
+        if kind == "w3t_thin":
+            S = (m.shape[1] + 15) // 16
+            m = torch.nn.functional.pad(m, (0, 0, 0, 16 * S - m.shape[1])).to(torch.bfloat16)
+            pk = m.view(n, S, 2, 8, m.shape[2] // 32, 32).permute(0, 1, 4, 2, 5, 3).contiguous()   # [n, s, nb, lhi, l31, e]
+        else:
+            m = torch.nn.functional.pad(m, (0, 0, 0, 512 - m.shape[1]))
+    if kind != "w3t_thin":
+        pk = pack_w2t_bf16(list(m.unbind(0)))
     for k in [k for k, v in _kpad_packed.items() if v[0]() is None]:
         del _kpad_packed[k]
     for i, w in enumerate(ws):
@@ -1977,6 +2008,9 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
         if f16_wide(C):
             keep += [packed_kpad_bf16(W1, "w1"), packed_kpad_bf16(W3, "w3t")]
             a.W1_bf16w, a.W3t_bf16w = keep[-2].data_ptr(), keep[-1].data_ptr()
+        elif CHAIN_CONV["on"]:
+            keep.append(packed_kpad_bf16(W3, "w3t_thin"))
+            a.W3t_thin_bf16w = keep[-1].data_ptr()
     a.panel, a.b1, a.b2, a.b3, a.eps = _ptr(panel), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(eps)
     cf = (ctypes.c_float * max(1, len(coeffs)))(*coeffs)
     a.coeffs, a.ncoeff = ctypes.cast(cf, c_p), len(coeffs)

@@ -105,6 +105,39 @@ def test_wide_conv_on_the_im2col_operand(N, H, W, C, sign):
     close16(hip.f16_unpack(u, M, Co), ref * r16(g).double(), "wide conv gated", ulps=1.5, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,H,W,C", [(8, 32, 32, 3), (128, 32, 32, 3), (4, 16, 16, 12), (128, 16, 16, 12), (2, 64, 64, 3), (32, 32, 32, 12)])
+def test_chain_conv_is_the_thin_convolution_and_the_chain_link_in_one_launch(N, H, W, C):
+    """indm_f16_chain_conv (one series iteration of the log-det estimators as one launch) builds the A tile the thin
+    convolution's gate epilogue would have stored, in the same k order and summation order: P is BIT-identical to
+    indm_f16_thin_conv(epilogue 2) + indm_f16_rows(mode 2), which have their own fp64 tests above."""
+    M, J = N * H * W, 9 * C
+    x, w3t = rnd(N, H, W, C), rnd(J, 512, seed=1, scale=0.2)
+    d2, d1 = rnd(M, 512, seed=2), rnd(M, 512, seed=3)
+    W2T, panel = rnd(512, 512, seed=4, scale=0.05), rnd(512, J, seed=5, scale=0.1)
+    d2_16, d1_16 = hip.f16_pack(d2.to(DEV)), hip.f16_pack(d1.to(DEV))
+    Wp = hip.pack_weight_bf16(W2T.to(DEV))
+    Pp = hip.pack_weight_bf16(torch.nn.functional.pad(panel, (0, (32 if J <= 32 else 128) - J)).to(DEV))
+    u2, none = hip.f16_thin_conv(x.to(DEV), w3t.to(DEV), 1, hip.F16_GATE, gate=d2_16)
+    assert none is None
+    want, _ = hip.f16_rows(hip.F16_CHAIN, u2, M, Wp=Wp, D1=d1_16, Pp=Pp, J=J)
+    got = hip.f16_chain_conv(x.to(DEV), hip.pack_thin_conv_bf16(w3t.to(DEV)), d2_16, Wp, d1_16, Pp, sign=1)
+    assert got is not None and torch.equal(got, want), (got - want).abs().max().item()
+    # and against the fp64 statement (bf16-rounded operands, the gated intermediates rounded to bf16 where the kernels round them)
+    idx = torch.arange(0, M, max(1, M // 128))
+    t3 = _emu.conv3x3_thin(r16(x).double(), r16(w3t).double(), 1).reshape(M, 512)[idx]
+    u = r16((t3 * r16(d2)[idx].double()).float()).double()
+    t2 = u @ r16(W2T).double()
+    ref = r16((t2 * r16(d1)[idx].double()).float()).double() @ r16(panel).double()
+    assert (got[idx.to(DEV)].cpu().double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+
+
+def test_chain_conv_declines_uncovered_geometry():
+    z16 = torch.zeros(2048 * 512, dtype=torch.bfloat16, device=DEV)
+    Wp = hip.pack_weight_bf16(rnd(512, 512).to(DEV))
+    assert hip.f16_chain_conv(rnd(2, 32, 32, 5).to(DEV), hip.pack_thin_conv_bf16(rnd(48, 512).to(DEV)), z16, Wp, z16,
+                              hip.pack_weight_bf16(rnd(512, 128).to(DEV))) is None
+
+
 def test_tap_spread_declines_uncovered_geometry():
     assert hip.f16_tap_spread(rnd(2, 16, 16, 6).to(DEV), -1) is None       # C % 4
     assert hip.f16_tap_spread(rnd(2, 16, 16, 64).to(DEV), -1) is None      # 9 C > 512
