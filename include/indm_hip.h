@@ -275,9 +275,10 @@ int indm_f16_rows(int mode, const void* A, const void* Wp, const void* D1, const
  * workgroup builds its A tile from x and the d2 gate itself (bit-identical to the two launches).  x: fp32 NHWC [Nimg,H,W,C] with
  * C <= 3 or C in {4, 8, 12}; Wc: the transposed convolution's weight w[(tap, co), ci] (rows zero-padded to 16 S, S = ceil(9 C / 16))
  * packed as Wc[s][nb][lane][e] = bf16(w[16 s + 8 (lane >> 5) + e][32 nb + (lane & 31)]); gate, D1: F16 [M, 512]; W2Tp, Pp: as for
- * indm_f16_rows.  Returns 1 if not covered. */
+ * indm_f16_rows.  t2_out (optional, F16): (C3^T x .* gate) W2Tp, the tensor mode 2 stores through out1; t3_out (optional, needs
+ * t2_out): the ungated C3^T x -- the training step's last link saves both for the backward.  Returns 1 if not covered. */
 int indm_f16_chain_conv(const float* x, const void* Wc, const void* gate, const void* W2Tp, const void* D1, const void* Pp, float* P,
-                        int Nimg, int H, int W, int C, int sign, int J, void* stream);
+                        void* t3_out, void* t2_out, int Nimg, int H, int W, int C, int sign, int J, void* stream);
 
 /* One Sin level of the hand-written iResBlock backward on F16 tensors (the F16 form of indm_ires_bwd_act_f32; replaces
  * autograd over iresblock.py:253-273's double backward): dp = da .* d - 4 pi^2 a .* (du .* t); seg (optional, fp32

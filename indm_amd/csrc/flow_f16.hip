@@ -540,10 +540,12 @@ struct ChainConvArgs {
   const float* X;    // [Nimg, H, W, C] fp32
   const u16* Wc;     // packed [S][16][64][8]: Wc[s][nb][lane][e] = bf16(w[16 s + 8 (lane >> 5) + e][32 nb + (lane & 31)]), rows >= 9 C zero
   const u16* G;      // F16 [M, 512]: d2
+  u16* T3;           // optional: the ungated convolution output (F16), as the thin kernel's gate epilogue stores it
   int H, W, C, sign, S;
 };
 
-template <int JB, int TMV, int SMAX, bool VEC4>
+// T2OUT: the training step's LAST link also stores t3 = C3^T w (a.T3) and t2 = (t3 .* d2) W2T (a.r.O1) for the backward
+template <int JB, int TMV, int SMAX, bool VEC4, bool T2OUT>
 __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvArgs a) {
   constexpr int MB = TMV / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -634,21 +636,28 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvA
         float v[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * s + e];
+        if constexpr (T2OUT) {
+          if (a.T3) *(u32x4*)(a.T3 + chunk(i, j, s)) = pack8(v);
+        }
         unpack8(gq[i][j][s], g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= g[e];
         *(u32x4*)(smem + (j * 32 + 2 * (2 * wave + i) + s) * 1024 + lane * 16) = pack8(v);
       }
   __syncthreads();
-  rows_tile<R_CHAIN, JB, false, TMV, 4>(a.r, smem, tile, tid, lane, wave, l31, lhi);
+  rows_tile<R_CHAIN, JB, T2OUT, TMV, 4>(a.r, smem, tile, tid, lane, wave, l31, lhi);
 }
 
+template <int JB, int TMV, int SMAX, bool VEC4, bool T2OUT>
+int launch_chain_conv_t(const ChainConvArgs& a, hipStream_t st) {
+  constexpr int bytes = TMV * R_N * 2 + (TMV / 32) * SMAX * 1024;
+  if (indm_lds_optin<f16_chain_conv_kernel<JB, TMV, SMAX, VEC4, T2OUT>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+  hipLaunchKernelGGL((f16_chain_conv_kernel<JB, TMV, SMAX, VEC4, T2OUT>), dim3(a.r.M / TMV), dim3(R_NW * 64), bytes, st, a);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
 template <int JB, int TMV, int SMAX, bool VEC4>
 int launch_chain_conv(const ChainConvArgs& a, hipStream_t st) {
-  constexpr int bytes = TMV * R_N * 2 + (TMV / 32) * SMAX * 1024;
-  if (indm_lds_optin<f16_chain_conv_kernel<JB, TMV, SMAX, VEC4>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
-  hipLaunchKernelGGL((f16_chain_conv_kernel<JB, TMV, SMAX, VEC4>), dim3(a.r.M / TMV), dim3(R_NW * 64), bytes, st, a);
-  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+  return a.r.O1 ? launch_chain_conv_t<JB, TMV, SMAX, VEC4, true>(a, st) : launch_chain_conv_t<JB, TMV, SMAX, VEC4, false>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1230,15 +1239,17 @@ INDM_API int indm_f16_rows(int mode, const void* A, const void* Bp, const void* 
 }
 
 INDM_API int indm_f16_chain_conv(const float* x, const void* Wc, const void* gate, const void* W2Tp, const void* D1,
-                                 const void* Pp, float* P, int Nimg, int H, int W, int C, int sign, int J, void* stream) {
+                                 const void* Pp, float* P, void* t3_out, void* t2_out, int Nimg, int H, int W, int C, int sign, int J,
+                                 void* stream) {
   if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0) return INDM_E_SHAPE;
   if (Nimg == 0) return INDM_OK;
   const long M = (long)Nimg * H * W;
   if (!(C <= 3 || (C <= 12 && !(C & 3))) || (M % R_TM) || M * C >= (1L << 31) || M >= (1L << 31) || J != 9 * C) return 1;
   if (!x || !Wc || !gate || !W2Tp || !D1 || !Pp || !P) return INDM_E_ARG;
-  if (!al16(x) || !al16(Wc) || !al16(gate) || !al16(W2Tp) || !al16(D1) || !al16(Pp)) return INDM_E_ARG;
-  ChainConvArgs a = {{nullptr, (const u16*)W2Tp, (const u16*)D1, (const u16*)Pp, P, nullptr, nullptr, nullptr, nullptr, (int)M, J, 1},
-                     x, (const u16*)Wc, (const u16*)gate, H, W, C, sign, (9 * C + 15) >> 4};
+  if (!al16(x) || !al16(Wc) || !al16(gate) || !al16(W2Tp) || !al16(D1) || !al16(Pp) || !al16(t3_out) || !al16(t2_out)) return INDM_E_ARG;
+  if (t3_out && !t2_out) return INDM_E_ARG;   // (t3 is stored by the form that stores t2: the training step's last link)
+  ChainConvArgs a = {{nullptr, (const u16*)W2Tp, (const u16*)D1, (const u16*)Pp, P, (u16*)t2_out, nullptr, nullptr, nullptr, (int)M, J, 1},
+                     x, (const u16*)Wc, (const u16*)gate, (u16*)t3_out, H, W, C, sign, (9 * C + 15) >> 4};
   hipStream_t st = (hipStream_t)stream;
   const bool small = M / R_TM < 512;   // the tile rule of launch_rows
   if (C <= 3) return small ? launch_chain_conv<1, 32, 2, false>(a, st) : launch_chain_conv<1, 64, 2, false>(a, st);

@@ -248,20 +248,20 @@ struct Ctx16 {
   // one series iteration: u2 = (C3^T v) .* d2, P = ((u2 W2T) .* d1) panel -- ONE launch (indm_f16_chain_conv) when the thin-order
   // pack of W3^T is given (C <= 12), else the thin convolution + the chain link
   int series(const float* vin, const float* w3t, const void* w3t_wide, const void* w3t_thin, const void* d2, void* u2,
-             const void* W2Tp, const void* d1, const void* panelp, float* P) const {
+             const void* W2Tp, const void* d1, const void* panelp, float* P, void* t3 = nullptr, void* t2 = nullptr) const {
     static const int fused = getenv("INDM_F16_CHAIN_CONV") ? atoi(getenv("INDM_F16_CHAIN_CONV")) : 1;
     if (fused && w3t_thin && !wide()) {
       const int J = 9 * C;
       hipEvent_t e0 = nullptr, e1 = nullptr;
       if (timer) {
-        const int cls = (J <= 32 ? 0 : 2);
+        const int cls = (J <= 32 ? 0 : 2) + (t2 ? 1 : 0);
         if (((timer->mask >> cls) & 1) && timer->used + 2 <= (int)timer->ev.size()) {
           e0 = timer->ev[timer->used];
           e1 = timer->ev[timer->used + 1];
         }
       }
       if (e0) (void)hipEventRecord(e0, (hipStream_t)st);
-      const int r = indm_f16_chain_conv(vin, w3t_thin, d2, W2Tp, d1, panelp, P, N, H, W, C, 1, J, st);
+      const int r = indm_f16_chain_conv(vin, w3t_thin, d2, W2Tp, d1, panelp, P, t3, t2, N, H, W, C, 1, J, st);
       if (r != 1) {
         if (e0) {
           (void)hipEventRecord(e1, (hipStream_t)st);
@@ -271,9 +271,9 @@ struct Ctx16 {
         return r;
       }
     }
-    int r = thin(vin, w3t, w3t_wide, nullptr, d2, u2, nullptr, 1, F16_GATE);
+    int r = thin(vin, w3t, w3t_wide, nullptr, d2, u2, t3, 1, F16_GATE);
     if (r != 0) return r;
-    return chain(u2, W2Tp, d1, panelp, P, nullptr);
+    return chain(u2, W2Tp, d1, panelp, P, t2);
   }
   int chain(const void* u2, const void* W2Tp, const void* d1, const void* panelp, float* P, void* t2) const {
     const int J = 9 * C;
@@ -360,8 +360,7 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
     }
     if (K == 0 && hipMemcpyAsync(a->w, a->eps, nC * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
       return INDM_E_LAUNCH;
-    TRY(c.thin(a->w, a->W3_tapco_ci, a->W3t_bf16w, nullptr, d2, u2, a->t3, 1, F16_GATE));   // ... and t3 itself, saved
-    TRY(c.chain(u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, a->t2));
+    TRY(c.series(a->w, a->W3_tapco_ci, a->W3t_bf16w, a->W3t_thin_bf16w, d2, u2, a->W2T_bf16w, d1, a->panel_bf16w, Pn, a->t3, a->t2));   // ... and t3, t2 saved
     if (a->preact) {
       TRY(indm_tap_gather_f32(Pn, nullptr, a->c1, c.N, c.H, c.W, c.C, -1, 1.0f, stream));
       TRY(indm_mul_f32(a->c1, d0, g, 1.0f, nC, stream));

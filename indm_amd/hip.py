@@ -132,7 +132,7 @@ _SIGS = {
     "indm_f16_unpack_f32": [c_p, c_p, c_l, c_i, c_p],
     "indm_f16_thin_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_tap_spread": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
-    "indm_f16_chain_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "indm_f16_chain_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "indm_f16_bwd_act_ok": [c_l, c_l],
     "indm_f16_bwd_act": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
@@ -1509,16 +1509,19 @@ def pack_thin_conv_bf16(w2d):
     return m.view(S, 2, 8, N // 32, 32).permute(0, 3, 1, 4, 2).contiguous()
 
 
-def f16_chain_conv(x, Wc, gate, W2Tp, D1, Pp, sign=1):
-    """indm_f16_chain_conv -> P fp32 [N H W, 9 C] (None if not covered)"""
+def f16_chain_conv(x, Wc, gate, W2Tp, D1, Pp, sign=1, want_t=False):
+    """indm_f16_chain_conv -> P fp32 [N H W, 9 C] (want_t: (P, t3, t2) with the two saved F16 tensors); None if not covered"""
     N, H, W, C = x.shape
-    P = torch.empty((N * H * W, 9 * C), dtype=torch.float32, device=x.device)
-    st = lib().indm_f16_chain_conv(_ptr(x), _ptr16(Wc), _ptr16(gate), _ptr16(W2Tp), _ptr16(D1), _ptr16(Pp), _ptr(P), N, H, W, C, sign,
-                                   9 * C, _stream())
+    M = N * H * W
+    P = torch.empty((M, 9 * C), dtype=torch.float32, device=x.device)
+    t3 = torch.empty(M * 512, dtype=torch.bfloat16, device=x.device) if want_t else None
+    t2 = torch.empty(M * 512, dtype=torch.bfloat16, device=x.device) if want_t else None
+    st = lib().indm_f16_chain_conv(_ptr(x), _ptr16(Wc), _ptr16(gate), _ptr16(W2Tp), _ptr16(D1), _ptr16(Pp), _ptr(P), _ptr16(t3),
+                                   _ptr16(t2), N, H, W, C, sign, 9 * C, _stream())
     if st == 1:
         return None
     _chk(st, "indm_f16_chain_conv")
-    return P
+    return (P, t3, t2) if want_t else P
 
 
 def f16_tap_spread(x, sign):

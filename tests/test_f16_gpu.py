@@ -122,6 +122,12 @@ def test_chain_conv_is_the_thin_convolution_and_the_chain_link_in_one_launch(N, 
     want, _ = hip.f16_rows(hip.F16_CHAIN, u2, M, Wp=Wp, D1=d1_16, Pp=Pp, J=J)
     got = hip.f16_chain_conv(x.to(DEV), hip.pack_thin_conv_bf16(w3t.to(DEV)), d2_16, Wp, d1_16, Pp, sign=1)
     assert got is not None and torch.equal(got, want), (got - want).abs().max().item()
+    # the training step's last link: t3 (ungated) and t2 stored as well, all three bit-identical to the two launches
+    u2b, t3w = hip.f16_thin_conv(x.to(DEV), w3t.to(DEV), 1, hip.F16_GATE, gate=d2_16, want_raw=True)
+    Pw, t2w = hip.f16_rows(hip.F16_CHAIN, u2b, M, Wp=Wp, D1=d1_16, Pp=Pp, J=J, want_t2=True)
+    Pg, t3g, t2g = hip.f16_chain_conv(x.to(DEV), hip.pack_thin_conv_bf16(w3t.to(DEV)), d2_16, Wp, d1_16, Pp, sign=1, want_t=True)
+    assert torch.equal(Pg, Pw) and torch.equal(t3g.view(torch.int16), t3w.view(torch.int16))
+    assert torch.equal(t2g.view(torch.int16), t2w.view(torch.int16))
     # and against the fp64 statement (bf16-rounded operands, the gated intermediates rounded to bf16 where the kernels round them)
     idx = torch.arange(0, M, max(1, M // 128))
     t3 = _emu.conv3x3_thin(r16(x).double(), r16(w3t).double(), 1).reshape(M, 512)[idx]
