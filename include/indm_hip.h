@@ -264,6 +264,7 @@ int indm_f16_tap_spread(const float* x, void* out, int Nimg, int H, int W, int C
  * mode 2  P[M, J] = ((A Wp) .* D1) Pp[:, :J]; out1 (optional) = A Wp                (the back-to-back VJP link of indm_ires_chain_*, iresblock.py:257,269)
  * mode 3  P[M, J] = A Pp[:, :J]                                                       (3x3 conv with a skinny OUTPUT before its tap gather)
  * mode 4  out1 = (A Wp + bias) .* D1, out2 (optional) = A Wp + bias                   (mode 0 with the gate epilogue of indm_f16_thin_conv)
+ * mode 5  mode 1, and P[M, J] = out1 Pp[:, :J] in the same launch (J <= 128)           (the g-net's Sin -> skinny-output 3x3 conv: modes 1 + 3)
  * Wp: packed [512, 512]; Pp: packed [512, 32 | 128 | 448] panel (J <= 32 | J <= 128 | J <= 448), P fp32 row-major.
  * Returns 1 if not covered. */
 int indm_f16_rows(int mode, const void* A, const void* Wp, const void* D1, const void* Pp, float* P, void* out1, void* out2,

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void f16_unpack_kernel(const u16* __restrict__
 
 // ---------------------------------------------------------------------------------------------------------------
 // f16_rows_kernel
-enum { R_GEMM = 0, R_GEMM_ACT = 1, R_CHAIN = 2, R_THINN = 3, R_GEMM_GATE = 4 };
+enum { R_GEMM = 0, R_GEMM_ACT = 1, R_CHAIN = 2, R_THINN = 3, R_GEMM_GATE = 4, R_GEMM_ACT_THINN = 5 };
 constexpr int R_TM = 64, R_N = 512, R_NW = 8;
 constexpr int R_LDS_BYTES = R_TM * R_N * 2;   // the A tile; the stage-2 reduction buffer [8][64][32] fp32 overlays it
 
@@ -201,7 +201,7 @@ __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const l
     return ((((tile * MB + j) * 16 + 2 * wave + i) * 2 + s) * 64 + lane) * 8;   // bf16 index
   };
 
-  if constexpr (MODE == R_GEMM || MODE == R_GEMM_ACT || MODE == R_GEMM_GATE) {
+  if constexpr (MODE == R_GEMM || MODE == R_GEMM_ACT || MODE == R_GEMM_GATE || MODE == R_GEMM_ACT_THINN) {
     // acc[i][j][r] = C[m = m0 + 32 j + l31][n = 64 wave + 32 i + (r & 3) + 8 (r >> 2) + 4 lhi]
     const float* b2 = p.bias2 ? p.bias2 + (m0 / p.rpg) * R_N : nullptr;   // rpg % 64 == 0: one image per tile
 #pragma unroll
@@ -225,7 +225,7 @@ __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const l
           float v[8], w[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * s + e] + bv[8 * s + e];
-          if constexpr (MODE == R_GEMM_ACT) {
+          if constexpr (MODE == R_GEMM_ACT || MODE == R_GEMM_ACT_THINN) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) sin_act(v[e], v[e], w[e]);
             *(u32x4*)(p.O2 + chunk(i, j, s)) = pack8(w);
@@ -236,10 +236,19 @@ __device__ __forceinline__ void rows_tile(const RowsArgs& p, char* smem, const l
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= w[e];
           }
-          *(u32x4*)(p.O1 + chunk(i, j, s)) = pack8(v);
+          if constexpr (MODE == R_GEMM_ACT_THINN) {
+            // (round 6) the activation a, rounded to bf16, IS the operand fragment of the thin-N product that follows it in the
+            // g-net (a2 W3 before the tap gather): stage 2 below runs on it -- the separate thin-N launch re-read a2 from HBM
+            const u32x4 pk = pack8(v);
+            hm2[i][j][s] = __builtin_bit_cast(bf16x8, pk);
+            *(u32x4*)(p.O1 + chunk(i, j, s)) = pk;
+          } else {
+            *(u32x4*)(p.O1 + chunk(i, j, s)) = pack8(v);
+          }
         }
     }
-    return;
+    if constexpr (MODE != R_GEMM_ACT_THINN) return;
+    else __syncthreads();   // every wave is done with the A tile: the reduction buffer overlays it
   }
 
   if constexpr (MODE == R_CHAIN) {
@@ -1224,6 +1233,10 @@ INDM_API int indm_f16_rows(int mode, const void* A, const void* Bp, const void* 
     case R_GEMM_GATE:
       if (!Bp || !D1 || !out1) return INDM_E_ARG;
       return launch_rows<R_GEMM_GATE, 1, false>(a, st);
+    case R_GEMM_ACT_THINN:
+      if (!Bp || !out1 || !out2 || !Pp || !P || J < 1 || J > 128) return INDM_E_ARG;
+      if (bias2 && (a.rpg % R_TM)) return 1;
+      return J <= 32 ? launch_rows<R_GEMM_ACT_THINN, 1, false>(a, st) : launch_rows<R_GEMM_ACT_THINN, 4, false>(a, st);
     case R_CHAIN:
       if (!Bp || !D1 || !Pp || !P || J < 1 || J > 448) return INDM_E_ARG;
       if (J <= 32) return out1 ? launch_rows<R_CHAIN, 1, true>(a, st) : launch_rows<R_CHAIN, 1, false>(a, st);

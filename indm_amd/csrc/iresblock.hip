@@ -208,7 +208,7 @@ INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int
 // by the chain kernel on its accumulators.  Per series iteration: 134 MB written + 134 MB read by the thin convolution,
 // 268 MB read by the chain kernel at batch 128 (fp32 tensors: 268 written, 805 read).
 namespace {
-enum { F16_PLAIN = 0, F16_ACT = 1, F16_GATE = 2, F16R_GEMM = 0, F16R_GEMM_ACT = 1, F16R_CHAIN = 2, F16R_THINN = 3, F16R_GEMM_GATE = 4 };
+enum { F16_PLAIN = 0, F16_ACT = 1, F16_GATE = 2, F16R_GEMM = 0, F16R_GEMM_ACT = 1, F16R_CHAIN = 2, F16R_THINN = 3, F16R_GEMM_GATE = 4, F16R_GEMM_ACT_THINN = 5 };
 
 // 12 < C (the 48-channel scale of the 64 x 64 flows, 9 C = 432 taps): no gathering thin kernel -- the skinny side's im2col image
 // becomes an F16 [M, 512] operand (indm_f16_tap_spread into `colF`, zero columns behind 9 C) and the convolution the 64-row
@@ -313,8 +313,17 @@ static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb,
     in = a0;
   }
   TRY(c.thin(in, W1, W1p, b1, nullptr, a1, d1, -1, F16_ACT));                                // (a1, d1) = Sin(conv(a0, W1) + b1)
-  TRY(indm_f16_rows(F16R_GEMM_ACT, a1, W2p, nullptr, nullptr, nullptr, a2, d2, b2, cb, (int)c.M, 0, c.H * c.W, c.st));   // Sin(a1 W2 + b2 + cb[n])
-  TRY(indm_f16_rows(F16R_THINN, a2, nullptr, nullptr, W3p, Pn, nullptr, nullptr, nullptr, nullptr, (int)c.M, 9 * c.C, 1, c.st));
+  // (a2, d2) = Sin(a1 W2 + b2 + cb[n]) and Pn = a2 W3 (the skinny-output convolution before its tap gather): one launch where the
+  // panel has <= 128 columns (round 6: the thin-N product runs on the activation's accumulators), else two
+  static const int fuse_thinn = getenv("INDM_F16_ACT_THINN") ? atoi(getenv("INDM_F16_ACT_THINN")) : 1;
+  int fz = 1;
+  if (fuse_thinn && 9 * c.C <= 128 && c.M / 64 >= 512)
+    fz = indm_f16_rows(F16R_GEMM_ACT_THINN, a1, W2p, nullptr, W3p, Pn, a2, d2, b2, cb, (int)c.M, 9 * c.C, c.H * c.W, c.st);
+  if (fz < 0) return fz;
+  if (fz == 1) {
+    TRY(indm_f16_rows(F16R_GEMM_ACT, a1, W2p, nullptr, nullptr, nullptr, a2, d2, b2, cb, (int)c.M, 0, c.H * c.W, c.st));   // Sin(a1 W2 + b2 + cb[n])
+    TRY(indm_f16_rows(F16R_THINN, a2, nullptr, nullptr, W3p, Pn, nullptr, nullptr, nullptr, nullptr, (int)c.M, 9 * c.C, 1, c.st));
+  }
   if (y_res) TRY(indm_tap_gather_acc_f32(Pn, b3, nullptr, g, x, y_res, 1.0f, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
   else TRY(indm_tap_gather_f32(Pn, b3, g, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
   return 0;

@@ -1459,7 +1459,7 @@ def pack_weight_bf16(w):
 
 
 F16_PLAIN, F16_ACT, F16_GATE = 0, 1, 2
-F16_GEMM, F16_GEMM_ACT, F16_CHAIN, F16_THINN, F16_GEMM_GATE = 0, 1, 2, 3, 4
+F16_GEMM, F16_GEMM_ACT, F16_CHAIN, F16_THINN, F16_GEMM_GATE, F16_GEMM_ACT_THINN = 0, 1, 2, 3, 4, 5
 
 
 def f16_thin_conv(x, w2d, sign, epilogue=F16_PLAIN, bias=None, gate=None, want_raw=False):
@@ -1483,9 +1483,9 @@ def f16_rows(mode, A, M, Wp=None, D1=None, Pp=None, J=0, bias=None, bias2=None, 
     F16_GEMM_GATE -> (C .* D1, C).  None if not covered."""
     dev = A.device
     new16 = lambda: torch.empty(M * 512, dtype=torch.bfloat16, device=dev)  # noqa: E731
-    o1 = new16() if (mode in (F16_GEMM, F16_GEMM_ACT, F16_GEMM_GATE) or (mode == F16_CHAIN and want_t2)) else None
-    o2 = new16() if mode in (F16_GEMM_ACT, F16_GEMM_GATE) else None
-    P = torch.empty((M, J), dtype=torch.float32, device=dev) if mode in (F16_CHAIN, F16_THINN) else None
+    o1 = new16() if (mode in (F16_GEMM, F16_GEMM_ACT, F16_GEMM_GATE, F16_GEMM_ACT_THINN) or (mode == F16_CHAIN and want_t2)) else None
+    o2 = new16() if mode in (F16_GEMM_ACT, F16_GEMM_GATE, F16_GEMM_ACT_THINN) else None
+    P = torch.empty((M, J), dtype=torch.float32, device=dev) if mode in (F16_CHAIN, F16_THINN, F16_GEMM_ACT_THINN) else None
     st = lib().indm_f16_rows(mode, _ptr16(A), _ptr16(Wp), _ptr16(D1), _ptr16(Pp), _ptr(P),
                              o1.data_ptr() if o1 is not None else None, o2.data_ptr() if o2 is not None else None,
                              _ptr(bias), _ptr(bias2), M, J, rows_per_group, _stream())
@@ -1494,6 +1494,8 @@ def f16_rows(mode, A, M, Wp=None, D1=None, Pp=None, J=0, bias=None, bias2=None, 
     _chk(st, "indm_f16_rows")
     if mode == F16_GEMM:
         return o1
+    if mode == F16_GEMM_ACT_THINN:
+        return o1, o2, P
     if mode in (F16_GEMM_ACT, F16_GEMM_GATE):
         return o1, o2
     if mode == F16_CHAIN:

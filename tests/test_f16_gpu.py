@@ -144,6 +144,22 @@ def test_chain_conv_declines_uncovered_geometry():
                               hip.pack_weight_bf16(rnd(512, 128).to(DEV))) is None
 
 
+@pytest.mark.parametrize("M,J", [(64, 27), (32768, 27), (32768, 108), (131072, 27)])
+def test_rows_activation_with_thin_n_in_one_launch(M, J):
+    """mode 5 = mode 1 (GEMM + Sin activation) + mode 3 (thin-N panel product of the activation) in one launch: all three outputs
+    bit-identical to the two launches (which have their own fp64 tests above)."""
+    A, Wm, b, b2 = rnd(M, 512), rnd(512, 512, seed=1, scale=0.05), rnd(512, seed=2), rnd(M // 64, 512, seed=3)
+    panel = rnd(512, J, seed=6, scale=0.1)
+    A16, Wp = hip.f16_pack(A.to(DEV)), hip.pack_weight_bf16(Wm.to(DEV))
+    Pp = hip.pack_weight_bf16(torch.nn.functional.pad(panel, (0, (32 if J <= 32 else 128) - J)).to(DEV))
+    a, d = hip.f16_rows(hip.F16_GEMM_ACT, A16, M, Wp=Wp, bias=b.to(DEV), bias2=b2.to(DEV), rows_per_group=64)
+    T = hip.f16_rows(hip.F16_THINN, a, M, Pp=Pp, J=J)
+    a5, d5, T5 = hip.f16_rows(hip.F16_GEMM_ACT_THINN, A16, M, Wp=Wp, Pp=Pp, J=J, bias=b.to(DEV), bias2=b2.to(DEV), rows_per_group=64)
+    assert torch.equal(a5.view(torch.int16), a.view(torch.int16)) and torch.equal(d5.view(torch.int16), d.view(torch.int16))
+    # (the thin-N launch sums its 32-row tiles' eight wave partials in the same fixed order; its tile is 32 rows, this one's 32 or 64)
+    assert torch.equal(T5, T), (T5 - T).abs().max().item()
+
+
 def test_tap_spread_declines_uncovered_geometry():
     assert hip.f16_tap_spread(rnd(2, 16, 16, 6).to(DEV), -1) is None       # C % 4
     assert hip.f16_tap_spread(rnd(2, 16, 16, 64).to(DEV), -1) is None      # 9 C > 512
