@@ -11,6 +11,7 @@ CLASSES = [
     ("H16 score net: GroupNorm", lambda n: "h16_gn_" in n),
     ("H16 score net: bias-grad sums", lambda n: "h16_col" in n),
     ("H16 score net: pack / convert / resample", lambda n: "h16_" in n),
+    ("F16 flow: series iteration in one launch (conv + gate + chain)", lambda n: "f16_chain_conv_kernel" in n),
     ("F16 flow: 64-row GEMM / chain / thin-N", lambda n: "f16_rows_kernel" in n),
     ("F16 flow: thin conv", lambda n: "f16_thin_conv" in n),
     ("F16 flow: weight grads", lambda n: "f16_thin_wgrad" in n or "f16_wgrad" in n),
