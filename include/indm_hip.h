@@ -281,6 +281,13 @@ int indm_f16_rows(int mode, const void* A, const void* Wp, const void* D1, const
 int indm_f16_chain_conv(const float* x, const void* Wc, const void* gate, const void* W2Tp, const void* D1, const void* Pp, float* P,
                         void* t3_out, void* t2_out, int Nimg, int H, int W, int C, int sign, int J, void* stream);
 
+/* The same tile construction followed by the plain 64-row GEMM (the backward's reverse sweep, replaces autograd through
+ * iresblock.py:264-273):  raw_out = conv(x, Wc), gated_out = raw_out .* gate, out = gated_out Wp  (all F16 [M, 512]; raw_out and
+ * gated_out optional) = indm_f16_thin_conv(epilogue 2) + indm_f16_rows mode 0 in one launch, bit-identical.  sign as for
+ * indm_f16_thin_conv; Wc as for indm_f16_chain_conv.  Returns 1 if not covered. */
+int indm_f16_conv_gemm(const float* x, const void* Wc, const void* gate, const void* Wp, void* out, void* raw_out, void* gated_out,
+                       int Nimg, int H, int W, int C, int sign, void* stream);
+
 /* One Sin level of the hand-written iResBlock backward on F16 tensors (the F16 form of indm_ires_bwd_act_f32; replaces
  * autograd over iresblock.py:253-273's double backward): dp = da .* d - 4 pi^2 a .* (du .* t); seg (optional, fp32
  * [R / rows_per_seg][512]) = per-image column sums of dp.  rows_per_seg % 128 == 0 (indm_f16_bwd_act_ok), else returns 1. */
@@ -567,6 +574,9 @@ typedef struct {
    * stream, the launch order of rounds 3 - 5.  Same kernels and results either way. */
   void* side_stream;
   float* side_splitk_ws; long side_splitk_ws_floats;
+  /* bf16 = 2 and C <= 12, optional: W1 as [(tap,c), idim] in indm_f16_chain_conv's Wc form -- q1, q1 .* d1 and du2 then come out of
+   * one launch (indm_f16_conv_gemm) */
+  const void* W1_thin_bf16w;
 } indm_iresblock_bwd_args;
 
 /* Fixed-point inverse x <- y - g(x) (iresblock.py:78-88): iterates until every element passes

@@ -550,11 +550,14 @@ struct ChainConvArgs {
   const u16* Wc;     // packed [S][16][64][8]: Wc[s][nb][lane][e] = bf16(w[16 s + 8 (lane >> 5) + e][32 nb + (lane & 31)]), rows >= 9 C zero
   const u16* G;      // F16 [M, 512]: d2
   u16* T3;           // optional: the ungated convolution output (F16), as the thin kernel's gate epilogue stores it
+  u16* U2;           // optional: the gated convolution output (F16) -- the tile itself
   int H, W, C, sign, S;
 };
 
-// T2OUT: the training step's LAST link also stores t3 = C3^T w (a.T3) and t2 = (t3 .* d2) W2T (a.r.O1) for the backward
-template <int JB, int TMV, int SMAX, bool VEC4, bool T2OUT>
+// T2OUT: the training step's LAST link also stores t3 = C3^T w (a.T3) and t2 = (t3 .* d2) W2T (a.r.O1) for the backward.
+// TAIL = R_GEMM (indm_f16_conv_gemm, the backward's  q1 = conv(q0, W1), q1 .* d1, du2 = (q1 .* d1) W2): the tile is followed by the
+// plain 64-row GEMM instead of the chain stages; the raw and the gated convolution outputs are stored too (a.T3, a.U2).
+template <int JB, int TMV, int SMAX, bool VEC4, bool T2OUT, int TAIL = R_CHAIN>
 __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvArgs a) {
   constexpr int MB = TMV / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -645,16 +648,28 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvA
         float v[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * s + e];
-        if constexpr (T2OUT) {
+        if constexpr (T2OUT || TAIL == R_GEMM) {
           if (a.T3) *(u32x4*)(a.T3 + chunk(i, j, s)) = pack8(v);
         }
         unpack8(gq[i][j][s], g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= g[e];
-        *(u32x4*)(smem + (j * 32 + 2 * (2 * wave + i) + s) * 1024 + lane * 16) = pack8(v);
+        const u32x4 pk = pack8(v);
+        if constexpr (TAIL == R_GEMM) {
+          if (a.U2) *(u32x4*)(a.U2 + chunk(i, j, s)) = pk;
+        }
+        *(u32x4*)(smem + (j * 32 + 2 * (2 * wave + i) + s) * 1024 + lane * 16) = pk;
       }
   __syncthreads();
-  rows_tile<R_CHAIN, JB, T2OUT, TMV, 4>(a.r, smem, tile, tid, lane, wave, l31, lhi);
+  rows_tile<TAIL, JB, T2OUT, TMV, 4>(a.r, smem, tile, tid, lane, wave, l31, lhi);
+}
+
+template <int TMV, int SMAX, bool VEC4>
+int launch_conv_gemm(const ChainConvArgs& a, hipStream_t st) {
+  constexpr int bytes = TMV * R_N * 2 + (TMV / 32) * SMAX * 1024;
+  if (indm_lds_optin<f16_chain_conv_kernel<1, TMV, SMAX, VEC4, false, R_GEMM>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+  hipLaunchKernelGGL((f16_chain_conv_kernel<1, TMV, SMAX, VEC4, false, R_GEMM>), dim3(a.r.M / TMV), dim3(R_NW * 64), bytes, st, a);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
 }
 
 template <int JB, int TMV, int SMAX, bool VEC4, bool T2OUT>
@@ -1262,11 +1277,27 @@ INDM_API int indm_f16_chain_conv(const float* x, const void* Wc, const void* gat
   if (!al16(x) || !al16(Wc) || !al16(gate) || !al16(W2Tp) || !al16(D1) || !al16(Pp) || !al16(t3_out) || !al16(t2_out)) return INDM_E_ARG;
   if (t3_out && !t2_out) return INDM_E_ARG;   // (t3 is stored by the form that stores t2: the training step's last link)
   ChainConvArgs a = {{nullptr, (const u16*)W2Tp, (const u16*)D1, (const u16*)Pp, P, (u16*)t2_out, nullptr, nullptr, nullptr, (int)M, J, 1},
-                     x, (const u16*)Wc, (const u16*)gate, (u16*)t3_out, H, W, C, sign, (9 * C + 15) >> 4};
+                     x, (const u16*)Wc, (const u16*)gate, (u16*)t3_out, nullptr, H, W, C, sign, (9 * C + 15) >> 4};
   hipStream_t st = (hipStream_t)stream;
   const bool small = M / R_TM < 512;   // the tile rule of launch_rows
   if (C <= 3) return small ? launch_chain_conv<1, 32, 2, false>(a, st) : launch_chain_conv<1, 64, 2, false>(a, st);
   return small ? launch_chain_conv<4, 32, 7, true>(a, st) : launch_chain_conv<4, 64, 7, true>(a, st);
+}
+
+INDM_API int indm_f16_conv_gemm(const float* x, const void* Wc, const void* gate, const void* Wp, void* out, void* raw_out,
+                                void* gated_out, int Nimg, int H, int W, int C, int sign, void* stream) {
+  if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0) return INDM_E_SHAPE;
+  if (Nimg == 0) return INDM_OK;
+  const long M = (long)Nimg * H * W;
+  if (!(C <= 3 || (C <= 12 && !(C & 3))) || (M % R_TM) || M * C >= (1L << 31) || M >= (1L << 31)) return 1;
+  if (!x || !Wc || !gate || !Wp || !out) return INDM_E_ARG;
+  if (!al16(x) || !al16(Wc) || !al16(gate) || !al16(Wp) || !al16(out) || !al16(raw_out) || !al16(gated_out)) return INDM_E_ARG;
+  ChainConvArgs a = {{nullptr, (const u16*)Wp, nullptr, nullptr, nullptr, (u16*)out, nullptr, nullptr, nullptr, (int)M, 0, 1},
+                     x, (const u16*)Wc, (const u16*)gate, (u16*)raw_out, (u16*)gated_out, H, W, C, sign, (9 * C + 15) >> 4};
+  hipStream_t st = (hipStream_t)stream;
+  const bool small = M / R_TM < 512;
+  if (C <= 3) return small ? launch_conv_gemm<32, 2, false>(a, st) : launch_conv_gemm<64, 2, false>(a, st);
+  return small ? launch_conv_gemm<32, 7, true>(a, st) : launch_conv_gemm<64, 7, true>(a, st);
 }
 
 INDM_API long indm_f16_bwd_act_ok(long R, long rows_per_seg) {

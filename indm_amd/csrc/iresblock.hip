@@ -512,10 +512,17 @@ static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
     q0p = q0;
   }
   void *q1 = bufB, *q1g = bufC;
-  TRY(c.thin(q0p, a->W1, a->W1_bf16w, nullptr, a->d1, q1g, q1, -1, F16_GATE));                             // q1 = conv(q0, W1); q1g = q1 .* d1 (= dt2)
-  TRY(c.wgrad(q0p, -1, col, a->t2, a->d1, qb, 1, sk, skn));                                                // (t2 .* d1)^T spread(q0)
+  // q1 = conv(q0, W1); q1g = q1 .* d1 (= dt2); du2 = q1g W2 -- ONE launch (indm_f16_conv_gemm) when W1's thin-order pack is given
   void* du2 = bufD;
-  TRY(indm_f16_rows(F16R_GEMM, q1g, a->W2_bf16w, nullptr, nullptr, nullptr, du2, nullptr, nullptr, nullptr, Mi, 0, 1, stream));   // du2 = (q1 .* d1) W2
+  static const int fuse_cg = getenv("INDM_F16_CONV_GEMM") ? atoi(getenv("INDM_F16_CONV_GEMM")) : 1;
+  int fcg = 1;
+  if (fuse_cg && a->W1_thin_bf16w && !c.wide())
+    fcg = indm_f16_conv_gemm(q0p, a->W1_thin_bf16w, a->d1, a->W2_bf16w, du2, q1, q1g, c.N, c.H, c.W, C, -1, stream);
+  if (fcg < 0) return fcg;
+  if (fcg == 1) TRY(c.thin(q0p, a->W1, a->W1_bf16w, nullptr, a->d1, q1g, q1, -1, F16_GATE));
+  TRY(c.wgrad(q0p, -1, col, a->t2, a->d1, qb, 1, sk, skn));                                                // (t2 .* d1)^T spread(q0)
+  if (fcg == 1)
+    TRY(indm_f16_rows(F16R_GEMM, q1g, a->W2_bf16w, nullptr, nullptr, nullptr, du2, nullptr, nullptr, nullptr, Mi, 0, 1, stream));   // du2 = (q1 .* d1) W2
   TRY(c.wgrad(a->w, 1, col, du2, a->d2, qc, 1, sk, skn));                                                  // (du2 .* d2)^T spread(w)
   TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream, ldq));
   void* dp2 = bufE;

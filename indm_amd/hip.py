@@ -133,6 +133,7 @@ _SIGS = {
     "indm_f16_thin_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_tap_spread": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_chain_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "indm_f16_conv_gemm": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "indm_f16_bwd_act_ok": [c_l, c_l],
     "indm_f16_bwd_act": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
@@ -1526,6 +1527,19 @@ def f16_chain_conv(x, Wc, gate, W2Tp, D1, Pp, sign=1, want_t=False):
     return (P, t3, t2) if want_t else P
 
 
+def f16_conv_gemm(x, Wc, gate, Wp, sign=-1):
+    """indm_f16_conv_gemm -> (out, raw, gated) F16 [N H W, 512] (None if not covered)"""
+    N, H, W, C = x.shape
+    M = N * H * W
+    o, r, g = (torch.empty(M * 512, dtype=torch.bfloat16, device=x.device) for _ in range(3))
+    st = lib().indm_f16_conv_gemm(_ptr(x), _ptr16(Wc), _ptr16(gate), _ptr16(Wp), o.data_ptr(), r.data_ptr(), g.data_ptr(), N, H, W, C,
+                                  sign, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_conv_gemm")
+    return o, r, g
+
+
 def f16_tap_spread(x, sign):
     """indm_f16_tap_spread: NHWC fp32 x [N,H,W,C] -> F16 [N H W, 512] im2col operand (None if not covered)"""
     N, H, W, C = x.shape
@@ -1857,7 +1871,7 @@ class _IResBwdArgs(ctypes.Structure):
                                       "W2T", "W3_tapco_ci", "dx", "dcb", "dW1", "dW2", "dW3", "dW2T", "db1", "db2", "db3")]
                 + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l)]
                 + [(n, c_p) for n in ("W2_bf16w", "W2T_bf16w", "panel_bf16w", "W1_bf16w", "W3t_bf16w")]
-                + [("side_stream", c_p), ("side_splitk_ws", c_p), ("side_splitk_ws_floats", c_l)])
+                + [("side_stream", c_p), ("side_splitk_ws", c_p), ("side_splitk_ws_floats", c_l), ("W1_thin_bf16w", c_p)])
 
 
 BLOCK_DRIVERS = {"on": os.environ.get("INDM_BLOCK_DRIVERS", "1") != "0"}   # tools / tests switch to the op-level composition
@@ -1945,20 +1959,20 @@ _kpad_packed = {}  # (id(w), kind) -> (weakref, version, packed bf16 copy of w a
 def pack_kpad_bf16(ws, kind):
     """F16 wide scales: the skinny 3x3 weights of a whole scale as K-padded packed GEMM operands, registered per weight object.
     kind 'w1': w [3,3,C,idim] -> [(tap,c), idim]; 'w3t': w [3,3,idim,C] -> [(tap,co), ci].  Rows zero-padded to 512.
-    kind 'w3t_thin' (C <= 12): the 'w3t' matrix with its rows padded to 16 S only, in indm_f16_chain_conv's Wc order
+    kinds 'w3t_thin' / 'w1_thin' (C <= 12): the 'w3t' / 'w1' matrix with its rows padded to 16 S only, in indm_f16_chain_conv's Wc order
     (k = 16 s + 8 (lane >> 5) + e: the thin convolution kernel's own fragment order)."""
     import weakref
     with torch.no_grad():
         st = torch.stack([w.detach() for w in ws])
         n, KH, KW, A, B = st.shape
-        m = st.reshape(n, KH * KW * A, B) if kind == "w1" else st.permute(0, 1, 2, 4, 3).reshape(n, KH * KW * B, A)
-        if kind == "w3t_thin":
+        m = st.reshape(n, KH * KW * A, B) if kind in ("w1", "w1_thin") else st.permute(0, 1, 2, 4, 3).reshape(n, KH * KW * B, A)
+        if kind in ("w3t_thin", "w1_thin"):
             S = (m.shape[1] + 15) // 16
             m = torch.nn.functional.pad(m, (0, 0, 0, 16 * S - m.shape[1])).to(torch.bfloat16)
             pk = m.view(n, S, 2, 8, m.shape[2] // 32, 32).permute(0, 1, 4, 2, 5, 3).contiguous()   # [n, s, nb, lhi, l31, e]
         else:
             m = torch.nn.functional.pad(m, (0, 0, 0, 512 - m.shape[1]))
-    if kind != "w3t_thin":
+    if kind not in ("w3t_thin", "w1_thin"):
         pk = pack_w2t_bf16(list(m.unbind(0)))
     for k in [k for k, v in _kpad_packed.items() if v[0]() is None]:
         del _kpad_packed[k]
@@ -2093,6 +2107,9 @@ def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact, panel=None):
         if f16_wide(C):
             keep += [packed_kpad_bf16(W1, "w1"), packed_kpad_bf16(W3, "w3t")]
             a.W1_bf16w, a.W3t_bf16w = keep[-2].data_ptr(), keep[-1].data_ptr()
+        elif CHAIN_CONV["on"]:
+            keep.append(packed_kpad_bf16(W1, "w1_thin"))
+            a.W1_thin_bf16w = keep[-1].data_ptr()
     else:
         a.a1, a.d1, a.a2, a.d2, a.t3, a.t2, a.w, a.eps = (_ptr(t) for t in (a1, d1, a2, d2, t3, t2, w, eps))
     a.W1, a.W2, a.W2T, a.W3_tapco_ci = _ptr(W1), _ptr(W2), _ptr(W2T), _ptr(_packed_weight(W3, "tapco_ci"))

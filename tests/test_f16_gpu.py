@@ -137,6 +137,21 @@ def test_chain_conv_is_the_thin_convolution_and_the_chain_link_in_one_launch(N, 
     assert (got[idx.to(DEV)].cpu().double() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("N,H,W,C", [(8, 32, 32, 3), (128, 32, 32, 3), (4, 16, 16, 12), (128, 16, 16, 12)])
+def test_conv_gemm_is_the_thin_convolution_and_the_gemm_in_one_launch(N, H, W, C):
+    """indm_f16_conv_gemm (the backward's q1 = conv(q0, W1), q1 .* d1, du2 = (q1 .* d1) W2) against the two launches it replaces:
+    all three outputs bit-identical."""
+    M = N * H * W
+    x, w1 = rnd(N, H, W, C), rnd(9 * C, 512, seed=1, scale=0.2)
+    d1, W2 = rnd(M, 512, seed=2), rnd(512, 512, seed=4, scale=0.05)
+    d1_16, Wp = hip.f16_pack(d1.to(DEV)), hip.pack_weight_bf16(W2.to(DEV))
+    gated, raw = hip.f16_thin_conv(x.to(DEV), w1.to(DEV), -1, hip.F16_GATE, gate=d1_16, want_raw=True)
+    want = hip.f16_rows(hip.F16_GEMM, gated, M, Wp=Wp)
+    o, r, g = hip.f16_conv_gemm(x.to(DEV), hip.pack_thin_conv_bf16(w1.to(DEV)), d1_16, Wp, sign=-1)
+    for got, ref, name in ((o, want, "out"), (r, raw, "raw"), (g, gated, "gated")):
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), name
+
+
 def test_chain_conv_declines_uncovered_geometry():
     z16 = torch.zeros(2048 * 512, dtype=torch.bfloat16, device=DEV)
     Wp = hip.pack_weight_bf16(rnd(512, 512).to(DEV))
