@@ -288,6 +288,14 @@ int indm_f16_chain_conv(const float* x, const void* Wc, const void* gate, const 
 int indm_f16_conv_gemm(const float* x, const void* Wc, const void* gate, const void* Wp, void* out, void* raw_out, void* gated_out,
                        int Nimg, int H, int W, int C, int sign, void* stream);
 
+/* The g-net of an iResBlock (iresblock.py:60-76 behind the optional first Sin) as ONE launch, bit-identical to
+ * indm_f16_thin_conv(epilogue 1) + indm_f16_rows mode 5:
+ *   (a1, d1) = Sin(conv(x, W1) + b1);  (a2, d2) = Sin(a1 W2 + b2 + cb[m / rows_per_group]);  P[M, 9 C] = a2 W3p
+ * x fp32 NHWC (C <= 3 or C in {4, 8, 12}); W1c: W1 as [(tap, c), 512] in indm_f16_chain_conv's Wc form; a1, d1, a2, d2: F16 [M, 512]
+ * outputs (all four are saved for the backward); needs M >= 32768 (64-row tiles).  Returns 1 if not covered. */
+int indm_f16_gnet(const float* x, const void* W1c, const float* b1, void* a1, void* d1, const void* W2p, const float* b2, const float* cb,
+                  int rows_per_group, void* a2, void* d2, const void* W3p, float* P, int Nimg, int H, int W, int C, void* stream);
+
 /* One Sin level of the hand-written iResBlock backward on F16 tensors (the F16 form of indm_ires_bwd_act_f32; replaces
  * autograd over iresblock.py:253-273's double backward): dp = da .* d - 4 pi^2 a .* (du .* t); seg (optional, fp32
  * [R / rows_per_seg][512]) = per-image column sums of dp.  rows_per_seg % 128 == 0 (indm_f16_bwd_act_ok), else returns 1. */
@@ -551,6 +559,7 @@ typedef struct {
   const void* W3t_bf16w;   /* W3_tapco_ci, rows zero-padded to 512, packed */
   /* bf16 = 2 and C <= 12, optional: W3_tapco_ci in indm_f16_chain_conv's Wc form -- the series iterations then run as one launch each */
   const void* W3t_thin_bf16w;
+  const void* W1_thin_bf16w;   /* optional, same form for W1 as [(tap,c), idim]: the g-net then runs as one launch (indm_f16_gnet) */
 } indm_iresblock_fwd_args;
 
 /* Backward of the training-mode block (replaces autograd's double backward through iresblock.py:264-273 and g's own

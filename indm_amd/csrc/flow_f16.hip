@@ -550,14 +550,19 @@ struct ChainConvArgs {
   const u16* Wc;     // packed [S][16][64][8]: Wc[s][nb][lane][e] = bf16(w[16 s + 8 (lane >> 5) + e][32 nb + (lane & 31)]), rows >= 9 C zero
   const u16* G;      // F16 [M, 512]: d2
   u16* T3;           // optional: the ungated convolution output (F16), as the thin kernel's gate epilogue stores it
-  u16* U2;           // optional: the gated convolution output (F16) -- the tile itself
+  u16* U2;           // optional: the gated convolution output (F16) -- the tile itself (EPI_ACT: the activation a1)
   int H, W, C, sign, S;
+  const float* cbias;   // EPI_ACT: the convolution's bias [512]; the cosine goes to T3
 };
+enum { CE_GATE = 0, CE_ACT = 1 };
 
 // T2OUT: the training step's LAST link also stores t3 = C3^T w (a.T3) and t2 = (t3 .* d2) W2T (a.r.O1) for the backward.
 // TAIL = R_GEMM (indm_f16_conv_gemm, the backward's  q1 = conv(q0, W1), q1 .* d1, du2 = (q1 .* d1) W2): the tile is followed by the
 // plain 64-row GEMM instead of the chain stages; the raw and the gated convolution outputs are stored too (a.T3, a.U2).
-template <int JB, int TMV, int SMAX, bool VEC4, bool T2OUT, int TAIL = R_CHAIN>
+// EPI = CE_ACT with TAIL = R_GEMM_ACT_THINN (indm_f16_gnet, the g-net of the block in one launch): the tile is the Sin activation
+// a1 = sin(2 pi p) / (2 pi), p = conv(a0, W1) + b1 (a1 -> a.U2, cos -> a.T3: the backward needs both), followed by
+// (a2, d2) = Sin(a1 W2 + b2 + cb[image]) and Pn = a2 W3 -- indm_f16_thin_conv(epilogue 1) + indm_f16_rows mode 5.
+template <int JB, int TMV, int SMAX, bool VEC4, bool T2OUT, int TAIL = R_CHAIN, int EPI = CE_GATE>
 __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvArgs a) {
   constexpr int MB = TMV / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -606,12 +611,14 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvA
   }
   // the d2 chunks of this wave's accumulators (HBM): requested behind the gathers, they fly under the convolution's MFMAs
   u32x4 gq[2][MB][2];
+  if constexpr (EPI == CE_GATE) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < MB; ++j)
+      for (int j = 0; j < MB; ++j)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) gq[i][j][s] = *(const u32x4*)(a.G + chunk(i, j, s));
+        for (int s = 0; s < 2; ++s) gq[i][j][s] = *(const u32x4*)(a.G + chunk(i, j, s));
+  }
   __syncthreads();
   // ---- (1) the tile of C3^T v: acc[i][j] = D[co = 32 (2 wave + i) + ..][pixel = 32 j + l31]
   f32x16 acc[2][MB];
@@ -638,9 +645,17 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvA
       }
     }
   }
-  // ---- (2) gate, round, store as operand fragments: chunk (m-block j, k-step 2 (2 wave + i) + s) of the A tile
+  // ---- (2) gate (or activate), round, store as operand fragments: chunk (m-block j, k-step 2 (2 wave + i) + s) of the A tile
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    float bv[16];
+    if constexpr (EPI == CE_ACT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *(const float4*)(a.cbias + 64 * wave + 32 * i + 8 * q + 4 * lhi);
+        bv[4 * q] = b.x; bv[4 * q + 1] = b.y; bv[4 * q + 2] = b.z; bv[4 * q + 3] = b.w;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < MB; ++j)
 #pragma unroll
@@ -648,22 +663,40 @@ __global__ __launch_bounds__(R_NW * 64, 4) void f16_chain_conv_kernel(ChainConvA
         float v[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * s + e];
-        if constexpr (T2OUT || TAIL == R_GEMM) {
-          if (a.T3) *(u32x4*)(a.T3 + chunk(i, j, s)) = pack8(v);
-        }
-        unpack8(gq[i][j][s], g);
+        u32x4 pk;
+        if constexpr (EPI == CE_ACT) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= g[e];
-        const u32x4 pk = pack8(v);
-        if constexpr (TAIL == R_GEMM) {
-          if (a.U2) *(u32x4*)(a.U2 + chunk(i, j, s)) = pk;
+          for (int e = 0; e < 8; ++e) sin_act(v[e] + bv[8 * s + e], v[e], g[e]);
+          *(u32x4*)(a.T3 + chunk(i, j, s)) = pack8(g);
+          pk = pack8(v);
+          *(u32x4*)(a.U2 + chunk(i, j, s)) = pk;
+        } else {
+          if constexpr (T2OUT || TAIL == R_GEMM) {
+            if (a.T3) *(u32x4*)(a.T3 + chunk(i, j, s)) = pack8(v);
+          }
+          unpack8(gq[i][j][s], g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= g[e];
+          pk = pack8(v);
+          if constexpr (TAIL == R_GEMM) {
+            if (a.U2) *(u32x4*)(a.U2 + chunk(i, j, s)) = pk;
+          }
         }
         *(u32x4*)(smem + (j * 32 + 2 * (2 * wave + i) + s) * 1024 + lane * 16) = pk;
       }
+  }
   __syncthreads();
   rows_tile<TAIL, JB, T2OUT, TMV, 4>(a.r, smem, tile, tid, lane, wave, l31, lhi);
 }
 
+template <int JB, int TMV, int SMAX, bool VEC4>
+int launch_gnet(const ChainConvArgs& a, hipStream_t st) {
+  constexpr int bytes = TMV * R_N * 2 + (TMV / 32) * SMAX * 1024;
+  if (indm_lds_optin<f16_chain_conv_kernel<JB, TMV, SMAX, VEC4, false, R_GEMM_ACT_THINN, CE_ACT>>(bytes) != INDM_OK) return INDM_E_LAUNCH;
+  hipLaunchKernelGGL((f16_chain_conv_kernel<JB, TMV, SMAX, VEC4, false, R_GEMM_ACT_THINN, CE_ACT>), dim3(a.r.M / TMV), dim3(R_NW * 64),
+                     bytes, st, a);
+  return hipGetLastError() == hipSuccess ? INDM_OK : INDM_E_LAUNCH;
+}
 template <int TMV, int SMAX, bool VEC4>
 int launch_conv_gemm(const ChainConvArgs& a, hipStream_t st) {
   constexpr int bytes = TMV * R_N * 2 + (TMV / 32) * SMAX * 1024;
@@ -1277,7 +1310,7 @@ INDM_API int indm_f16_chain_conv(const float* x, const void* Wc, const void* gat
   if (!al16(x) || !al16(Wc) || !al16(gate) || !al16(W2Tp) || !al16(D1) || !al16(Pp) || !al16(t3_out) || !al16(t2_out)) return INDM_E_ARG;
   if (t3_out && !t2_out) return INDM_E_ARG;   // (t3 is stored by the form that stores t2: the training step's last link)
   ChainConvArgs a = {{nullptr, (const u16*)W2Tp, (const u16*)D1, (const u16*)Pp, P, (u16*)t2_out, nullptr, nullptr, nullptr, (int)M, J, 1},
-                     x, (const u16*)Wc, (const u16*)gate, (u16*)t3_out, nullptr, H, W, C, sign, (9 * C + 15) >> 4};
+                     x, (const u16*)Wc, (const u16*)gate, (u16*)t3_out, nullptr, H, W, C, sign, (9 * C + 15) >> 4, nullptr};
   hipStream_t st = (hipStream_t)stream;
   const bool small = M / R_TM < 512;   // the tile rule of launch_rows
   if (C <= 3) return small ? launch_chain_conv<1, 32, 2, false>(a, st) : launch_chain_conv<1, 64, 2, false>(a, st);
@@ -1293,11 +1326,32 @@ INDM_API int indm_f16_conv_gemm(const float* x, const void* Wc, const void* gate
   if (!x || !Wc || !gate || !Wp || !out) return INDM_E_ARG;
   if (!al16(x) || !al16(Wc) || !al16(gate) || !al16(Wp) || !al16(out) || !al16(raw_out) || !al16(gated_out)) return INDM_E_ARG;
   ChainConvArgs a = {{nullptr, (const u16*)Wp, nullptr, nullptr, nullptr, (u16*)out, nullptr, nullptr, nullptr, (int)M, 0, 1},
-                     x, (const u16*)Wc, (const u16*)gate, (u16*)raw_out, (u16*)gated_out, H, W, C, sign, (9 * C + 15) >> 4};
+                     x, (const u16*)Wc, (const u16*)gate, (u16*)raw_out, (u16*)gated_out, H, W, C, sign, (9 * C + 15) >> 4, nullptr};
   hipStream_t st = (hipStream_t)stream;
   const bool small = M / R_TM < 512;
   if (C <= 3) return small ? launch_conv_gemm<32, 2, false>(a, st) : launch_conv_gemm<64, 2, false>(a, st);
   return small ? launch_conv_gemm<32, 7, true>(a, st) : launch_conv_gemm<64, 7, true>(a, st);
+}
+
+INDM_API int indm_f16_gnet(const float* x, const void* W1c, const float* b1, void* a1, void* d1, const void* W2p, const float* b2,
+                           const float* cb, int rows_per_group, void* a2, void* d2, const void* W3p, float* P, int Nimg, int H, int W,
+                           int C, void* stream) {
+  if (Nimg < 0 || H <= 0 || W <= 0 || C <= 0) return INDM_E_SHAPE;
+  if (Nimg == 0) return INDM_OK;
+  const long M = (long)Nimg * H * W;
+  const int J = 9 * C;
+  if (!(C <= 3 || (C <= 12 && !(C & 3))) || (M % R_TM) || M * C >= (1L << 31) || M >= (1L << 31) || M / R_TM < 512) return 1;
+  if (cb && (rows_per_group <= 0 || rows_per_group % R_TM)) return 1;
+  if (!x || !W1c || !b1 || !a1 || !d1 || !W2p || !a2 || !d2 || !W3p || !P) return INDM_E_ARG;
+  if (!al16(x) || !al16(W1c) || !al16(b1) || !al16(a1) || !al16(d1) || !al16(W2p) || !al16(b2) || !al16(cb) || !al16(a2) || !al16(d2) ||
+      !al16(W3p))
+    return INDM_E_ARG;
+  ChainConvArgs a = {{nullptr, (const u16*)W2p, nullptr, (const u16*)W3p, P, (u16*)a2, (u16*)d2, b2, cb, (int)M, J,
+                      rows_per_group > 0 ? rows_per_group : 1},
+                     x, (const u16*)W1c, nullptr, (u16*)d1, (u16*)a1, H, W, C, -1, (J + 15) >> 4, b1};
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 3) return launch_gnet<1, 64, 2, false>(a, st);
+  return launch_gnet<4, 64, 7, true>(a, st);
 }
 
 INDM_API long indm_f16_bwd_act_ok(long R, long rows_per_seg) {

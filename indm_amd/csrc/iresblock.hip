@@ -303,14 +303,25 @@ static bool covered16(int N, int H, int W, int C, int idim) {
 }
 
 // g(x, h) on F16 tensors: fills a0, d0 (preact, fp32), a1, d1, a2, d2 (F16) and g (fp32) [+ y = x + g]
-static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb, const float* W1, const void* W1p, const void* W2p,
-                    const void* W3p, const float* b1, const float* b2, const float* b3, float* a0, float* d0, void* a1, void* d1,
+static int g_pass16(const Ctx16& c, int preact, const float* x, const float* cb, const float* W1, const void* W1p, const void* W1thin,
+                    const void* W2p, const void* W3p, const float* b1, const float* b2, const float* b3, float* a0, float* d0, void* a1, void* d1,
                     void* a2, void* d2, float* Pn, float* g, float* y_res) {
   const long nC = c.M * c.C;
   const float* in = x;
   if (preact) {
     TRY(indm_sincos_act_fwd_f32(x, a0, d0, nC, c.st));
     in = a0;
+  }
+  // round 6: the whole g-net -- conv + Sin, GEMM + Sin, thin-N -- as ONE launch where the geometry allows (indm_f16_gnet)
+  static const int fuse_gnet = getenv("INDM_F16_GNET") ? atoi(getenv("INDM_F16_GNET")) : 1;
+  int fg = 1;
+  if (fuse_gnet && W1thin && !c.wide())
+    fg = indm_f16_gnet(in, W1thin, b1, a1, d1, W2p, b2, cb, c.H * c.W, a2, d2, W3p, Pn, c.N, c.H, c.W, c.C, c.st);
+  if (fg < 0) return fg;
+  if (fg == 0) {
+    if (y_res) TRY(indm_tap_gather_acc_f32(Pn, b3, nullptr, g, x, y_res, 1.0f, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
+    else TRY(indm_tap_gather_f32(Pn, b3, g, c.N, c.H, c.W, c.C, 1, 1.0f, c.st));
+    return 0;
   }
   TRY(c.thin(in, W1, W1p, b1, nullptr, a1, d1, -1, F16_ACT));                                // (a1, d1) = Sin(conv(a0, W1) + b1)
   // (a2, d2) = Sin(a1 W2 + b2 + cb[n]) and Pn = a2 W3 (the skinny-output convolution before its tap gather): one launch where the
@@ -353,7 +364,7 @@ static int fwd_logdet_f16(const indm_iresblock_fwd_args* a, void* stream) {
   if (!u2 || !Pn || !g || !v || !rws || (c.wide() && !c.colF) || (!a->training && (!a1 || !d2 || (a->preact && !d0))))
     return INDM_E_ARG;
   const int K = a->ncoeff;
-  TRY(g_pass16(c, a->preact, a->x, a->cb, a->W1, a->W1_bf16w, a->W2_bf16w, a->W3_bf16w, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2,
+  TRY(g_pass16(c, a->preact, a->x, a->cb, a->W1, a->W1_bf16w, a->W1_thin_bf16w, a->W2_bf16w, a->W3_bf16w, a->b1, a->b2, a->b3, a0, d0, a1, d1, a2, d2,
                Pn, g, a->y));
   const float* gate0 = a->preact ? d0 : nullptr;
   if (a->training) {

@@ -438,8 +438,8 @@ class ResidualFlow(nn.Module):
                         hip.pack_w2t_bf16([hip._packed_weight(Ws[blks.index(b)][2], "ci_tapco") for b in sc])
                         if hip.CHAIN_CONV["on"]:   # W3^T for the one-launch series iteration (indm_f16_chain_conv)
                             hip.pack_kpad_bf16([Ws[blks.index(b)][2] for b in sc], "w3t_thin")
-                            if self.training:   # ... and W1 for the backward's conv + gate + GEMM launch (indm_f16_conv_gemm)
-                                hip.pack_kpad_bf16([Ws[blks.index(b)][0] for b in sc], "w1_thin")
+                            # ... and W1 for the one-launch g-net (indm_f16_gnet) and the backward's conv + gate + GEMM launch
+                            hip.pack_kpad_bf16([Ws[blks.index(b)][0] for b in sc], "w1_thin")
                 elif hip.storage_dtype() == "bf16" and hip.f16_wide(C_) and I_ == 512:
                     # the 48-channel scale of the 64 x 64 flows on the F16 drivers (round 6): panels [idim, 9C -> 448] for the chain /
                     # thin-N stages, W1 and W3^T as K-padded GEMM operands for the convolutions on the im2col operand

@@ -134,6 +134,7 @@ _SIGS = {
     "indm_f16_tap_spread": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_chain_conv": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_conv_gemm": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "indm_f16_gnet": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "indm_f16_rows": [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "indm_f16_bwd_act_ok": [c_l, c_l],
     "indm_f16_bwd_act": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_l, c_p],
@@ -1527,6 +1528,20 @@ def f16_chain_conv(x, Wc, gate, W2Tp, D1, Pp, sign=1, want_t=False):
     return (P, t3, t2) if want_t else P
 
 
+def f16_gnet(x, W1c, b1, W2p, b2, cb, rows_per_group, W3p):
+    """indm_f16_gnet -> (a1, d1, a2, d2, P) (None if not covered)"""
+    N, H, W, C = x.shape
+    M = N * H * W
+    a1, d1, a2, d2 = (torch.empty(M * 512, dtype=torch.bfloat16, device=x.device) for _ in range(4))
+    P = torch.empty((M, 9 * C), dtype=torch.float32, device=x.device)
+    st = lib().indm_f16_gnet(_ptr(x), _ptr16(W1c), _ptr(b1), a1.data_ptr(), d1.data_ptr(), _ptr16(W2p), _ptr(b2), _ptr(cb), rows_per_group,
+                             a2.data_ptr(), d2.data_ptr(), _ptr16(W3p), _ptr(P), N, H, W, C, _stream())
+    if st == 1:
+        return None
+    _chk(st, "indm_f16_gnet")
+    return a1, d1, a2, d2, P
+
+
 def f16_conv_gemm(x, Wc, gate, Wp, sign=-1):
     """indm_f16_conv_gemm -> (out, raw, gated) F16 [N H W, 512] (None if not covered)"""
     N, H, W, C = x.shape
@@ -1861,7 +1876,7 @@ class _IResFwdArgs(ctypes.Structure):
                 + [("ncoeff", c_i)]
                 + [(n, c_p) for n in ("y", "logdet", "a0", "d0", "a1", "d1", "a2", "d2", "t3", "t2", "c1", "w")]
                 + [("ws", c_p), ("ws_floats", c_l), ("splitk_ws", c_p), ("splitk_ws_floats", c_l), ("timer", c_p)]
-                + [(n, c_p) for n in ("W2_bf16w", "panel_bf16w", "W3_bf16w", "W1_bf16w", "W3t_bf16w", "W3t_thin_bf16w")])
+                + [(n, c_p) for n in ("W2_bf16w", "panel_bf16w", "W3_bf16w", "W1_bf16w", "W3t_bf16w", "W3t_thin_bf16w", "W1_thin_bf16w")])
 
 
 class _IResBwdArgs(ctypes.Structure):
@@ -2028,8 +2043,8 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
             keep += [packed_kpad_bf16(W1, "w1"), packed_kpad_bf16(W3, "w3t")]
             a.W1_bf16w, a.W3t_bf16w = keep[-2].data_ptr(), keep[-1].data_ptr()
         elif CHAIN_CONV["on"]:
-            keep.append(packed_kpad_bf16(W3, "w3t_thin"))
-            a.W3t_thin_bf16w = keep[-1].data_ptr()
+            keep += [packed_kpad_bf16(W3, "w3t_thin"), packed_kpad_bf16(W1, "w1_thin")]
+            a.W3t_thin_bf16w, a.W1_thin_bf16w = keep[-2].data_ptr(), keep[-1].data_ptr()
     a.panel, a.b1, a.b2, a.b3, a.eps = _ptr(panel), _ptr(b1), _ptr(b2), _ptr(b3), _ptr(eps)
     cf = (ctypes.c_float * max(1, len(coeffs)))(*coeffs)
     a.coeffs, a.ncoeff = ctypes.cast(cf, c_p), len(coeffs)

@@ -152,6 +152,25 @@ def test_conv_gemm_is_the_thin_convolution_and_the_gemm_in_one_launch(N, H, W, C
         assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), name
 
 
+@pytest.mark.parametrize("N,H,W,C", [(32, 32, 32, 3), (128, 32, 32, 3), (128, 16, 16, 12)])
+def test_gnet_in_one_launch(N, H, W, C):
+    """indm_f16_gnet (conv + Sin, GEMM + Sin, thin-N) against indm_f16_thin_conv(epilogue 1) + indm_f16_rows mode 5: five outputs,
+    bit-identical."""
+    M, J = N * H * W, 9 * C
+    x, w1, b1 = rnd(N, H, W, C), rnd(J, 512, seed=1, scale=0.2), rnd(512, seed=7)
+    W2, b2, cb = rnd(512, 512, seed=4, scale=0.05), rnd(512, seed=8), rnd(N, 512, seed=9)
+    panel = rnd(512, J, seed=6, scale=0.1)
+    Wp = hip.pack_weight_bf16(W2.to(DEV))
+    Pp = hip.pack_weight_bf16(torch.nn.functional.pad(panel, (0, (32 if J <= 32 else 128) - J)).to(DEV))
+    a1, d1 = hip.f16_thin_conv(x.to(DEV), w1.to(DEV), -1, hip.F16_ACT, bias=b1.to(DEV))
+    a2, d2, P = hip.f16_rows(hip.F16_GEMM_ACT_THINN, a1, M, Wp=Wp, Pp=Pp, J=J, bias=b2.to(DEV), bias2=cb.to(DEV), rows_per_group=H * W)
+    got = hip.f16_gnet(x.to(DEV), hip.pack_thin_conv_bf16(w1.to(DEV)), b1.to(DEV), Wp, b2.to(DEV), cb.to(DEV), H * W, Pp)
+    assert got is not None
+    for g, r, name in zip(got[:4], (a1, d1, a2, d2), ("a1", "d1", "a2", "d2")):
+        assert torch.equal(g.view(torch.int16), r.view(torch.int16)), name
+    assert torch.equal(got[4], P)
+
+
 def test_chain_conv_declines_uncovered_geometry():
     z16 = torch.zeros(2048 * 512, dtype=torch.bfloat16, device=DEV)
     Wp = hip.pack_weight_bf16(rnd(512, 512).to(DEV))
