@@ -534,7 +534,10 @@ def run_training(args, cfg_name, batch, dtype, steps, warmup, rank, world, dev, 
         # links, another kernel: say so
         roof["kernel_class_chosen_on"] = roof["kernel"]
         roof["kernel"] = roof["kernel"][:-1] + ",f16_storage>"
-        roof["kernel_symbol"] = "f16_rows_kernel<CHAIN, ...> (csrc/flow_f16.hip), timed by the C-side launch timer of the block drivers"
+        roof["kernel_symbol"] = ("f16_chain_conv_kernel (csrc/flow_f16.hip, round 6: thin transposed convolution + d2 gate + chain link of one "
+                                 "series iteration in ONE launch; its FLOPs include the convolution's), timed by the C-side launch timer of "
+                                 "the block drivers" if getattr(hip, "CHAIN_CONV", {}).get("on") else
+                                 "f16_rows_kernel<CHAIN, ...> (csrc/flow_f16.hip), timed by the C-side launch timer of the block drivers")
     imgs_per_s = batch * world * steps / elapsed
     if roof is not None and n_bar is not None:
         # BASELINE.md section 3's definition: the WHOLE step at the realised n-bar (the dominant kernel above is ~13 % of it)
