@@ -1,4 +1,5 @@
-"""40 optimisation steps on a FIXED synthetic batch: the NLL objective must go down and stay finite (run on the GPU box)."""
+"""40 optimisation steps on a FIXED synthetic batch: the NLL objective must go down and stay finite (run on the GPU box).
+usage: train_sanity.py [f32|bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +11,7 @@ from bench import synthetic_batch
 dev = torch.device("cuda")
 cfg = configs.get_config("vp/CIFAR10/indm_nll")
 cfg.device = dev
+cfg.compute_dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
 torch.manual_seed(0)
 score = utils.create_model(cfg, dev)
 flow = create_flow_model(cfg).to(dev)
