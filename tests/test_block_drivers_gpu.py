@@ -102,6 +102,30 @@ def test_eval_logdet_and_inverse_drivers_match_op_level(drivers):
     assert (x1 - x0).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("B", [4, 32])
+def test_fused_f16_launches_are_bit_identical_at_the_flow_level(drivers, B):
+    """Round 6: with the thin-order weight packs the F16 drivers run a series iteration (indm_f16_chain_conv), the g-net
+    (indm_f16_gnet, batch >= 32: 64-row tiles) and the backward's conv + gate + GEMM (indm_f16_conv_gemm) as one launch each.  Each
+    kernel is bit-identical to the launches it replaces (tests/test_f16_gpu.py); here the whole flow: output, log-dets and every
+    parameter gradient must not change by a bit when the packs are withheld (hip.CHAIN_CONV off)."""
+    cfg, fl = _flow()
+    x = torch.rand(B, 3, 32, 32, device=DEV) * 2 - 1
+    was = hip.CHAIN_CONV["on"]
+    try:
+        hip.set_compute_dtype("bf16")
+        hip.f16_storage(True)
+        hip.CHAIN_CONV["on"] = True
+        z1, ld1, g1 = _train_pass(cfg, fl, x, True)
+        hip.CHAIN_CONV["on"] = False
+        z0, ld0, g0 = _train_pass(cfg, fl, x, True)
+    finally:
+        hip.CHAIN_CONV["on"] = was
+        hip.set_compute_dtype("f32")
+    assert torch.equal(z1, z0) and torch.equal(ld1, ld0) and set(g1) == set(g0) and len(g0) > 200
+    for n in g0:
+        assert torch.equal(g1[n], g0[n]), (n, (g1[n] - g0[n]).abs().max().item())
+
+
 def test_two_stream_backward_is_bit_identical(drivers):
     """indm_iresblock_bwd_args.side_stream (weight / bias gradients on a second stream, ordered by events): same kernels and
     arguments -> the same bits as the one-stream order, repeatedly (a missing event would show up as a run-to-run difference)."""
