@@ -184,7 +184,7 @@ INDM_API long indm_iresblock_ws_floats(int N, int H, int W, int C, int idim, int
     case 18: {  // backward, bf16 storage: five F16 [M, idim] buffers + the fp32 skinny side
       const long small = 6 * pad64((long)idim * (C > 12 ? 512 : 9 * C)) + pad64((long)N * idim) + pad64(idim);
       const long redb = pad64(indm_colreduce_ws_floats(M, C)) + pad64(indm_colreduce_ws_floats(N, idim));
-      return 5 * nH + 2 * nP + 5 * nC + small + redb + (C > 12 ? nH : 0) + 64;
+      return 6 * nH + 2 * nP + 5 * nC + small + redb + (C > 12 ? 2 * nH : 0) + 64;   // (+ dp1's own buffer / the side stream's spread operand)
     }
     case 0:  // forward, training: p, Pn, g, v, wtmp, vj + reductions
       return nW + nP + 4 * nC + red + 64;
@@ -480,6 +480,27 @@ INDM_API int indm_iresblock_fwd_logdet(const indm_iresblock_fwd_args* a, void* s
 }
 
 namespace {
+// Round 6, the "two-stream" form of the fp32 backward: the block's weight / bias gradients do not feed its data path, so they
+// are enqueued on a SIDE stream (args.side_stream, with its own split-K scratch) behind events recorded where their operands are
+// complete -- the HBM-bound thin weight gradients then run next to the MFMA-bound fused GEMMs of the data path, and the
+// MFMA-bound [512, 512] weight gradients next to the HBM-bound thin convolutions (fp32 MFMAs and memory streaming use
+// different parts of the CU; inside ONE stream every kernel waits for the previous one).  Same kernels, same arguments, same
+// results; the main stream waits for the side stream before the call returns (the scratch is the caller's).
+struct SideEvents {
+  hipEvent_t ev[7];
+  bool ok = false;
+  SideEvents() {
+    ok = true;
+    for (auto& e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  }
+};
+static SideEvents* side_events() {
+  static SideEvents* s = new SideEvents();   // (never destroyed: the HIP runtime may be gone at static-destructor time)
+  return s->ok ? s : nullptr;
+}
+}  // namespace
+
+namespace {
 // backward of the training-mode block on F16 tensors (args.bf16 == 2): the launch sequence of indm_iresblock_bwd with the
 // F16 kernels.  Differences in HOW: the thin convolution that produces q1 also writes q1 .* d1 (= dt2, the cotangent the
 // fp32 path takes from the Sin-level kernel), so the contraction behind it needs no gate; pre-gated operands replace
@@ -508,20 +529,56 @@ static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
   if (!bufA || !bufB || !bufC || !bufD || !bufE || !col || !Pn || !dvj || !q0 || !dd0 || !da0 || !tmpc || !qa || !qb || !qc ||
       !qd || !seg1 || !cr_c || !cr_n || (c.wide() && !c.colF))
     return INDM_E_ARG;
+  // ---- the side stream of the weight / bias gradients (SideEvents above): at the 16 x 16 scale and at the per-rank shards these
+  // launches are short and latency-bound -- next to the data path's they fill the chip instead of queueing behind it
+  SideEvents* se = (a->side_stream && a->side_splitk_ws && a->side_stream != stream) ? side_events() : nullptr;
+  Ctx16 w = c;
+  hipStream_t ms = (hipStream_t)stream, ss = ms;
   float* sk = a->splitk_ws;
-  const long skn = a->splitk_ws_floats;
+  long skn = a->splitk_ws_floats;
+  void* bufF = bufD;   // dp1: du2's buffer when everything runs in one stream
+  if (se) {
+    w.st = a->side_stream;
+    ss = (hipStream_t)a->side_stream;
+    sk = a->side_splitk_ws;
+    skn = a->side_splitk_ws_floats;
+    bufF = ws.get(nH);                       // du2 is still being read by the side stream's weight gradient when dp1 is written
+    if (c.wide()) w.colF = ws.get(nH);       // the spread operand of the side stream's weight gradients
+    if (!bufF || (c.wide() && !w.colF)) return INDM_E_ARG;
+  }
+  auto fork = [&](int i) -> int {
+    if (!se) return 0;
+    if (hipEventRecord(se->ev[i], ms) != hipSuccess || hipStreamWaitEvent(ss, se->ev[i], 0) != hipSuccess) return INDM_E_LAUNCH;
+    return 0;
+  };
+  auto join = [&]() -> int {
+    if (!se) return 0;
+    if (hipEventRecord(se->ev[6], ss) != hipSuccess || hipStreamWaitEvent(ms, se->ev[6], 0) != hipSuccess) return INDM_E_LAUNCH;
+    return 0;
+  };
+#define TRYJ(call)                                              \
+  do {                                                          \
+    int st_ = (call);                                           \
+    if (st_ != 0) {                                             \
+      (void)join();                                             \
+      return st_ < 0 ? st_ : INDM_E_SHAPE;                      \
+    }                                                           \
+  } while (0)
+  void* sst = w.st;
+  TRYJ(fork(0));   // the inputs of this call are complete on the main stream
   // ---- g path, level 3:  g = conv(a2, W3) + b3 ----
   void* da2 = bufA;
-  TRY(c.thin(a->gy, a->W3_tapco_ci, a->W3t_bf16w, nullptr, nullptr, da2, nullptr, 1, F16_PLAIN));          // da2 = C3^T gy
-  TRY(c.wgrad(a->gy, 1, col, a->a2, nullptr, qa, 1, sk, skn));                                             // a2^T spread(gy): [Cw, 9C]
-  TRY(indm_colreduce_f32(a->gy, nullptr, a->db3, c.M, C, 0, 1.0f, 0.0f, cr_c, stream));
+  TRYJ(c.thin(a->gy, a->W3_tapco_ci, a->W3t_bf16w, nullptr, nullptr, da2, nullptr, 1, F16_PLAIN));         // da2 = C3^T gy
+  TRYJ(w.wgrad(a->gy, 1, col, a->a2, nullptr, qa, 1, sk, skn));                                            // a2^T spread(gy): [Cw, 9C]
+  TRYJ(indm_colreduce_f32(a->gy, nullptr, a->db3, c.M, C, 0, 1.0f, 0.0f, cr_c, sst));
   // ---- reverse sweep of the last VJP chain ----
-  TRY(indm_scale_rows_f32(a->eps, a->gld, dvj, c.N, (long)rps * C, stream));
+  TRYJ(indm_scale_rows_f32(a->eps, a->gld, dvj, c.N, (long)rps * C, stream));
   const float* q0p = dvj;
   if (a->preact) {
-    TRY(indm_mul2_f32(dvj, a->d0, a->c1, q0, dd0, nC, stream));
+    TRYJ(indm_mul2_f32(dvj, a->d0, a->c1, q0, dd0, nC, stream));
     q0p = q0;
   }
+  TRYJ(fork(1));   // q0
   void *q1 = bufB, *q1g = bufC;
   // q1 = conv(q0, W1); q1g = q1 .* d1 (= dt2); du2 = q1g W2 -- ONE launch (indm_f16_conv_gemm) when W1's thin-order pack is given
   void* du2 = bufD;
@@ -529,57 +586,40 @@ static int bwd_f16(const indm_iresblock_bwd_args* a, void* stream) {
   int fcg = 1;
   if (fuse_cg && a->W1_thin_bf16w && !c.wide())
     fcg = indm_f16_conv_gemm(q0p, a->W1_thin_bf16w, a->d1, a->W2_bf16w, du2, q1, q1g, c.N, c.H, c.W, C, -1, stream);
-  if (fcg < 0) return fcg;
-  if (fcg == 1) TRY(c.thin(q0p, a->W1, a->W1_bf16w, nullptr, a->d1, q1g, q1, -1, F16_GATE));
-  TRY(c.wgrad(q0p, -1, col, a->t2, a->d1, qb, 1, sk, skn));                                                // (t2 .* d1)^T spread(q0)
+  if (fcg < 0) { (void)join(); return fcg; }
+  if (fcg == 1) TRYJ(c.thin(q0p, a->W1, a->W1_bf16w, nullptr, a->d1, q1g, q1, -1, F16_GATE));
+  TRYJ(w.wgrad(q0p, -1, col, a->t2, a->d1, qb, 1, sk, skn));                                               // (t2 .* d1)^T spread(q0)
   if (fcg == 1)
-    TRY(indm_f16_rows(F16R_GEMM, q1g, a->W2_bf16w, nullptr, nullptr, nullptr, du2, nullptr, nullptr, nullptr, Mi, 0, 1, stream));   // du2 = (q1 .* d1) W2
-  TRY(c.wgrad(a->w, 1, col, du2, a->d2, qc, 1, sk, skn));                                                  // (du2 .* d2)^T spread(w)
-  TRY(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, stream, ldq));
+    TRYJ(indm_f16_rows(F16R_GEMM, q1g, a->W2_bf16w, nullptr, nullptr, nullptr, du2, nullptr, nullptr, nullptr, Mi, 0, 1, stream));   // du2 = (q1 .* d1) W2
+  TRYJ(fork(2));   // q1g, du2
+  TRYJ(w.wgrad(a->w, 1, col, du2, a->d2, qc, 1, sk, skn));                                                 // (du2 .* d2)^T spread(w)
+  TRYJ(permute021_add(qa, qc, nullptr, a->dW3, Cw, 9, C, sst, ldq));
+  TRYJ(indm_f16_wgrad_gemm(a->t3, a->d2, q1g, a->dW2T, c.M, 1.0f, 0, sk, skn, sst));                        // dW2T = (t3 .* d2)^T (q1 .* d1)
   void* dp2 = bufE;
-  TRY(indm_f16_bwd_act(da2, du2, a->d2, a->a2, a->t3, dp2, a->dcb, c.M, rps, stream));
-  TRY(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  TRYJ(indm_f16_bwd_act(da2, du2, a->d2, a->a2, a->t3, dp2, a->dcb, c.M, rps, stream));
+  TRYJ(fork(3));   // dp2, dcb
+  TRYJ(indm_colreduce_f32(a->dcb, nullptr, a->db2, c.N, Cw, 0, 1.0f, 0.0f, cr_n, sst));
+  TRYJ(indm_f16_wgrad_gemm(a->a1, nullptr, dp2, a->dW2, c.M, 1.0f, 0, sk, skn, sst));                       // dW2 = a1^T dp2
   // ---- level 2:  p2 = a1 W2 + b2 + cb[image] ----
   void* da1 = bufA;
-  TRY(indm_f16_rows(F16R_GEMM, dp2, a->W2T_bf16w, nullptr, nullptr, nullptr, da1, nullptr, nullptr, nullptr, Mi, 0, 1, stream));  // da1 = dp2 W2^T
-  TRY(indm_f16_wgrad_gemm(a->a1, nullptr, dp2, a->dW2, c.M, 1.0f, 0, sk, skn, stream));                      // dW2 = a1^T dp2
-  void* dp1 = bufD;
-  TRY(indm_f16_bwd_act(da1, q1, a->d1, a->a1, a->t2, dp1, seg1, c.M, rps, stream));
-  TRY(indm_f16_wgrad_gemm(a->t3, a->d2, q1g, a->dW2T, c.M, 1.0f, 0, sk, skn, stream));                       // dW2T = (t3 .* d2)^T (q1 .* d1)
-  TRY(indm_colreduce_f32(seg1, nullptr, a->db1, c.N, Cw, 0, 1.0f, 0.0f, cr_n, stream));
+  TRYJ(indm_f16_rows(F16R_GEMM, dp2, a->W2T_bf16w, nullptr, nullptr, nullptr, da1, nullptr, nullptr, nullptr, Mi, 0, 1, stream));  // da1 = dp2 W2^T
+  void* dp1 = bufF;
+  TRYJ(indm_f16_bwd_act(da1, q1, a->d1, a->a1, a->t2, dp1, seg1, c.M, rps, stream));
+  TRYJ(fork(4));   // dp1, seg1
+  TRYJ(indm_colreduce_f32(seg1, nullptr, a->db1, c.N, Cw, 0, 1.0f, 0.0f, cr_n, sst));
   // ---- level 1:  p1 = conv(a0, W1) + b1 ----
-  TRY(indm_f16_rows(F16R_THINN, dp1, nullptr, nullptr, a->panel_bf16w, Pn, nullptr, nullptr, nullptr, nullptr, Mi, J, 1, stream));
-  TRY(indm_tap_gather_f32(Pn, nullptr, da0, c.N, c.H, c.W, C, -1, 1.0f, stream));
-  TRY(c.wgrad(a->a0, -1, col, dp1, nullptr, qd, 0, sk, skn));                                              // spread(a0)^T dp1: [9C, Cw]
-  TRY(permute021_add(qb, nullptr, qd, a->dW1, Cw, J, 1, stream, ldq));
+  TRYJ(indm_f16_rows(F16R_THINN, dp1, nullptr, nullptr, a->panel_bf16w, Pn, nullptr, nullptr, nullptr, nullptr, Mi, J, 1, stream));
+  TRYJ(indm_tap_gather_f32(Pn, nullptr, da0, c.N, c.H, c.W, C, -1, 1.0f, stream));
+  TRYJ(w.wgrad(a->a0, -1, col, dp1, nullptr, qd, 0, sk, skn));                                             // spread(a0)^T dp1: [9C, Cw]
+  TRYJ(permute021_add(qb, nullptr, qd, a->dW1, Cw, J, 1, sst, ldq));
   if (a->preact) {
-    TRY(indm_sincos_act_bwd_f32(da0, dd0, a->a0, a->d0, tmpc, nC, stream));
-    TRY(indm_axpby_f32(a->gy, tmpc, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+    TRYJ(indm_sincos_act_bwd_f32(da0, dd0, a->a0, a->d0, tmpc, nC, stream));
+    TRYJ(indm_axpby_f32(a->gy, tmpc, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
   } else {
-    TRY(indm_axpby_f32(a->gy, da0, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
+    TRYJ(indm_axpby_f32(a->gy, da0, a->dx, 1.0f, 1.0f, 0.0f, nC, stream));
   }
-  return INDM_OK;
-}
-}  // namespace
-
-namespace {
-// Round 6, the "two-stream" form of the fp32 backward: the block's weight / bias gradients do not feed its data path, so they
-// are enqueued on a SIDE stream (args.side_stream, with its own split-K scratch) behind events recorded where their operands are
-// complete -- the HBM-bound thin weight gradients then run next to the MFMA-bound fused GEMMs of the data path, and the
-// MFMA-bound [512, 512] weight gradients next to the HBM-bound thin convolutions (fp32 MFMAs and memory streaming use
-// different parts of the CU; inside ONE stream every kernel waits for the previous one).  Same kernels, same arguments, same
-// results; the main stream waits for the side stream before the call returns (the scratch is the caller's).
-struct SideEvents {
-  hipEvent_t ev[5];
-  bool ok = false;
-  SideEvents() {
-    ok = true;
-    for (auto& e : ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-  }
-};
-static SideEvents* side_events() {
-  static SideEvents* s = new SideEvents();   // (never destroyed: the HIP runtime may be gone at static-destructor time)
-  return s->ok ? s : nullptr;
+#undef TRYJ
+  return join() == 0 ? INDM_OK : INDM_E_LAUNCH;
 }
 }  // namespace
 

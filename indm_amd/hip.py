@@ -2081,6 +2081,9 @@ def iresblock_fwd(x, cb, W1, W2T, W3, panel, b1, b2, b3, eps, coeffs, preact, tr
 # 35 ms of the step's kernels do run concurrently and the step is 0.3 % SLOWER -- 85 % of the data path are MFMA-bound GEMMs, so
 # the side stream's GEMMs mostly share the MFMA pipe with them, and its HBM-bound launches take LDS / CU slots from them.
 BWD_STREAMS = {"on": os.environ.get("INDM_BWD_STREAMS", "0") == "1"}
+# the same for the bf16-storage (F16) backward driver, whose weight-gradient launches are short and latency-bound at the 16 x 16
+# scale and at the per-rank shards: INDM_BWD_STREAMS_F16
+BWD_STREAMS_F16 = {"on": os.environ.get("INDM_BWD_STREAMS_F16", "0") == "1"}
 _side = {}
 
 
@@ -2135,7 +2138,7 @@ def iresblock_bwd(gy, gld, saved, eps, W1, W2, W2T, W3, preact, panel=None):
     a.ws, a.ws_floats = ws.data_ptr(), n
     sk = _ws(SPLITK_WS_FLOATS, dev)
     a.splitk_ws, a.splitk_ws_floats = sk.data_ptr(), SPLITK_WS_FLOATS
-    if BWD_STREAMS["on"] and not f16 and not torch.cuda.is_current_stream_capturing():
+    if (BWD_STREAMS["on"] or (f16 and BWD_STREAMS_F16["on"])) and not torch.cuda.is_current_stream_capturing():
         side = _side_stream(dev)
         a.side_stream, a.side_splitk_ws, a.side_splitk_ws_floats = side[0].cuda_stream, side[1].data_ptr(), SPLITK_WS_FLOATS
     st = lib().indm_iresblock_bwd(ctypes.byref(a), _stream())

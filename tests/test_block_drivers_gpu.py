@@ -126,6 +126,30 @@ def test_fused_f16_launches_are_bit_identical_at_the_flow_level(drivers, B):
         assert torch.equal(g1[n], g0[n]), (n, (g1[n] - g0[n]).abs().max().item())
 
 
+@pytest.mark.parametrize("name", ["vp/CIFAR10/indm_nll", "vp/CELEBA/indm_fid"])
+def test_two_stream_f16_backward_is_bit_identical(drivers, name):
+    """the bf16-storage backward driver with its weight / bias gradients on the side stream (hip.BWD_STREAMS_F16): same bits, three
+    times in a row (CelebA: the wide 48-channel form has a spread operand per stream)."""
+    cfg, fl = _flow(name=name)
+    S = cfg.data.image_size
+    x = torch.rand(8, 3, S, S, device=DEV) * 2 - 1
+    was = hip.BWD_STREAMS_F16["on"]
+    try:
+        hip.set_compute_dtype("bf16")
+        hip.f16_storage(True)
+        hip.BWD_STREAMS_F16["on"] = False
+        z0, ld0, g0 = _train_pass(cfg, fl, x, True)
+        hip.BWD_STREAMS_F16["on"] = True
+        for _ in range(3):
+            z1, ld1, g1 = _train_pass(cfg, fl, x, True)
+            assert torch.equal(z1, z0) and torch.equal(ld1, ld0) and set(g1) == set(g0)
+            for n in g0:
+                assert torch.equal(g1[n], g0[n]), (n, (g1[n] - g0[n]).abs().max().item())
+    finally:
+        hip.BWD_STREAMS_F16["on"] = was
+        hip.set_compute_dtype("f32")
+
+
 def test_two_stream_backward_is_bit_identical(drivers):
     """indm_iresblock_bwd_args.side_stream (weight / bias gradients on a second stream, ordered by events): same kernels and
     arguments -> the same bits as the one-stream order, repeatedly (a missing event would show up as a run-to-run difference)."""
